@@ -1,0 +1,239 @@
+"""MI355X-native calc-witness path of circom-witnesscalc -- Python host-side mirror of the C-ABI.
+
+The product is `libcircom_witnesscalc_amd.so` (HIP kernels for gfx950 + C++ host, see csrc/ and
+include/*.h).  This module binds it with ctypes and mirrors the reference's Rust-level API names
+(reference src/lib.rs:114-247): `calc_witness`, `wtns_from_witness`, `deserialize_inputs`-equivalent
+`inputs_from_json`, plus the additive batch API.  torch is used only to hold device buffers.
+
+There is no CPU evaluation path: every witness value is computed by the HIP kernels; without the
+shared library or without a HIP device the calls raise.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcircom_witnesscalc_amd.so")
+_lib = None
+
+
+class GwStatus(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_int), ("error_msg", ctypes.c_void_p)]
+
+
+class GraphInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("n_nodes", "n_op", "n_input_nodes", "n_const", "n_inputs",
+                                                "n_witness", "depth", "algorithmic_bytes_per_set")]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("tile_width", ctypes.c_uint32), ("n_launches", ctypes.c_uint32), ("n_bundles", ctypes.c_uint64),
+                ("n_slots", ctypes.c_uint64), ("interp_ms", ctypes.c_float), ("pack_ms", ctypes.c_float)]
+
+
+class WitnessCalcError(RuntimeError):
+    pass
+
+
+EXPORTED_SYMBOLS = [
+    "gw_calc_witness", "gwb_graph_load", "gwb_graph_free", "gwb_graph_info", "gwb_graph_serialize",
+    "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
+    "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
+    "gwb_free_status",
+]
+
+
+def build(verbose=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WitnessCalcError("HIP extension %s is missing: run __graft_entry__.build() "
+                                   "(there is no CPU fallback)" % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64 (soname libamdhip64.so.7).  Loading
+        # torch first makes this library's NEEDED libamdhip64.so.7 resolve to that already-loaded copy; the
+        # other order would map a second runtime (system ROCm) next to torch's and torch then sees no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, u32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)
+        stp = ctypes.POINTER(GwStatus)
+        L.gw_calc_witness.restype = ctypes.c_int
+        L.gw_calc_witness.argtypes = [ctypes.c_char_p, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+        L.gwb_graph_load.restype = ctypes.c_int
+        L.gwb_graph_load.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
+        L.gwb_graph_free.argtypes = [vp]
+        L.gwb_graph_info.argtypes = [vp, ctypes.POINTER(GraphInfo)]
+        L.gwb_graph_serialize.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+        L.gwb_inputs_from_json.argtypes = [vp, ctypes.c_char_p, vp, stp]
+        L.gwb_set_tile_width.argtypes = [vp, ctypes.c_uint32]
+        L.gwb_calc_witness_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, stp]
+        L.gwb_calc_witness_batch_host.argtypes = [vp, vp, sz, vp, vp, stp]
+        L.gwb_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+        L.gwb_wtns_size.restype = sz
+        L.gwb_wtns_size.argtypes = [sz]
+        L.gwb_wtns_from_witness.argtypes = [vp, sz, vp]
+        L.gwb_graph_export.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+        L.gwb_graph_import.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
+        L.gwb_free_status.argtypes = [stp]
+        _lib = L
+    return _lib
+
+
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+
+
+def _take_status(st):
+    msg = ctypes.string_at(st.error_msg).decode("utf-8", "replace") if st.error_msg else ""
+    lib().gwb_free_status(ctypes.byref(st))
+    return msg
+
+
+def _check(rc, st):
+    msg = _take_status(st)
+    if rc != 0:
+        raise WitnessCalcError(msg or "call failed")
+
+
+def calc_witness_wtns(inputs_json, graph_data):
+    """gw_calc_witness (reference src/lib.rs:44-111): JSON text + `.bin` bytes -> `.wtns` bytes."""
+    if isinstance(inputs_json, str):
+        inputs_json = inputs_json.encode("utf-8")
+    graph_data = bytes(graph_data)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), GwStatus()
+    rc = lib().gw_calc_witness(inputs_json, graph_data, len(graph_data), ctypes.byref(out), ctypes.byref(n),
+                               ctypes.byref(st))
+    _check(rc, st)
+    data = ctypes.string_at(out.value, n.value)
+    _libc.free(out)
+    return data
+
+
+def calc_witness(inputs_json, graph_data):
+    """calc_witness (reference src/lib.rs:125-136): -> list[int] witness values."""
+    w = calc_witness_wtns(inputs_json, graph_data)
+    body = w[76:]
+    return [int.from_bytes(body[i:i + 32], "little") for i in range(0, len(body), 32)]
+
+
+def wtns_from_witness(witness):
+    """wtns_from_witness (reference src/lib.rs:114-123). witness: list[int] or uint8 array [W, 32]."""
+    if not isinstance(witness, np.ndarray):
+        witness = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in witness), dtype=np.uint8)
+    witness = np.ascontiguousarray(witness, dtype=np.uint8).reshape(-1, 32)
+    n = witness.shape[0]
+    out = np.zeros(lib().gwb_wtns_size(n), dtype=np.uint8)
+    if lib().gwb_wtns_from_witness(witness.ctypes.data, n, out.ctypes.data) != 0:
+        raise WitnessCalcError("gwb_wtns_from_witness failed")
+    return out.tobytes()
+
+
+class Graph:
+    """A parsed + compiled graph (deserialize_witnesscalc_graph, reference src/storage.rs:214-249), reusable
+    across calls -- the reference re-parses the `.bin` on every calc_witness (src/lib.rs:129)."""
+
+    def __init__(self, graph_data=None, _handle=None):
+        self._h = ctypes.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            graph_data = bytes(graph_data)
+            st = GwStatus()
+            rc = lib().gwb_graph_load(graph_data, len(graph_data), ctypes.byref(self._h), ctypes.byref(st))
+            _check(rc, st)
+        info = GraphInfo()
+        lib().gwb_graph_info(self._h, ctypes.byref(info))
+        for name, _ in GraphInfo._fields_:
+            setattr(self, name, int(getattr(info, name)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gwb_graph_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @classmethod
+    def from_blob(cls, blob):
+        """gwb_graph_import: build a replica from a compiled-program blob (what ranks receive over RCCL)."""
+        blob = bytes(blob)
+        h, st = ctypes.c_void_p(), GwStatus()
+        rc = lib().gwb_graph_import(blob, len(blob), ctypes.byref(h), ctypes.byref(st))
+        _check(rc, st)
+        return cls(_handle=h)
+
+    def export_blob(self, tile_width):
+        out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), GwStatus()
+        rc = lib().gwb_graph_export(self._h, tile_width, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        _check(rc, st)
+        data = ctypes.string_at(out.value, n.value)
+        _libc.free(out)
+        return data
+
+    def serialize(self):
+        """serialize_witnesscalc_graph (reference src/storage.rs:137-183)."""
+        out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), GwStatus()
+        rc = lib().gwb_graph_serialize(self._h, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        _check(rc, st)
+        data = ctypes.string_at(out.value, n.value)
+        _libc.free(out)
+        return data
+
+    def set_tile_width(self, t):
+        if lib().gwb_set_tile_width(self._h, t) != 0:
+            raise WitnessCalcError("tile width must be 0 or a power of two in 1..64")
+
+    def inputs_from_json(self, inputs_json):
+        """-> uint8 [n_inputs, 32] row (slot 0 = 1); reference src/lib.rs:195-247, 154-181."""
+        if isinstance(inputs_json, str):
+            inputs_json = inputs_json.encode("utf-8")
+        row = np.zeros((self.n_inputs, 32), dtype=np.uint8)
+        st = GwStatus()
+        rc = lib().gwb_inputs_from_json(self._h, inputs_json, row.ctypes.data, ctypes.byref(st))
+        _check(rc, st)
+        return row
+
+    def calc_witness_batch(self, inputs):
+        """Host buffers: inputs uint8 [B, n_inputs, 32] -> (witness uint8 [B, W, 32], status uint32 [B])."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+        b = inputs.shape[0]
+        assert inputs.shape[1:] == (self.n_inputs, 32), inputs.shape
+        wit = np.zeros((b, self.n_witness, 32), dtype=np.uint8)
+        status = np.zeros(b, dtype=np.uint32)
+        st = GwStatus()
+        rc = lib().gwb_calc_witness_batch_host(self._h, inputs.ctypes.data, b, wit.ctypes.data, status.ctypes.data,
+                                               ctypes.byref(st))
+        _check(rc, st)
+        return wit, status
+
+    def calc_witness_batch_device(self, d_inputs, d_witness, d_status, stream=None):
+        """Device-resident: torch uint8 cuda tensors [B, n_inputs, 32] -> [B, W, 32], int32/uint32 [B].
+        Asynchronous on `stream` (torch.cuda.Stream) or the current torch stream."""
+        import torch
+        b = d_inputs.shape[0]
+        assert d_inputs.is_cuda and d_witness.is_cuda and d_status.is_cuda
+        assert d_inputs.is_contiguous() and d_witness.is_contiguous() and d_status.is_contiguous()
+        assert tuple(d_inputs.shape[1:]) == (self.n_inputs, 32) and tuple(d_witness.shape) == (b, self.n_witness, 32)
+        s = stream if stream is not None else torch.cuda.current_stream()
+        st = GwStatus()
+        rc = lib().gwb_calc_witness_batch_device(self._h, d_inputs.data_ptr(), b, d_witness.data_ptr(),
+                                                 d_status.data_ptr(), s.cuda_stream, ctypes.byref(st))
+        _check(rc, st)
+
+    def last_timing(self):
+        t = Timing()
+        if lib().gwb_last_timing(self._h, ctypes.byref(t)) != 0:
+            raise WitnessCalcError("gwb_last_timing failed")
+        return {n: getattr(t, n) for n, _ in Timing._fields_}

@@ -1,0 +1,274 @@
+// BN254 scalar field (Fr) arithmetic for gfx950 lanes: 8 x u32 limbs, Montgomery form with R = 2^256.
+//
+// Semantics follow the reference's use of ark_bn254::Fr / ruint::U256 in src/graph.rs:102-144,
+// 188-197, 221-225, 621-769 (modulus src/field.rs:3-4).  The internal representation is free
+// (every exit of the reference goes through into_bigint, src/graph.rs:387): 32-bit limbs are used
+// here because the gfx950 integer multiplier is v_mad_u64_u32 (32x32+64 -> 64).
+//
+// The same header compiles for the host (g++) where the graph compiler converts constants.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FRD __host__ __device__ __forceinline__
+#else
+#define FRD inline
+#endif
+
+namespace cwc {
+
+struct Fr {
+    uint32_t v[8];
+};
+
+// r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+#define CWC_P0 0xf0000001u
+#define CWC_P1 0x43e1f593u
+#define CWC_P2 0x79b97091u
+#define CWC_P3 0x2833e848u
+#define CWC_P4 0x8181585du
+#define CWC_P5 0xb85045b6u
+#define CWC_P6 0xe131a029u
+#define CWC_P7 0x30644e72u
+#define CWC_INV32 0xefffffffu  // -r^-1 mod 2^32
+
+FRD Fr fr_p() { return Fr{{CWC_P0, CWC_P1, CWC_P2, CWC_P3, CWC_P4, CWC_P5, CWC_P6, CWC_P7}}; }
+// R mod r  (Montgomery form of 1)
+FRD Fr fr_one() { return Fr{{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u}}; }
+// R^2 mod r
+FRD Fr fr_r2() { return Fr{{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u}}; }
+// (r-1)/2  (reference src/graph.rs:720, halfM)
+FRD Fr fr_half() { return Fr{{0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u}}; }
+FRD Fr fr_zero() { return Fr{{0, 0, 0, 0, 0, 0, 0, 0}}; }
+
+FRD bool u256_is_zero(const Fr& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+}
+FRD bool u256_eq(const Fr& a, const Fr& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// r = a + b, returns carry out
+FRD uint32_t u256_add(Fr& r, const Fr& a, const Fr& b) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)c;
+}
+// r = a - b, returns borrow out (1 if a < b)
+FRD uint32_t u256_sub(Fr& r, const Fr& a, const Fr& b) {
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (int64_t)a.v[i] - (int64_t)b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;  // arithmetic: 0 or -1
+    }
+    return (uint32_t)(c & 1);
+}
+FRD bool u256_lt(const Fr& a, const Fr& b) {
+    Fr t;
+    return u256_sub(t, a, b) != 0;
+}
+FRD Fr u256_select(bool c, const Fr& a, const Fr& b) {  // c ? a : b
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
+// (a + b) mod r for a, b < r
+FRD Fr fr_add(const Fr& a, const Fr& b) {
+    Fr s, t;
+    u256_add(s, a, b);  // < 2^255, no carry out
+    uint32_t br = u256_sub(t, s, fr_p());
+    return u256_select(br != 0, s, t);
+}
+// (a - b) mod r
+FRD Fr fr_sub(const Fr& a, const Fr& b) {
+    Fr d, t;
+    uint32_t br = u256_sub(d, a, b);
+    u256_add(t, d, fr_p());
+    return u256_select(br != 0, t, d);
+}
+// reference src/graph.rs:188-194: 0 -> 0, else r - a   (identical in Montgomery form)
+FRD Fr fr_neg(const Fr& a) {
+    Fr t;
+    u256_sub(t, fr_p(), a);
+    return u256_select(u256_is_zero(a), a, t);
+}
+
+// Montgomery product a*b/2^256 mod r.  Requires b < r; a may be any value < 2^256
+// (result < r after one conditional subtraction since (a*b + m*r)/2^256 < b + r < 2r).
+FRD Fr fr_mul(const Fr& a, const Fr& b) {
+    const uint32_t p[8] = {CWC_P0, CWC_P1, CWC_P2, CWC_P3, CWC_P4, CWC_P5, CWC_P6, CWC_P7};
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c += (uint64_t)a.v[i] * b.v[j] + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[8] = (uint32_t)c;  // t < 2r + 2^32 r: fits 9 words
+        uint32_t m = t[0] * CWC_INV32;
+        c = (uint64_t)m * p[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            c += (uint64_t)m * p[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (uint32_t)c;  // quotient < 2r < 2^255: no ninth word after the shift
+    }
+    Fr r, s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+    uint32_t br = u256_sub(s, r, fr_p());
+    return u256_select(br != 0, r, s);
+}
+FRD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
+
+// canonical -> Montgomery (Fr::new): reduces any x < 2^256
+FRD Fr fr_to_mont(const Fr& x) { return fr_mul(x, fr_r2()); }
+// Montgomery -> canonical (into_bigint): Montgomery reduction of x alone
+FRD Fr fr_from_mont(const Fr& x) {
+    const uint32_t p[8] = {CWC_P0, CWC_P1, CWC_P2, CWC_P3, CWC_P4, CWC_P5, CWC_P6, CWC_P7};
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = x.v[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t m = t[0] * CWC_INV32;
+        uint64_t c = (uint64_t)m * p[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            c += (uint64_t)m * p[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[7] = (uint32_t)c;
+    }
+    Fr r, s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+    uint32_t br = u256_sub(s, r, fr_p());  // x < r  =>  result < r already; kept for x in [r, 2^256)
+    return u256_select(br != 0, r, s);
+}
+
+// a^-1 (Montgomery in, Montgomery out) by Fermat: a^(r-2).  a != 0 expected (0 -> 0).
+FRD Fr fr_inv_fermat(const Fr& a) {
+    // r - 2, most significant limb first
+    const uint32_t e[8] = {CWC_P7, CWC_P6, CWC_P5, CWC_P4, CWC_P3, CWC_P2, CWC_P1, CWC_P0 - 2u};
+    Fr acc = fr_one();
+    for (int w = 0; w < 8; ++w) {
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = fr_sqr(acc);
+            if ((e[w] >> bit) & 1u) acc = fr_mul(acc, a);
+        }
+    }
+    return acc;
+}
+
+// logical right shift of a 256-bit value by n in [0, 255]
+FRD Fr u256_shr(const Fr& x, uint32_t n) {
+    Fr a = x;
+    uint32_t w = n >> 5, s = n & 31;
+    if (w & 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.v[i] = (i + 4 < 8) ? a.v[i + 4] : 0;
+    }
+    if (w & 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.v[i] = (i + 2 < 8) ? a.v[i + 2] : 0;
+    }
+    if (w & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.v[i] = (i + 1 < 8) ? a.v[i + 1] : 0;
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t pair = ((uint64_t)(i + 1 < 8 ? a.v[i + 1] : 0) << 32) | a.v[i];
+        r.v[i] = (uint32_t)(pair >> s);
+    }
+    return r;
+}
+// left shift by n in [0, 255], bits past 2^256 dropped (ark-ff BigInt::muln)
+FRD Fr u256_shl(const Fr& x, uint32_t n) {
+    Fr a = x;
+    uint32_t w = n >> 5, s = n & 31;
+    if (w & 4) {
+#pragma unroll
+        for (int i = 7; i >= 0; --i) a.v[i] = (i - 4 >= 0) ? a.v[i - 4] : 0;
+    }
+    if (w & 2) {
+#pragma unroll
+        for (int i = 7; i >= 0; --i) a.v[i] = (i - 2 >= 0) ? a.v[i - 2] : 0;
+    }
+    if (w & 1) {
+#pragma unroll
+        for (int i = 7; i >= 0; --i) a.v[i] = (i - 1 >= 0) ? a.v[i - 1] : 0;
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        uint64_t pair = ((uint64_t)a.v[i] << 32) | (i - 1 >= 0 ? a.v[i - 1] : 0);
+        r.v[i] = (uint32_t)((pair << s) >> 32);
+    }
+    return r;
+}
+
+FRD uint32_t u256_bitlen(const Fr& a) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (a.v[i]) n = 32u * i + (32u - (uint32_t)__builtin_clz(a.v[i]));
+    return n;
+}
+
+// q = a / b, rem = a % b on canonical integers (ruint U256 / and %), b != 0.
+// Restoring shift-subtract from bit `top` (exclusive) downwards; callers pass top = bit length of a
+// (or a wave-wide maximum of it, so that control flow stays uniform).
+FRD void u256_divrem(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t top) {
+    // (rem : num) is one 512-bit shift register; num starts as a aligned so that bit top-1 is bit 255.
+    // All indices are static (runtime-indexed register arrays would spill to scratch on the GPU).
+    Fr num = top ? u256_shl(a, 256u - top) : fr_zero();
+    q = fr_zero();
+    rem = fr_zero();
+    for (uint32_t i = 0; i < top; ++i) {
+        uint32_t carry = num.v[7] >> 31;
+#pragma unroll
+        for (int k = 7; k > 0; --k) num.v[k] = (num.v[k] << 1) | (num.v[k - 1] >> 31);
+        num.v[0] <<= 1;
+        uint32_t ov = rem.v[7] >> 31;
+#pragma unroll
+        for (int k = 7; k > 0; --k) rem.v[k] = (rem.v[k] << 1) | (rem.v[k - 1] >> 31);
+        rem.v[0] = (rem.v[0] << 1) | carry;
+        Fr t;
+        uint32_t br = u256_sub(t, rem, b);
+        bool ge = (br == 0) || ov;  // ov: rem overflowed 2^256 (cannot happen for operands < r)
+        rem = u256_select(ge, t, rem);
+#pragma unroll
+        for (int k = 7; k > 0; --k) q.v[k] = (q.v[k] << 1) | (q.v[k - 1] >> 31);
+        q.v[0] = (q.v[0] << 1) | (ge ? 1u : 0u);
+    }
+}
+
+}  // namespace cwc

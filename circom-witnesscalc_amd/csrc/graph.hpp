@@ -1,0 +1,69 @@
+// Host-side graph IR and file formats of the calc-witness path.
+//
+// Mirrors the roles of the reference's src/graph.rs:37-59,174-178,209-212,236-245 (Node / Operation
+// types), src/storage.rs:137-249 (`wtns.graph.001` container), src/lib.rs:138-247 (inputs JSON,
+// inputs buffer) and src/lib.rs:114-123 (`.wtns` framing).  Function names follow the reference.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "fr_gfx950.hpp"
+#include "ops.h"
+
+namespace cwc {
+
+enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES = 4 };
+
+// graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into
+// Graph::const_values (canonical value, already reduced mod r as storage.rs:28 does on load).
+struct Node {
+    uint8_t kind;
+    uint8_t op;
+    uint32_t a, b, c;
+};
+
+struct InputSignal {  // InputSignalsInfo entry (reference src/lib.rs:19)
+    std::string name;
+    uint32_t offset, len;
+};
+
+struct Graph {
+    std::vector<Node> nodes;
+    std::vector<Fr> const_values;            // canonical (non-Montgomery) 256-bit little-endian limbs
+    std::vector<uint32_t> witness_signals;   // node index per witness element
+    std::vector<InputSignal> inputs;         // in file order
+    std::unordered_map<std::string, uint32_t> input_index;  // name -> position in `inputs`
+    uint64_t n_op = 0;                       // Uno + Duo + Tres nodes
+};
+
+// storage.rs:214-249.  Returns false and sets err on malformed data (the reference panics / returns io::Error).
+bool deserialize_witnesscalc_graph(const uint8_t* data, size_t len, Graph& g, std::string& err);
+// storage.rs:137-183
+std::vector<uint8_t> serialize_witnesscalc_graph(const Graph& g);
+
+// lib.rs:138-152
+size_t get_inputs_size(const Graph& g);
+// Size actually allocated for the inputs buffer: max(get_inputs_size, max(offset+len) over the input map,
+// 1 + max Input index anywhere) so that no access is out of range (reference would panic).
+size_t inputs_buffer_size(const Graph& g);
+
+typedef std::vector<std::pair<std::string, std::vector<Fr>>> InputList;  // insertion order, unique keys
+// lib.rs:195-247.  Error strings follow the reference's Error Debug output.
+bool deserialize_inputs(const char* json, size_t len, InputList& out, std::string& err);
+// lib.rs:177-181 + 154-168: buf = n_inputs x 32-byte canonical LE, buf[0] = 1.
+bool populate_inputs(const InputList& inputs, const Graph& g, uint8_t* buf, size_t n_inputs, std::string& err);
+
+// lib.rs:114-123: 76-byte header + 32*n bytes
+size_t wtns_size(size_t n_witness);
+void wtns_write_header(uint8_t* out, size_t n_witness);
+void wtns_from_witness(const uint8_t* witness32, size_t n_witness, uint8_t* out);
+
+// canonical reduction helpers (host)
+Fr u256_from_le_bytes_mod_order(const uint8_t* b, size_t n);
+bool u256_parse_dec(const std::string& s, Fr& out, std::string& err);
+
+}  // namespace cwc

@@ -1,0 +1,46 @@
+// Compiled program: what the host graph compiler hands to the HIP interpreter.
+//
+// A *tile* is T input sets evaluated by one 64-lane wavefront; the wave's lanes are (node slot j,
+// set t) with j in [0, G), G = 64/T, t in [0, T).  The op graph is level-scheduled by dependency
+// depth and, inside a level, grouped into same-class *bundles* of up to G independent nodes that one
+// wave-instruction stream evaluates at once (T = 64 degenerates to one node per bundle in node order,
+// i.e. the reference's sequential loop src/graph.rs:372-382 with lanes = input sets).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "graph.hpp"
+#include "program_dev.h"
+
+namespace cwc {
+
+struct ProgramStats {
+    uint64_t n_nodes = 0, n_op = 0, n_input_nodes = 0, n_const = 0, n_witness = 0;
+    uint64_t depth = 0;                 // dependency levels
+    uint64_t class_nodes[C_COUNT] = {0};
+    uint64_t class_bundles[C_COUNT] = {0};
+    uint64_t algorithmic_bytes_per_set = 0;  // 32*[sum_ops(arity+1) + 2*n_input_nodes + 2*W]  
+};
+
+struct Program {
+    uint32_t T = 0, G = 0;
+    uint32_t n_bundles = 0, n_slots = 0, n_const = 0, n_inputs = 0, n_witness = 0;
+    std::vector<uint32_t> hdr;           // [n_bundles]      class | count << 8
+    std::vector<uint32_t> recs;          // [n_bundles*G*4]  {subop, dst slot, a ref, b ref}
+    std::vector<uint32_t> crefs;         // [n_bundles*G]    third operand ref (C_TERN), else 0
+    std::vector<uint32_t> consts;        // [n_const*8]      Montgomery form
+    std::vector<uint32_t> witness_refs;  // [n_witness]      slot or REF_CONST|idx
+    ProgramStats stats;
+};
+
+// Validates the graph (backward references, evaluable ops, index ranges) and compiles it for tile width T
+// (power of two, 1..64).
+bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err);
+
+// pointer-free serialisation (what is broadcast between GPUs)
+std::vector<uint8_t> program_to_blob(const Program& p);
+bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string& err);
+
+}  // namespace cwc

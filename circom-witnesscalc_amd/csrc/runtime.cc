@@ -1,0 +1,562 @@
+// C-ABI runtime: gw_calc_witness (drop-in for reference src/lib.rs:44-111) and the additive batch API
+// (include/graph_witness_batch.h).  Everything numeric runs in the HIP kernels of kernels.hip; this file
+// parses, compiles, moves buffers and launches.  There is deliberately no CPU evaluation path.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define GW_NO_INLINE_FREE_STATUS
+#include "../../include/graph_witness_batch.h"
+#include "graph.hpp"
+#include "program.hpp"
+
+namespace cwc {
+hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void* inputs, uint32_t* status,
+                         uint32_t batch, hipStream_t stream);
+hipError_t launch_pack(uint32_t T, const ProgramDev& p, const void* vals, void* out, uint32_t batch, hipStream_t stream);
+}  // namespace cwc
+
+using namespace cwc;
+
+namespace {
+
+// prepare_status, reference src/lib.rs:28-38
+void set_status(gw_status_t* st, GW_ERROR_CODE code, const std::string& msg) {
+    if (!st) return;
+    st->code = code;
+    if (code == OK && msg.empty()) {
+        st->error_msg = nullptr;
+        return;
+    }
+    st->error_msg = (char*)malloc(msg.size() + 1);
+    if (st->error_msg) memcpy(st->error_msg, msg.c_str(), msg.size() + 1);
+}
+int fail(gw_status_t* st, const std::string& msg) {
+    set_status(st, ERROR, msg);
+    return 1;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e_);    \
+    } while (0)
+
+struct DeviceProgram {
+    Program host;
+    void* d_blob = nullptr;
+    ProgramDev dev{};
+};
+
+std::string upload_program(DeviceProgram& dp) {
+    const Program& p = dp.host;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_hdr = 0, o_recs = o_hdr + al(p.hdr.size() * 4), o_crefs = o_recs + al(p.recs.size() * 4),
+                 o_consts = o_crefs + al(p.crefs.size() * 4), o_wit = o_consts + al(p.consts.size() * 4 + 32),
+                 total = o_wit + al(p.witness_refs.size() * 4 + 4);
+    HIP_TRY(hipMalloc(&dp.d_blob, total));
+    char* d = (char*)dp.d_blob;
+    HIP_TRY(hipMemset(d, 0, total));
+    if (!p.hdr.empty()) HIP_TRY(hipMemcpy(d + o_hdr, p.hdr.data(), p.hdr.size() * 4, hipMemcpyHostToDevice));
+    if (!p.recs.empty()) HIP_TRY(hipMemcpy(d + o_recs, p.recs.data(), p.recs.size() * 4, hipMemcpyHostToDevice));
+    if (!p.crefs.empty()) HIP_TRY(hipMemcpy(d + o_crefs, p.crefs.data(), p.crefs.size() * 4, hipMemcpyHostToDevice));
+    if (!p.consts.empty()) HIP_TRY(hipMemcpy(d + o_consts, p.consts.data(), p.consts.size() * 4, hipMemcpyHostToDevice));
+    if (!p.witness_refs.empty()) HIP_TRY(hipMemcpy(d + o_wit, p.witness_refs.data(), p.witness_refs.size() * 4, hipMemcpyHostToDevice));
+    dp.dev.hdr = (const uint32_t*)(d + o_hdr);
+    dp.dev.recs = (const uint32_t*)(d + o_recs);
+    dp.dev.crefs = (const uint32_t*)(d + o_crefs);
+    dp.dev.consts = (const uint32_t*)(d + o_consts);
+    dp.dev.witness_refs = (const uint32_t*)(d + o_wit);
+    dp.dev.n_bundles = p.n_bundles;
+    dp.dev.n_slots = p.n_slots;
+    dp.dev.n_inputs = p.n_inputs;
+    dp.dev.n_witness = p.n_witness;
+    return "";
+}
+
+uint64_t workspace_budget() {
+    const char* e = getenv("CWC_WORKSPACE_GB");
+    double gb = e ? atof(e) : 48.0;
+    if (gb < 0.25) gb = 0.25;
+    return (uint64_t)(gb * (double)(1ull << 30));
+}
+
+}  // namespace
+
+struct gwb_graph {
+    Graph graph;
+    bool has_graph = false;
+    // metadata that exists for loaded and imported handles alike
+    std::vector<InputSignal> inputs;
+    std::unordered_map<std::string, uint32_t> input_index;
+    uint32_t n_inputs = 0, n_witness = 0;
+    ProgramStats stats;
+    std::map<uint32_t, std::unique_ptr<DeviceProgram>> progs;
+    uint32_t forced_T = 0;
+    void* d_vals = nullptr;
+    size_t vals_bytes = 0;
+    bool timing_pending = false;
+    gwb_timing_t timing{};
+    struct ChunkEvents { hipEvent_t start, after_interp, after_pack; };
+    std::vector<ChunkEvents> pending;  // HIP events of the last call, recorded on its launch stream
+    std::mutex mu;
+
+    void drop_events() {
+        for (auto& c : pending) { (void)hipEventDestroy(c.start); (void)hipEventDestroy(c.after_interp); (void)hipEventDestroy(c.after_pack); }
+        pending.clear();
+    }
+
+    ~gwb_graph() {
+        for (auto& kv : progs)
+            if (kv.second->d_blob) (void)hipFree(kv.second->d_blob);
+        if (d_vals) (void)hipFree(d_vals);
+        drop_events();
+    }
+};
+
+namespace {
+
+std::string check_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+               "); this library has no CPU fallback";
+    return "";
+}
+
+uint32_t pick_tile_width(const gwb_graph* g, size_t batch) {
+    if (!g->has_graph && !g->progs.empty()) return g->progs.begin()->first;  // imported: the one program it has
+    if (g->forced_T) return g->forced_T;
+    if (const char* e = getenv("CWC_TILE_WIDTH")) {
+        uint32_t t = (uint32_t)atoi(e);
+        if (t >= 1 && t <= 64 && !(t & (t - 1))) return t;
+    }
+    // Fill the chip's 1024 SIMDs with about two waves each before widening the tile.
+    uint32_t t = 1;
+    while (t < 64 && batch / (t * 2) >= 2048) t *= 2;
+    return t;
+}
+
+std::string get_program(gwb_graph* g, uint32_t T, DeviceProgram** out) {
+    auto it = g->progs.find(T);
+    if (it != g->progs.end()) {
+        *out = it->second.get();
+        return "";
+    }
+    if (!g->has_graph) return "imported graph handle has no program for tile width " + std::to_string(T);
+    std::unique_ptr<DeviceProgram> dp(new DeviceProgram());
+    std::string err;
+    if (!compile_program(g->graph, T, dp->host, err)) return err;
+    err = upload_program(*dp);
+    if (!err.empty()) return err;
+    *out = dp.get();
+    g->progs[T] = std::move(dp);
+    return "";
+}
+
+std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d_witness, uint32_t* d_status,
+                       hipStream_t stream) {
+    if (batch == 0) return "";
+    if (batch > 0x7fffffffull) return "batch too large";
+    const uint32_t T = pick_tile_width(g, batch);
+    DeviceProgram* dp = nullptr;
+    std::string err = get_program(g, T, &dp);
+    if (!err.empty()) return err;
+    const Program& p = dp->host;
+    // chunk the batch so that the value workspace stays within budget
+    const uint64_t bytes_per_tile = (uint64_t)p.n_slots * T * 32;
+    uint64_t max_tiles = workspace_budget() / (bytes_per_tile ? bytes_per_tile : 1);
+    if (max_tiles == 0) max_tiles = 1;
+    const uint64_t tiles_total = (batch + T - 1) / T;
+    const uint64_t chunk_tiles = tiles_total < max_tiles ? tiles_total : max_tiles;
+    const size_t need = (size_t)(chunk_tiles * bytes_per_tile);
+    if (need > g->vals_bytes) {
+        if (g->d_vals) HIP_TRY(hipFree(g->d_vals));
+        g->d_vals = nullptr;
+        g->vals_bytes = 0;
+        HIP_TRY(hipMalloc(&g->d_vals, need));
+        g->vals_bytes = need;
+    }
+    g->drop_events();
+    g->timing = gwb_timing_t{};
+    g->timing.tile_width = T;
+    g->timing.n_bundles = p.n_bundles;
+    g->timing.n_slots = p.n_slots;
+    HIP_TRY(hipMemsetAsync(d_status, 0, batch * sizeof(uint32_t), stream));
+    const size_t chunk_sets = (size_t)chunk_tiles * T;
+    for (size_t s0 = 0; s0 < batch; s0 += chunk_sets) {
+        const uint32_t nb = (uint32_t)((batch - s0) < chunk_sets ? (batch - s0) : chunk_sets);
+        hipEvent_t e0, e1, e2;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventCreate(&e2));
+        HIP_TRY(hipEventRecord(e0, stream));
+        HIP_TRY(launch_interp(T, dp->dev, g->d_vals, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream));
+        HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(launch_pack(T, dp->dev, g->d_vals, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
+        HIP_TRY(hipEventRecord(e2, stream));
+        g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});
+        g->timing.n_launches++;
+    }
+    g->timing_pending = true;
+    return "";
+}
+
+std::string run_host(gwb_graph* g, const void* inputs, size_t batch, void* witness, uint32_t* set_status) {
+    if (batch == 0) return "";
+    void *d_in = nullptr, *d_out = nullptr, *d_st = nullptr;
+    const size_t in_b = batch * (size_t)g->n_inputs * 32, out_b = batch * (size_t)g->n_witness * 32;
+    std::string err;
+    auto body = [&]() -> std::string {
+        HIP_TRY(hipMalloc(&d_in, in_b ? in_b : 32));
+        HIP_TRY(hipMalloc(&d_out, out_b ? out_b : 32));
+        HIP_TRY(hipMalloc(&d_st, batch * 4));
+        HIP_TRY(hipMemcpy(d_in, inputs, in_b, hipMemcpyHostToDevice));
+        std::string e = run_device(g, d_in, batch, d_out, (uint32_t*)d_st, nullptr);
+        if (!e.empty()) return e;
+        HIP_TRY(hipDeviceSynchronize());
+        if (out_b) HIP_TRY(hipMemcpy(witness, d_out, out_b, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(set_status, d_st, batch * 4, hipMemcpyDeviceToHost));
+        return "";
+    };
+    err = body();
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_st) (void)hipFree(d_st);
+    return err;
+}
+
+std::string set_status_text(uint32_t bits) {
+    std::string s;
+    if (bits & ST_SHL_OVERFLOW) s += "Shl result does not fit the field (reference panics at graph.rs:634)";
+    if (bits & ST_BITOP_EQ_R) s += std::string(s.empty() ? "" : "; ") + "bit operation result equals the modulus (reference panics at graph.rs:686/701/716)";
+    return s;
+}
+
+// ---- compiled-graph cache for the single-shot entry point (the reference re-parses per call, lib.rs:129) ----
+struct CacheEntry {
+    uint64_t hash;
+    size_t len;
+    std::shared_ptr<gwb_graph> g;
+};
+std::mutex g_cache_mu;
+std::vector<CacheEntry> g_cache;
+
+uint64_t fnv1a(const uint8_t* p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+int load_graph(const void* data, size_t len, gwb_graph** out, std::string& err) {
+    std::unique_ptr<gwb_graph> g(new gwb_graph());
+    if (!deserialize_witnesscalc_graph((const uint8_t*)data, len, g->graph, err)) return 1;
+    g->has_graph = true;
+    // validate by compiling the widest program's metadata (cheap) -- catches bad indices / Pow / Id early
+    Program probe;
+    if (!compile_program(g->graph, 64, probe, err)) return 1;
+    g->stats = probe.stats;
+    g->n_inputs = probe.n_inputs;
+    g->n_witness = probe.n_witness;
+    g->inputs = g->graph.inputs;
+    g->input_index = g->graph.input_index;
+    *out = g.release();
+    return 0;
+}
+
+bool quirks() {
+    const char* e = getenv("GW_REFERENCE_QUIRKS");
+    return e && *e && strcmp(e, "0") != 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// exported C symbols
+// =====================================================================================================
+extern "C" {
+
+void gwb_free_status(gw_status_t* status) {
+    if (status && status->error_msg) {
+        free(status->error_msg);
+        status->error_msg = nullptr;
+    }
+}
+
+int gwb_graph_load(const void* graph_data, size_t len, gwb_graph_t** out, gw_status_t* status) {
+    if (!graph_data) return fail(status, "graph_data is null");
+    if (len == 0) return fail(status, "graph_data_len is 0");
+    if (!out) return fail(status, "out is null");
+    std::string err;
+    if (load_graph(graph_data, len, out, err)) return fail(status, "Failed to load graph: " + err);
+    set_status(status, OK, "");
+    return 0;
+}
+
+void gwb_graph_free(gwb_graph_t* g) { delete g; }
+
+int gwb_graph_info(const gwb_graph_t* g, gwb_graph_info_t* info) {
+    if (!g || !info) return 1;
+    info->n_nodes = g->stats.n_nodes;
+    info->n_op = g->stats.n_op;
+    info->n_input_nodes = g->stats.n_input_nodes;
+    info->n_const = g->stats.n_const;
+    info->n_inputs = g->n_inputs;
+    info->n_witness = g->n_witness;
+    info->depth = g->stats.depth;
+    info->algorithmic_bytes_per_set = g->stats.algorithmic_bytes_per_set;
+    return 0;
+}
+
+int gwb_graph_serialize(const gwb_graph_t* g, void** out, size_t* out_len, gw_status_t* status) {
+    if (!g || !out || !out_len) return fail(status, "null argument");
+    if (!g->has_graph) return fail(status, "imported handle holds no graph to serialize");
+    std::vector<uint8_t> b = serialize_witnesscalc_graph(g->graph);
+    *out = malloc(b.size() ? b.size() : 1);
+    if (!*out) return fail(status, "out of memory");
+    memcpy(*out, b.data(), b.size());
+    *out_len = b.size();
+    set_status(status, OK, "");
+    return 0;
+}
+
+int gwb_inputs_from_json(const gwb_graph_t* g, const char* json, void* row, gw_status_t* status) {
+    if (!g || !json || !row) return fail(status, "null argument");
+    InputList list;
+    std::string err;
+    if (!deserialize_inputs(json, strlen(json), list, err)) return fail(status, "Failed to calculate witness: " + err);
+    Graph meta;  // populate_inputs only needs the input map
+    meta.inputs = g->inputs;
+    meta.input_index = g->input_index;
+    if (!populate_inputs(list, meta, (uint8_t*)row, g->n_inputs, err)) return fail(status, "Failed to calculate witness: " + err);
+    if (quirks())
+        for (const auto& kv : list) {  // lib.rs:162
+            const InputSignal& s = g->inputs[g->input_index.at(kv.first)];
+            printf("input %s, offset %u, len %u\n", kv.first.c_str(), s.offset, s.len);
+        }
+    set_status(status, OK, "");
+    return 0;
+}
+
+int gwb_set_tile_width(gwb_graph_t* g, uint32_t T) {
+    if (!g || T > 64 || (T & (T - 1))) return 1;
+    g->forced_T = T;
+    return 0;
+}
+
+int gwb_calc_witness_batch_device(gwb_graph_t* g, const void* d_inputs, size_t batch, void* d_witness,
+                                  uint32_t* d_set_status, void* hip_stream, gw_status_t* status) {
+    if (!g || (batch && (!d_inputs || !d_witness || !d_set_status))) return fail(status, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    std::string err = check_device();
+    if (err.empty()) err = run_device(g, d_inputs, batch, d_witness, d_set_status, (hipStream_t)hip_stream);
+    if (!err.empty()) return fail(status, err);
+    set_status(status, OK, "");
+    return 0;
+}
+
+int gwb_calc_witness_batch_host(gwb_graph_t* g, const void* inputs, size_t batch, void* witness, uint32_t* set_status_out,
+                                gw_status_t* status) {
+    if (!g || (batch && (!inputs || !witness || !set_status_out))) return fail(status, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    std::string err = check_device();
+    if (err.empty()) err = run_host(g, inputs, batch, witness, set_status_out);
+    if (!err.empty()) return fail(status, err);
+    set_status(status, OK, "");
+    return 0;
+}
+
+int gwb_last_timing(gwb_graph_t* g, gwb_timing_t* t) {
+    if (!g || !t) return 1;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->timing_pending) {
+        float interp = 0.f, pack = 0.f;
+        for (auto& c : g->pending) {
+            float a = 0.f, b = 0.f;
+            if (hipEventSynchronize(c.after_pack) != hipSuccess || hipEventElapsedTime(&a, c.start, c.after_interp) != hipSuccess ||
+                hipEventElapsedTime(&b, c.after_interp, c.after_pack) != hipSuccess)
+                return 1;
+            interp += a;
+            pack += b;
+        }
+        g->timing.interp_ms = interp;
+        g->timing.pack_ms = pack;
+        g->timing_pending = false;
+    }
+    *t = g->timing;
+    return 0;
+}
+
+size_t gwb_wtns_size(size_t n_witness) { return wtns_size(n_witness); }
+
+int gwb_wtns_from_witness(const void* row, size_t n_witness, void* out) {
+    if ((!row && n_witness) || !out) return 1;
+    wtns_from_witness((const uint8_t*)row, n_witness, (uint8_t*)out);
+    return 0;
+}
+
+int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, gw_status_t* status) {
+    if (!g || !blob || !blob_len) return fail(status, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    Program tmp;
+    const Program* p = nullptr;
+    auto it = g->progs.find(T);
+    std::string err;
+    if (it != g->progs.end()) {
+        p = &it->second->host;
+    } else {
+        if (!g->has_graph) return fail(status, "imported handle has no program for that tile width");
+        if (!compile_program(g->graph, T, tmp, err)) return fail(status, err);
+        p = &tmp;
+    }
+    std::vector<uint8_t> b = program_to_blob(*p);
+    // trailer: input map
+    auto put32 = [&](uint32_t v) { b.insert(b.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
+    while (b.size() % 8) b.push_back(0);
+    const size_t prog_len = b.size();
+    put32((uint32_t)g->inputs.size());
+    for (const InputSignal& s : g->inputs) {
+        put32(s.offset);
+        put32(s.len);
+        put32((uint32_t)s.name.size());
+        b.insert(b.end(), s.name.begin(), s.name.end());
+    }
+    uint64_t pl = prog_len;
+    b.insert(b.end(), (uint8_t*)&pl, (uint8_t*)&pl + 8);
+    *blob = malloc(b.size());
+    if (!*blob) return fail(status, "out of memory");
+    memcpy(*blob, b.data(), b.size());
+    *blob_len = b.size();
+    set_status(status, OK, "");
+    return 0;
+}
+
+int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_t* status) {
+    if (!blob || !out || len < 16) return fail(status, "bad blob");
+    const uint8_t* b = (const uint8_t*)blob;
+    uint64_t prog_len;
+    memcpy(&prog_len, b + len - 8, 8);
+    if (prog_len > len - 8) return fail(status, "bad blob trailer");
+    std::unique_ptr<gwb_graph> g(new gwb_graph());
+    std::unique_ptr<DeviceProgram> dp(new DeviceProgram());
+    std::string err;
+    // program_from_blob checks an exact size: find the unpadded length by trying the padded one minus 0..7
+    bool ok = false;
+    for (size_t pad = 0; pad < 8 && !ok; ++pad) ok = program_from_blob(b, (size_t)prog_len - pad, dp->host, err);
+    if (!ok) return fail(status, "bad program blob: " + err);
+    size_t pos = (size_t)prog_len;
+    auto get32 = [&](uint32_t& v) {
+        if (pos + 4 > len - 8) return false;
+        memcpy(&v, b + pos, 4);
+        pos += 4;
+        return true;
+    };
+    uint32_t n;
+    if (!get32(n)) return fail(status, "bad blob trailer");
+    for (uint32_t i = 0; i < n; ++i) {
+        InputSignal s;
+        uint32_t nl;
+        if (!get32(s.offset) || !get32(s.len) || !get32(nl) || pos + nl > len - 8) return fail(status, "bad blob trailer");
+        s.name.assign((const char*)b + pos, nl);
+        pos += nl;
+        g->input_index[s.name] = (uint32_t)g->inputs.size();
+        g->inputs.push_back(s);
+    }
+    g->stats = dp->host.stats;
+    g->n_inputs = dp->host.n_inputs;
+    g->n_witness = dp->host.n_witness;
+    err = check_device();
+    if (err.empty()) err = upload_program(*dp);
+    if (!err.empty()) return fail(status, err);
+    const uint32_t T = dp->host.T;
+    g->progs[T] = std::move(dp);
+    *out = g.release();
+    set_status(status, OK, "");
+    return 0;
+}
+
+// ---- the reference's symbol (src/lib.rs:44-111) ----------------------------------------------------
+int gw_calc_witness(const char* inputs, const void* graph_data, const size_t graph_data_len, void** wtns_data,
+                    size_t* wtns_len, const gw_status_t* status_c) {
+    gw_status_t* status = const_cast<gw_status_t*>(status_c);  // the reference writes through it too
+    if (!inputs) return fail(status, "inputs is null");                    // lib.rs:51-54
+    if (!graph_data) return fail(status, "graph_data is null");            // lib.rs:56-59
+    if (graph_data_len == 0) return fail(status, "graph_data_len is 0");   // lib.rs:61-64
+    if (!wtns_data || !wtns_len) return fail(status, "wtns_data or wtns_len is null");
+    // CStr::to_str UTF-8 check (lib.rs:72-84)
+    {
+        const unsigned char* s = (const unsigned char*)inputs;
+        size_t i = 0, n = strlen(inputs);
+        while (i < n) {
+            unsigned char c = s[i];
+            size_t k = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+            bool ok = k != 0 && i + k <= n;
+            for (size_t q = 1; ok && q < k; ++q) ok = (s[i + q] & 0xC0) == 0x80;
+            if (ok && k == 2) ok = c >= 0xC2;
+            if (ok && k == 3) ok = !(c == 0xE0 && s[i + 1] < 0xA0) && !(c == 0xED && s[i + 1] >= 0xA0);
+            if (ok && k == 4) ok = !(c == 0xF0 && s[i + 1] < 0x90) && !(c > 0xF4) && !(c == 0xF4 && s[i + 1] >= 0x90);
+            if (!ok) return fail(status, "Failed to parse inputs: invalid utf-8 sequence at byte " + std::to_string(i));
+            i += k;
+        }
+    }
+    // calc_witness (lib.rs:125-136): inputs first, then the graph
+    InputList list;
+    std::string err;
+    if (!deserialize_inputs(inputs, strlen(inputs), list, err)) return fail(status, "Failed to calculate witness: " + err);
+
+    std::shared_ptr<gwb_graph> g;
+    const uint64_t h = fnv1a((const uint8_t*)graph_data, graph_data_len);
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto& e : g_cache)
+            if (e.hash == h && e.len == graph_data_len) g = e.g;
+    }
+    if (!g) {
+        gwb_graph* raw = nullptr;
+        if (load_graph(graph_data, graph_data_len, &raw, err)) return fail(status, "Failed to calculate witness: " + err);
+        g.reset(raw);
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_cache.size() >= 4) g_cache.erase(g_cache.begin());
+        g_cache.push_back(CacheEntry{h, graph_data_len, g});
+    }
+    std::vector<uint8_t> row((size_t)g->n_inputs * 32), wit((size_t)g->n_witness * 32);
+    if (!populate_inputs(list, g->graph, row.data(), g->n_inputs, err)) return fail(status, "Failed to calculate witness: " + err);
+    if (quirks())
+        for (const auto& kv : list) {
+            const InputSignal& s = g->inputs[g->input_index.at(kv.first)];
+            printf("input %s, offset %u, len %u\n", kv.first.c_str(), s.offset, s.len);
+        }
+    uint32_t st = 0;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        err = check_device();
+        if (err.empty()) err = run_host(g.get(), row.data(), 1, wit.data(), &st);
+    }
+    if (!err.empty()) return fail(status, "Failed to calculate witness: " + err);
+    if (st) return fail(status, "Failed to calculate witness: " + set_status_text(st));
+    const size_t n = wtns_size(g->n_witness);
+    void* buf = malloc(n);
+    if (!buf) return fail(status, "Failed to allocate memory for wtns_data");  // lib.rs:99-102
+    wtns_from_witness(wit.data(), g->n_witness, (uint8_t*)buf);
+    *wtns_len = n;
+    *wtns_data = buf;
+    if (quirks()) {
+        set_status(status, ERROR, "test error");  // lib.rs:106
+        printf("OK\n");                            // lib.rs:108
+    } else {
+        set_status(status, OK, "");
+    }
+    return 0;
+}
+
+}  // extern "C"

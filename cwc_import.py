@@ -1,0 +1,21 @@
+"""Import helper: the package directory is `circom-witnesscalc_amd/` (hyphenated, per the repo layout
+contract), which is not a valid Python identifier -- load it under the module name
+`circom_witnesscalc_amd`."""
+import importlib.util
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+_NAME = "circom_witnesscalc_amd"
+
+
+def load():
+    if _NAME in sys.modules:
+        return sys.modules[_NAME]
+    pkg_dir = os.path.join(_ROOT, "circom-witnesscalc_amd")
+    spec = importlib.util.spec_from_file_location(_NAME, os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod

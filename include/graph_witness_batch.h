@@ -1,0 +1,88 @@
+/* Additive batch C-ABI: many independent input sets for one graph, evaluated on an MI355X.
+ *
+ * The reference has no batch entry point: calc_witness (src/lib.rs:125-136) re-parses the graph and
+ * evaluates one input set per call.  These functions split that call into its stages so that the graph
+ * is parsed/compiled once (replaces storage.rs:214-249 per call), inputs and witnesses stay resident in
+ * HBM (replaces graph::evaluate, src/graph.rs:367-391, per set) and `.wtns` framing (src/lib.rs:114-123)
+ * is applied per set on demand.  The single-shot symbol gw_calc_witness is unchanged.
+ *
+ * Plain pointers and sizes only.  All functions return 0 on success, 1 on failure with status filled as
+ * in graph_witness.h (status may be NULL).
+ */
+#ifndef CWC_AMD_GRAPH_WITNESS_BATCH_H
+#define CWC_AMD_GRAPH_WITNESS_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "graph_witness.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gwb_graph gwb_graph_t;
+
+typedef struct {
+  uint64_t n_nodes;          /* nodes in the .bin */
+  uint64_t n_op;             /* Op + UnoOp + TresOp nodes (field-ops per input set) */
+  uint64_t n_input_nodes;    /* Input nodes */
+  uint64_t n_const;          /* constant nodes */
+  uint64_t n_inputs;         /* length of the inputs buffer (slot 0 = 1), reference src/lib.rs:138-152 */
+  uint64_t n_witness;        /* witness elements per set */
+  uint64_t depth;            /* dependency levels */
+  uint64_t algorithmic_bytes_per_set; /* 32*[sum_ops(arity+1) + 2*n_input_nodes + 2*n_witness] */
+} gwb_graph_info_t;
+
+typedef struct {
+  uint32_t tile_width;       /* input sets per wavefront used by the last call */
+  uint32_t n_launches;       /* interpreter launches of the last call (chunks) */
+  uint64_t n_bundles;        /* wave-instruction bundles per tile */
+  uint64_t n_slots;          /* value slots per set */
+  float interp_ms;           /* HIP-event time of the interpreter kernel(s), on the launch stream */
+  float pack_ms;             /* HIP-event time of the witness pack kernel(s) */
+} gwb_timing_t;
+
+/* Parse + validate a `wtns.graph.001` image (deserialize_witnesscalc_graph, src/storage.rs:214-249). */
+int gwb_graph_load(const void *graph_data, size_t graph_data_len, gwb_graph_t **out, gw_status_t *status);
+void gwb_graph_free(gwb_graph_t *g);
+int gwb_graph_info(const gwb_graph_t *g, gwb_graph_info_t *info);
+/* Re-serialize the loaded graph (serialize_witnesscalc_graph, src/storage.rs:137-183): *out is malloc'ed. */
+int gwb_graph_serialize(const gwb_graph_t *g, void **out, size_t *out_len, gw_status_t *status);
+
+/* JSON -> one inputs row of n_inputs x 32 bytes, canonical little-endian, row[0] = 1
+ * (deserialize_inputs + get_inputs_buffer + populate_inputs, src/lib.rs:195-247, 177-181, 154-168). */
+int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *row, gw_status_t *status);
+
+/* 0 = choose from the batch size (default); else a power of two in 1..64 */
+int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
+
+/* Evaluate `batch` input sets resident in device memory (graph::evaluate per set, src/graph.rs:367-391).
+ *   d_inputs  : [batch][n_inputs][32 B] canonical LE
+ *   d_witness : [batch][n_witness][32 B] canonical LE (= the .wtns section-2 body of each set)
+ *   d_set_status : [batch] u32, 0 = ok, bit0 = Shl overflow, bit1 = bit-op result == r (reference panics)
+ *   hip_stream: hipStream_t or NULL.  Asynchronous: returns after enqueueing. */
+int gwb_calc_witness_batch_device(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
+                                  uint32_t *d_set_status, void *hip_stream, gw_status_t *status);
+/* Same with host buffers (copies in/out, synchronous). */
+int gwb_calc_witness_batch_host(gwb_graph_t *g, const void *inputs, size_t batch, void *witness,
+                                uint32_t *set_status, gw_status_t *status);
+/* Kernel times of the last batch call on this handle (synchronizes on its events). */
+int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
+
+/* `.wtns` framing of one witness row (wtns_from_witness, src/lib.rs:114-123): out holds gwb_wtns_size bytes. */
+size_t gwb_wtns_size(size_t n_witness);
+int gwb_wtns_from_witness(const void *witness_row, size_t n_witness, void *out);
+
+/* Compiled-program exchange between the GPUs of a node: rank 0 exports a pointer-free blob, the caller
+ * moves it (RCCL broadcast over xGMI), the other ranks import it instead of re-parsing the .bin. */
+int gwb_graph_export(gwb_graph_t *g, uint32_t tile_width, void **blob, size_t *blob_len, gw_status_t *status);
+int gwb_graph_import(const void *blob, size_t blob_len, gwb_graph_t **out, gw_status_t *status);
+
+/* exported twin of the header-inline gw_free_status, for FFI callers that cannot use the inline */
+void gwb_free_status(gw_status_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWC_AMD_GRAPH_WITNESS_BATCH_H */
