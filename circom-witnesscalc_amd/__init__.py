@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "gw_calc_witness", "gwb_graph_load", "gwb_graph_free", "gwb_graph_info", "gwb_graph_serialize",
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
-    "gwb_free_status",
+    "gwb_free_status", "gwb_profile_classes",
 ]
 
 
@@ -87,6 +87,7 @@ def lib():
         L.gwb_graph_export.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
         L.gwb_graph_import.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
         L.gwb_free_status.argtypes = [stp]
+        L.gwb_profile_classes.argtypes = [vp, vp, sz, vp, vp, vp, stp]
         _lib = L
     return _lib
 
@@ -231,6 +232,16 @@ class Graph:
         rc = lib().gwb_calc_witness_batch_device(self._h, d_inputs.data_ptr(), b, d_witness.data_ptr(),
                                                  d_status.data_ptr(), s.cuda_stream, ctypes.byref(st))
         _check(rc, st)
+
+    def profile_classes(self, d_inputs, d_witness, d_status):
+        """Diagnostic stamped build: {class: (load_cycles, compute_cycles, store_cycles, bundles)} per sampled wave."""
+        out = np.zeros(36, dtype=np.uint64)
+        st = GwStatus()
+        rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),
+                                       d_status.data_ptr(), out.ctypes.data, ctypes.byref(st))
+        _check(rc, st)
+        names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN"]
+        return {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
 
     def last_timing(self):
         t = Timing()

@@ -25,9 +25,13 @@ __device__ __forceinline__ Fr fr_from_u4(const uint4& lo, const uint4& hi) {
 // wave-wide OR-reduction of a predicate ("does any lane need the slow path")
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
-template <int T>
+// PROF = true is a diagnostic build (gwb_profile_classes): s_memtime stamps around the operand loads, the
+// arithmetic and the store of every bundle, summed per bundle class by lane 0 of every 64th tile.  Its
+// waits serialise the loop, so read its shares, not its length; no stamp executes in the product kernel.
+template <int T, bool PROF>
 __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, const uint4* __restrict__ inputs,
-                                                    uint32_t* __restrict__ status, uint32_t batch) {
+                                                    uint32_t* __restrict__ status, uint32_t batch,
+                                                    unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
     const int lane = (int)threadIdx.x;
     const int t = lane % T;
@@ -48,15 +52,47 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
         return fr_from_u4(lo, hi);
     };
     uint32_t err_bits = 0;
+    unsigned long long pf[C_COUNT][4];
+    if (PROF) {
+#pragma unroll
+        for (int c = 0; c < (int)C_COUNT; ++c) pf[c][0] = pf[c][1] = pf[c][2] = pf[c][3] = 0;
+    }
+    auto stamp = [&]() -> unsigned long long {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
 
+    // Software pipeline: the header and the records of bundle b+1 are fetched while bundle b computes, so
+    // that only the operand loads (which depend on earlier stores) sit on the critical path.
+    uint32_t h_next = p.n_bundles ? p.hdr[0] : 0u;
+    uint4 rec_next = p.n_bundles ? recs[j] : make_uint4(0, 0, 0, 0);
     for (uint32_t b = 0; b < p.n_bundles; ++b) {
-        const uint32_t h = p.hdr[b];
+        const uint32_t h = h_next;
+        const uint4 rec = rec_next;
+        {
+            const uint32_t nb = b + 1 < p.n_bundles ? b + 1 : b;
+            h_next = p.hdr[nb];
+            rec_next = recs[(size_t)nb * G + j];
+        }
         const uint32_t cls = h & 0xffu;
         const uint32_t cnt = h >> 8;
-        const uint4 rec = recs[(size_t)b * G + j];
         const bool active = (uint32_t)j < cnt;  // inactive node slots carry a copy of record 0 (valid operands)
         const uint32_t sub = rec.x;
         Fr r;
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+        if (PROF) {
+            ts0 = stamp();
+            // touch the operands so that their loads complete before ts1
+            if (cls != C_INPUT) {
+                const Fr a0 = load(rec.z), c0 = load(rec.w);
+                asm volatile("" ::"v"(a0.v[0]), "v"(c0.v[7]));
+            }
+            ts1 = stamp();
+        }
         switch (cls) {
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + rec.z) * 2;
@@ -70,16 +106,16 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
             }
             case C_LIN: {  // graph.rs:110-111 Add/Sub, :188-194 Neg (= 0 - a)
                 const Fr a = load(rec.z), c = load(rec.w);  // Neg records carry b = a
+                // one modular addition: x + (+-y), with -y = r - y (0 stays 0)
                 const bool is_neg = sub == SUB_NEG;
                 const Fr x = u256_select(is_neg, fr_zero(), a);
                 const Fr y = u256_select(is_neg, a, c);
-                const Fr s = fr_add(x, y), d = fr_sub(x, y);
-                r = u256_select(sub == OP_ADD, s, d);
+                r = fr_add(x, u256_select(sub == OP_ADD, y, fr_neg(y)));
                 break;
             }
             case C_DIV: {  // graph.rs:109  b == 0 -> 0 else a / b
                 const Fr a = load(rec.z), c = load(rec.w);
-                const Fr inv = fr_inv_fermat(c);  // 0^(r-2) = 0
+                const Fr inv = fr_inv(c);  // safegcd divsteps; inv(0) = 0
                 r = u256_select(u256_is_zero(c), fr_zero(), fr_mul(a, inv));
                 break;
             }
@@ -161,6 +197,10 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
             }
             default: r = fr_zero(); break;
         }
+        if (PROF) {
+            asm volatile("" ::"v"(r.v[0]), "v"(r.v[7]));
+            ts2 = stamp();
+        }
         if (active) {
             uint4* q = tv + (size_t)rec.y * (2 * T) + t;
             q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
@@ -169,6 +209,23 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
         // Later bundles read these stores from other lanes of this wave; a wave's vector-memory
         // instructions execute in order, the fence only keeps the compiler from reordering them.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (PROF) {
+            const unsigned long long ts3 = stamp();
+#pragma unroll
+            for (int c = 0; c < (int)C_COUNT; ++c)
+                if (cls == (uint32_t)c) {
+                    pf[c][0] += ts1 - ts0;
+                    pf[c][1] += ts2 - ts1;
+                    pf[c][2] += ts3 - ts2;
+                    pf[c][3] += 1;
+                }
+        }
+    }
+    if (PROF && lane == 0 && (tile % 64u) == 0u) {
+#pragma unroll
+        for (int c = 0; c < (int)C_COUNT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&prof[c * 4 + q], pf[c][q]);
     }
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }
@@ -198,21 +255,21 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, const uint4* __
 
 // ---- launchers (called from runtime.cc) -----------------------------------------------------------
 hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void* inputs, uint32_t* status,
-                         uint32_t batch, hipStream_t stream) {
+                         uint32_t batch, hipStream_t stream, unsigned long long* prof) {
     const uint32_t tiles = (batch + T - 1) / T;
     dim3 grid(tiles), block(64);
     uint4* v = (uint4*)vals;
     const uint4* in = (const uint4*)inputs;
+#define CWC_LAUNCH(TT)                                                                               \
+    case TT:                                                                                         \
+        if (prof) interp_kernel<TT, true><<<grid, block, 0, stream>>>(p, v, in, status, batch, prof); \
+        else interp_kernel<TT, false><<<grid, block, 0, stream>>>(p, v, in, status, batch, nullptr);  \
+        break;
     switch (T) {
-        case 1: interp_kernel<1><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
-        case 2: interp_kernel<2><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
-        case 4: interp_kernel<4><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
-        case 8: interp_kernel<8><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
-        case 16: interp_kernel<16><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
-        case 32: interp_kernel<32><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
-        case 64: interp_kernel<64><<<grid, block, 0, stream>>>(p, v, in, status, batch); break;
+        CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32) CWC_LAUNCH(64)
         default: return hipErrorInvalidValue;
     }
+#undef CWC_LAUNCH
     return hipGetLastError();
 }
 

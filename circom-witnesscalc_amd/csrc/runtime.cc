@@ -19,7 +19,7 @@
 
 namespace cwc {
 hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void* inputs, uint32_t* status,
-                         uint32_t batch, hipStream_t stream);
+                         uint32_t batch, hipStream_t stream, unsigned long long* prof);
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const void* vals, void* out, uint32_t batch, hipStream_t stream);
 }  // namespace cwc
 
@@ -103,6 +103,7 @@ struct gwb_graph {
     size_t vals_bytes = 0;
     bool timing_pending = false;
     gwb_timing_t timing{};
+    unsigned long long* d_prof = nullptr;  // diagnostic per-class stamps (gwb_profile_classes), else null
     struct ChunkEvents { hipEvent_t start, after_interp, after_pack; };
     std::vector<ChunkEvents> pending;  // HIP events of the last call, recorded on its launch stream
     std::mutex mu;
@@ -198,7 +199,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
         HIP_TRY(hipEventRecord(e0, stream));
-        HIP_TRY(launch_interp(T, dp->dev, g->d_vals, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream));
+        HIP_TRY(launch_interp(T, dp->dev, g->d_vals, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_pack(T, dp->dev, g->d_vals, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
         HIP_TRY(hipEventRecord(e2, stream));
@@ -394,6 +395,27 @@ int gwb_last_timing(gwb_graph_t* g, gwb_timing_t* t) {
         g->timing_pending = false;
     }
     *t = g->timing;
+    return 0;
+}
+
+int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void* d_witness, uint32_t* d_set_status,
+                        uint64_t* out36, gw_status_t* status) {
+    // Diagnostic: one batch through the stamped interpreter build; out36[class*4 + {load, compute, store, count}]
+    // in shader cycles, summed over the sampled waves (lane 0 of every 64th tile).
+    if (!g || !out36) return fail(status, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    std::string err = check_device();
+    if (!err.empty()) return fail(status, err);
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, 36 * 8) != hipSuccess || hipMemset(d, 0, 36 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
+    g->d_prof = d;
+    err = run_device(g, d_inputs, batch, d_witness, d_set_status, nullptr);
+    g->d_prof = nullptr;
+    if (err.empty() && hipDeviceSynchronize() != hipSuccess) err = "hipDeviceSynchronize failed";
+    if (err.empty() && hipMemcpy(out36, d, 36 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
+    (void)hipFree(d);
+    if (!err.empty()) return fail(status, err);
+    set_status(status, OK, "");
     return 0;
 }
 

@@ -70,6 +70,11 @@ int gwb_calc_witness_batch_host(gwb_graph_t *g, const void *inputs, size_t batch
 /* Kernel times of the last batch call on this handle (synchronizes on its events). */
 int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 
+/* Diagnostic build of the interpreter with in-kernel cycle stamps: out36[class*4 + {operand-load, compute,
+ * store, bundles}] in shader cycles summed over the sampled waves.  Serialised -- read shares, not totals. */
+int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
+                        uint32_t *d_set_status, uint64_t *out36, gw_status_t *status);
+
 /* `.wtns` framing of one witness row (wtns_from_witness, src/lib.rs:114-123): out holds gwb_wtns_size bytes. */
 size_t gwb_wtns_size(size_t n_witness);
 int gwb_wtns_from_witness(const void *witness_row, size_t n_witness, void *out);

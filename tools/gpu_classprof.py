@@ -1,0 +1,34 @@
+"""Diagnostic: per-bundle-class cycle shares of the interpreter (stamped build) on the authV2-class graph."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import cwc_import
+pkg = cwc_import.load()
+from tools.graphgen import circuits as C
+kind = os.environ.get("PROBE_GRAPH", "authv2")
+b = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512)
+g = pkg.Graph(b.to_bin())
+B = int(os.environ.get("PROBE_B", "1024"))
+rng = np.random.default_rng(1)
+rows = np.frombuffer(rng.bytes(B * g.n_inputs * 32), dtype=np.uint8).reshape(B, g.n_inputs, 32).copy()
+if kind == "authv2":
+    rows[:, :, 31] &= 0x1f
+else:
+    rows[:, :, 1:] = 0; rows[:, :, 0] &= 1
+rows[:, 0, :] = 0; rows[:, 0, 0] = 1
+d_in = torch.from_numpy(rows).cuda()
+d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+d_st = torch.zeros(B, dtype=torch.int32, device="cuda")
+for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
+    g.set_tile_width(tw)
+    g.calc_witness_batch_device(d_in, d_out, d_st); torch.cuda.synchronize()
+    t = g.last_timing()
+    prof = g.profile_classes(d_in, d_out, d_st)
+    nw = max(1, (B + tw - 1) // tw // 64 + (1 if ((B + tw - 1) // tw) % 64 else 0))
+    tot = sum(sum(v[:3]) for v in prof.values())
+    print("T=%d B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw, B, t["interp_ms"], nw, tot / nw))
+    for k, (ld, cp, stc, n) in prof.items():
+        if n:
+            print("   %-8s bundles/wave %7d  per bundle: load %7.0f  compute %8.0f  store %6.0f cycles   share %.1f%%" % (
+                k, n // nw, ld / n, cp / n, stc / n, 100.0 * (ld + cp + stc) / tot))
