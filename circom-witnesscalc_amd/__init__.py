@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "gw_calc_witness", "gwb_graph_load", "gwb_graph_free", "gwb_graph_info", "gwb_graph_serialize",
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
-    "gwb_free_status", "gwb_profile_classes",
+    "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width",
 ]
 
 
@@ -88,6 +88,8 @@ def lib():
         L.gwb_graph_import.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
         L.gwb_free_status.argtypes = [stp]
         L.gwb_profile_classes.argtypes = [vp, vp, sz, vp, vp, vp, stp]
+        L.gwb_pick_tile_width.restype = ctypes.c_uint32
+        L.gwb_pick_tile_width.argtypes = [sz]
         _lib = L
     return _lib
 
@@ -106,6 +108,11 @@ def _check(rc, st):
     msg = _take_status(st)
     if rc != 0:
         raise WitnessCalcError(msg or "call failed")
+
+
+def pick_tile_width(batch):
+    """Input sets per wavefront the library uses for a batch of this size (gwb_pick_tile_width)."""
+    return int(lib().gwb_pick_tile_width(batch))
 
 
 def calc_witness_wtns(inputs_json, graph_data):
@@ -160,8 +167,8 @@ class Graph:
             setattr(self, name, int(getattr(info, name)))
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().gwb_graph_free(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.gwb_graph_free(self._h)
             self._h = None
 
     __del__ = close

@@ -121,6 +121,20 @@ struct gwb_graph {
     }
 };
 
+// Tile width heuristic: the interpreter is latency-bound per wave, and measured on MI355X (authV2-class graph)
+// the time per batch is flat up to ~512 waves in flight and rises beyond; so widen the tile (more input sets per
+// wave, fewer node slots) only once there are at least CWC_TARGET_WAVES (default 512) tiles.
+extern "C" uint32_t gwb_pick_tile_width(size_t batch) {
+    size_t target = 512;
+    if (const char* e = getenv("CWC_TARGET_WAVES")) {
+        long v = atol(e);
+        if (v > 0) target = (size_t)v;
+    }
+    uint32_t t = 1;
+    while (t < 64 && batch / (t * 2) >= target) t *= 2;
+    return t;
+}
+
 namespace {
 
 std::string check_device() {
@@ -139,10 +153,7 @@ uint32_t pick_tile_width(const gwb_graph* g, size_t batch) {
         uint32_t t = (uint32_t)atoi(e);
         if (t >= 1 && t <= 64 && !(t & (t - 1))) return t;
     }
-    // Fill the chip's 1024 SIMDs with about two waves each before widening the tile.
-    uint32_t t = 1;
-    while (t < 64 && batch / (t * 2) >= 2048) t *= 2;
-    return t;
+    return gwb_pick_tile_width(batch);
 }
 
 std::string get_program(gwb_graph* g, uint32_t T, DeviceProgram** out) {

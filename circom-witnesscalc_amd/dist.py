@@ -1,0 +1,48 @@
+"""Multi-GPU plumbing for batched witness generation: one process per GPU, input sets sharded
+contiguously, the compiled graph program broadcast once from rank 0 (RCCL over xGMI when the backend is
+"nccl"; "gloo" in CPU tests).  There is no steady-state collective: every input set is independent
+(reference graph::evaluate touches only its own `values`, src/graph.rs:371-382)."""
+import numpy as np
+
+
+def shard_range(batch, rank, world_size):
+    """Contiguous shard [lo, hi) of `batch` input sets for `rank`: sizes differ by at most one."""
+    base, rem = divmod(batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_blob(blob, src=0, device=None):
+    """Broadcast a bytes object from `src` to every rank with torch.distributed; returns bytes.
+    `blob` is only read on `src`.  `device`: torch device of the staging tensor ("cuda:N" for the
+    nccl/RCCL backend so that the payload moves GPU to GPU, "cpu" for gloo)."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=src)
+    size = int(n.item())
+    if rank == src:
+        buf = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+    else:
+        buf = torch.empty(size, dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src=src)
+    return buf.cpu().numpy().tobytes()
+
+
+def broadcast_graph(pkg, graph_data, tile_width, src=0, device=None):
+    """Rank `src` parses + compiles `graph_data` (`.bin` bytes) for `tile_width` and broadcasts the compiled
+    program; the other ranks import it (gwb_graph_import) instead of re-parsing.  Returns a pkg.Graph."""
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    g = None
+    blob = b""
+    if rank == src:
+        g = pkg.Graph(graph_data)
+        g.set_tile_width(tile_width)
+        blob = g.export_blob(tile_width)
+    blob = broadcast_blob(blob, src=src, device=device)
+    if rank != src:
+        g = pkg.Graph.from_blob(blob)
+    return g

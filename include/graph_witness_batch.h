@@ -56,6 +56,8 @@ int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *ro
 
 /* 0 = choose from the batch size (default); else a power of two in 1..64 */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
+/* the tile width (input sets per wavefront) the library chooses for a batch of this size */
+uint32_t gwb_pick_tile_width(size_t batch);
 
 /* Evaluate `batch` input sets resident in device memory (graph::evaluate per set, src/graph.rs:367-391).
  *   d_inputs  : [batch][n_inputs][32 B] canonical LE

@@ -1,0 +1,191 @@
+"""CPU-side tests of the product's host logic through the C-ABI (no GPU compute calls): `.bin` reader and
+writer, inputs JSON, `.wtns` framing, error behaviour of gw_calc_witness, exported symbols, and the graph
+compiler checked by emulating the exported program blob."""
+import ctypes
+import hashlib
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from oracle import model
+from tools.graphgen import circuits as C
+import program_emulator as pe
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    declared = set()
+    for h in ("graph_witness.h", "graph_witness_batch.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        declared |= set(re.findall(r"\b(gwb?_[a-z_0-9]+)\s*\(", txt))
+    declared -= {"gw_free_status"}  # header-inline, as in the reference header
+    assert declared == set(pkg.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert getattr(L, s) is not None
+
+
+def test_gw_calc_witness_argument_errors(pkg):
+    # reference src/lib.rs:51-64 messages; these return before any device work
+    L = pkg.lib()
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), pkg.GwStatus()
+    data = open(os.path.join(GOLD, "circuit1.bin"), "rb").read()
+    cases = [((None, data, len(data)), "inputs is null"), ((b"{}", None, 5), "graph_data is null"),
+             ((b"{}", data, 0), "graph_data_len is 0")]
+    for (a, b, c), msg in cases:
+        rc = L.gw_calc_witness(a, b, c, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        assert rc == 1 and st.code == 1
+        assert ctypes.string_at(st.error_msg).decode() == msg
+        L.gwb_free_status(ctypes.byref(st))
+    # bad JSON classes -> "Failed to calculate witness: ..." (reference lib.rs:88-92)
+    for bad, frag in [(b'[1]', "inputs must be an object"), (b'{"a": -1}', "not a positive integer"),
+                      (b'{"a": "12x"}', "InputFieldNumberParseError"), (b'{"a": [[1]]}', "inputs must be a string: a"),
+                      (b'{"a": true}', "value for key a must be"), (b'{"a": ', "invalid JSON"),
+                      (b'\xff\xfe', "Failed to parse inputs")]:
+        rc = L.gw_calc_witness(bad, data, len(data), ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        assert rc == 1
+        assert frag in ctypes.string_at(st.error_msg).decode(), bad
+        L.gwb_free_status(ctypes.byref(st))
+    # malformed graphs (reference panics at lib.rs:130)
+    for g in (b"not a graph at all......", data[:40], b"wtns.graph.001" + (2 ** 40).to_bytes(8, "little")):
+        rc = L.gw_calc_witness(b'{"a":1}', g, len(g), ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        assert rc == 1 and b"Failed to calculate witness" in ctypes.string_at(st.error_msg)
+        L.gwb_free_status(ctypes.byref(st))
+
+
+def test_bin_reader_and_writer_roundtrip(pkg):
+    for b in (C.build_circuit1(), C.build_gadgets(), C.build_poseidon(2), C.build_random_dag(5, n_ops=200)):
+        data = b.to_bin()
+        g = pkg.Graph(data)
+        nodes, wit, ins = model.deserialize_witnesscalc_graph(data)
+        assert g.n_nodes == len(nodes) and g.n_witness == len(wit)
+        assert g.n_inputs == model.get_inputs_size(nodes)
+        assert g.n_op == sum(1 for n in nodes if n[0] in ("Uno", "Duo", "Tres"))
+        # serialize_witnesscalc_graph reproduces the reference writer's bytes (storage.rs:137-183)
+        assert g.serialize() == data
+    # circuit1 fixture bytes
+    assert pkg.Graph(open(os.path.join(GOLD, "circuit1.bin"), "rb").read()).serialize() == open(os.path.join(GOLD, "circuit1.bin"), "rb").read()
+
+
+def test_bin_reader_accepts_unpacked_witness_and_long_constants(pkg):
+    from tools.graphgen.builder import _varint, _field_bytes, _field_varint, encode_node
+    import struct
+    nodes = [("Const", 0), ("Input", 0), ("Input", 1), ("Duo", "Add", 2, 0)]
+    out = bytearray(b"wtns.graph.001") + struct.pack("<Q", len(nodes))
+    # constant longer than 32 bytes and >= r: reduced mod r on load (storage.rs:28)
+    big = (model.M * 7 + 5) << 16
+    body = _field_bytes(2, _field_bytes(1, _field_bytes(1, big.to_bytes(40, "little"))))
+    out += _varint(len(body)) + body
+    for n in nodes[1:]:
+        body = encode_node(n)
+        out += _varint(len(body)) + body
+    md = b"".join(_varint((1 << 3) | 0) + _varint(w) for w in (1, 3, 0))  # unpacked repeated uint32
+    md += _field_bytes(2, _field_bytes(1, b"a") + _field_bytes(2, _field_varint(1, 1) + _field_varint(2, 1)))
+    md_off = len(out)
+    out += _varint(len(md)) + md + struct.pack("<Q", md_off)
+    g = pkg.Graph(bytes(out))
+    assert (g.n_nodes, g.n_witness, g.n_inputs) == (4, 3, 2)
+    n2, w2, i2 = model.deserialize_witnesscalc_graph(bytes(out))
+    assert w2 == [1, 3, 0] and i2 == {"a": (1, 1)} and n2[0] == ("Const", big % model.M)
+    blob = pe.Blob(g.export_blob(64))
+    assert pe.run(blob, [1, 9])[0] == [1, (9 + big) % model.M, big % model.M]
+
+
+def test_graph_validation_errors(pkg):
+    from tools.graphgen.builder import serialize_graph
+    bad = [
+        ([("Input", 0), ("Duo", "Add", 0, 1)], [0], "not before it"),          # forward reference
+        ([("Input", 0), ("Duo", "Pow", 0, 0)], [0], "Pow"),                     # graph.rs:141-142
+        ([("Input", 0), ("Uno", "Id", 0)], [0], "Id"),                          # graph.rs:195
+        ([("Input", 0)], [3], "witness signal"),
+    ]
+    for nodes, wit, frag in bad:
+        with pytest.raises(pkg.WitnessCalcError, match=frag):
+            pkg.Graph(serialize_graph(nodes, wit, {}))
+
+
+def test_inputs_from_json_matches_reference_semantics(pkg):
+    b = C.build_gadgets()
+    g = pkg.Graph(b.to_bin())
+    nodes, wit, ins = model.deserialize_witnesscalc_graph(b.to_bin())
+    good = ['{"x": "123", "y": 7, "arr": ["1", 2, "3", 4]}', '{"x": 18446744073709551615, "arr": [1,2,3,4]}',
+            '{"y": "%d"}' % (2 ** 256 - 1), '{"x":"1","x":"2"}', '{ "x" : "1_000" }', '{}',
+            '{"\\u0078": "5"}', '{"y": ""}']
+    for txt in good:
+        row = g.inputs_from_json(txt)
+        buf = model.get_inputs_buffer(g.n_inputs)
+        model.populate_inputs(model.deserialize_inputs(txt), ins, buf)
+        assert [int.from_bytes(row[i].tobytes(), "little") for i in range(g.n_inputs)] == buf, txt
+    bad = ['{"x": 18446744073709551616}', '{"x": 1e3}', '{"x": "%d"}' % 2 ** 256, '{"nope": 1}', '{"arr": [1,2,3]}',
+           '{"x": {"a":1}}', '{"x": [1, null]}', '{"x": 01}', '{"x": "1",}', "{'x': 1}", '{"x": "+1"}']
+    for txt in bad:
+        with pytest.raises(pkg.WitnessCalcError):
+            g.inputs_from_json(txt)
+    # reference lib.rs:259-271 vector: keys unknown to this graph -> reference panics, here an error; parse itself is
+    # covered through the graph of matching shape
+    from tools.graphgen.builder import Builder
+    bb = Builder()
+    k1 = bb.input("key1", 3); k2 = bb.input("key2"); k3 = bb.input("key3")
+    for h in k1 + k2 + k3:
+        bb.signal(h)
+    g2 = pkg.Graph(bb.to_bin())
+    kat = json.load(open(os.path.join(GOLD, "kat_ops.json")))["inputs_json"]
+    row = g2.inputs_from_json(kat["text"])
+    assert [int.from_bytes(row[i].tobytes(), "little") for i in range(6)] == [1, 123, 456, 100500, 789, 123123]
+
+
+def test_wtns_framing(pkg):
+    rnd = random.Random(2)
+    for n in (0, 1, 4, 33):
+        w = [rnd.randrange(model.M) for _ in range(n)]
+        assert pkg.wtns_from_witness(w) == model.wtns_from_witness(w)
+    assert pkg.wtns_from_witness([1, 31817, 105, 303]) == open(os.path.join(GOLD, "circuit1.wtns"), "rb").read()
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64])
+def test_graph_compiler_emulated(pkg, tile):
+    """Level scheduling, bundling, slot reuse and operand encoding for every tile width (host logic only)."""
+    rnd = random.Random(tile)
+    cases = [(C.build_gadgets(), 7), (C.build_poseidon(2), 3)] + [(C.build_random_dag(s, n_ops=250, panic_free=(s % 2 == 0)), 7) for s in range(6)]
+    for b, n_in in cases:
+        data = b.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        g = pkg.Graph(data)
+        blob = pe.Blob(g.export_blob(tile))
+        assert blob.T == tile and blob.n_witness == len(wit)
+        assert blob.stats["algorithmic_bytes_per_set"] == g.algorithmic_bytes_per_set
+        arity = {"Uno": 1, "Duo": 2, "Tres": 3}
+        want_bytes = 32 * (sum(arity[n[0]] + 1 for n in nodes if n[0] in arity) + 2 * sum(1 for n in nodes if n[0] == "Input") + 2 * len(wit))
+        assert g.algorithmic_bytes_per_set == want_bytes
+        for _ in range(2):
+            row = [1] + [rnd.randrange(model.M) if rnd.random() < 0.6 else rnd.randrange(1 << 10) for _ in range(n_in - 1)]
+            got, st = pe.run(blob, row)
+            try:
+                want = model.evaluate(nodes, row, wit)
+            except model.ReferencePanic:
+                assert st != 0
+                continue
+            assert st == 0 and got == want
+
+
+def test_slot_reuse_keeps_workspace_small(pkg):
+    b = C.build_poseidon(2)
+    g = pkg.Graph(b.to_bin())
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(b.to_bin())
+    blob = pe.Blob(g.export_blob(64))
+    n_values = sum(1 for n in nodes if n[0] != "Const")
+    assert blob.n_slots < n_values  # liveness reuse
+    assert blob.n_slots >= len(set(wit))  # witness values stay resident
+
+
+def test_cli_usage(pkg):
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "calc-witness")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr and "<graph.bin> <inputs.json> <witness.wtns>" in r.stderr

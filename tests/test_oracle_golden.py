@@ -1,0 +1,148 @@
+"""Pins the oracles (oracle/model.py, oracle/cwc_oracle.c) against the reference's own unit vectors and
+fixtures; the Rust reference itself cannot be built or run here.  CPU only."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import cbind, model
+from tools.graphgen import circuits as C
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KAT = json.load(open(os.path.join(GOLD, "kat_ops.json")))
+
+
+def test_reference_unit_vectors_both_oracles():
+    # reference src/graph.rs:779-883
+    for op, a, b, want in KAT["reference_unit_vectors"]:
+        a, b, want = int(a), int(b), int(want)
+        assert model.eval_duo(op, a, b) == want, (op, a, b)
+        assert cbind.eval_op("Duo", model.DUO_CODE[op], a, b) == want, (op, a, b)
+
+
+def test_edge_vectors_c_oracle_matches_model():
+    # SURVEY 7.6 edge list; expected values were produced by the big-int model (make_golden.py)
+    for op, a, b, want in KAT["edge_vectors"]:
+        a, b = int(a), int(b)
+        try:
+            got = str(cbind.eval_op("Duo", model.DUO_CODE[op], a, b))
+        except ArithmeticError:
+            got = "panic"
+        assert got == want, (op, a, b)
+    for a, want in KAT["neg_vectors"]:
+        assert cbind.eval_op("Uno", 0, int(a)) == int(want)
+
+
+def test_survey_7_6_named_cases():
+    M = model.M
+    e = model.eval_duo
+    assert e("Div", 5, 0) == 0 and e("Idiv", 5, 0) == 0 and e("Mod", 5, 0) == 0
+    assert model.eval_uno("Neg", 0) == 0 and e("Sub", 0, 1) == M - 1 and e("Add", M - 1, 1) == 0
+    assert e("Mul", M - 1, M - 1) == 1
+    assert e("Lt", M - 1, 3) == 1 and e("Gt", M - 1, 3) == 0
+    assert e("Geq", M // 2, M // 2 + 1) == 1  # halfM non-negative, halfM+1 negative
+    assert e("Shl", 7, 0) == 7 and e("Shl", 7, 254) == 0 and e("Shl", 7, M - 1) == 0 and e("Shl", 1, 253) == 1 << 253
+    assert e("Shl", 1, 255) == 0
+    with pytest.raises(model.ReferencePanic):
+        e("Shl", M - 1, 1)
+    assert e("Shr", 7, 0) == 7 and e("Shr", 7, 254) == 0 and e("Shr", 1 << 253, 253) == 1
+    A = M & ((1 << 253) - 1)
+    with pytest.raises(model.ReferencePanic):
+        e("Bor", A, M ^ A)  # result == r
+    assert e("Bor", (1 << 253), (1 << 253) - 1) == ((1 << 254) - 1) - M  # one subtraction
+    assert model.eval_tres("TernCond", 0, 11, 22) == 22 and model.eval_tres("TernCond", 5, 11, 22) == 11
+    with pytest.raises(model.ReferencePanic):
+        e("Pow", 2, 3)
+
+
+def test_inputs_json_reference_vector():
+    v = KAT["inputs_json"]  # reference src/lib.rs:259-271
+    got = model.deserialize_inputs(v["text"])
+    assert {k: [str(x) for x in xs] for k, xs in got.items()} == v["want"]
+    for bad in ['[1]', '{"a": -1}', '{"a": 1.5}', '{"a": [[1]]}', '{"a": true}', '{"a": "0x10"}', '{"a": null}']:
+        with pytest.raises(model.InputsError):
+            model.deserialize_inputs(bad)
+
+
+def test_node_framing_vectors():
+    # reference src/storage.rs:316-342 style records; bytes from SURVEY 8(a) a13
+    from tools.graphgen.builder import encode_node, _varint
+    nodes = {"Input(0)": ("Input", 0), "Input(1)": ("Input", 1), "Input(2)": ("Input", 2), "Const(2)": ("Const", 2),
+             "Mul(2,3)": ("Duo", "Mul", 2, 3), "Add(4,0)": ("Duo", "Add", 4, 0)}
+    for name, hx in KAT["node_framing"].items():
+        body = encode_node(nodes[name])
+        assert (_varint(len(body)) + body).hex() == hx, name
+        # and the oracle's reader decodes it back
+        assert model._decode_node(bytes.fromhex(hx)[1:])[0] == nodes[name][0]
+
+
+def test_circuit1_fixture_end_to_end():
+    data = open(os.path.join(GOLD, "circuit1.bin"), "rb").read()
+    assert len(data) == 94 and C.build_circuit1().to_bin() == data
+    inputs = open(os.path.join(GOLD, "circuit1_inputs.json")).read()
+    w = model.calc_witness(inputs, data)
+    assert w == [1, 31817, 105, 303]
+    wt = model.wtns_from_witness(w)
+    assert wt == open(os.path.join(GOLD, "circuit1.wtns"), "rb").read()
+    assert hashlib.sha256(wt).hexdigest() == "bbb1fcd1ba5ef0d68a6bbd526b66d34c1a67d99a06ed0e6a3da5ba288961c72b"
+    g = cbind.Graph(data)
+    out, st = g.evaluate_batch(cbind.ints_to_array([[1, 105, 303]]))
+    assert st[0] == 0 and cbind.wtns_from_witness(out[0]) == wt
+
+
+def test_expected_wtns_digests_c_oracle():
+    exp = json.load(open(os.path.join(GOLD, "expected_wtns.json")))
+    builders = {"poseidon1": lambda: C.build_poseidon(1), "gadgets": C.build_gadgets, "sha256_512": lambda: C.build_sha256(512),
+                "authv2_class": C.build_authv2_class, "dag1": lambda: C.build_random_dag(1, n_ops=300),
+                "dag2": lambda: C.build_random_dag(2, n_ops=300), "dag3": lambda: C.build_random_dag(3, n_ops=300)}
+    for name, e in exp.items():
+        data = builders[name]().to_bin()
+        assert hashlib.sha256(data).hexdigest() == e["bin_sha256"], name  # generators are deterministic
+        nodes, wit, ins = model.deserialize_witnesscalc_graph(data)
+        buf = model.get_inputs_buffer(model.get_inputs_size(nodes))
+        model.populate_inputs(model.deserialize_inputs(e["inputs"]), ins, buf)
+        g = cbind.Graph(data)
+        out, st = g.evaluate_batch(cbind.ints_to_array([buf]))
+        assert st[0] == 0
+        assert hashlib.sha256(cbind.wtns_from_witness(out[0])).hexdigest() == e["wtns_sha256"], name
+
+
+def test_sha256_graph_matches_hashlib():
+    """External anchor: the generated SHA-256(512) graph evaluated by the oracle equals hashlib."""
+    data = C.build_sha256(512).to_bin()
+    g = cbind.Graph(data)
+    rnd = random.Random(4)
+    msgs = [bytes(64), bytes(range(64)), bytes([255] * 64)] + [bytes(rnd.getrandbits(8) for _ in range(64)) for _ in range(3)]
+    ref_in = json.load(open(os.path.join(GOLD, "circuit8_sha256_512_inputs.json")))["in"]
+    msgs.append(bytes(sum(ref_in[8 * i + k] << (7 - k) for k in range(8)) for i in range(64)))
+    rows = [[1] + [(m[i // 8] >> (7 - i % 8)) & 1 for i in range(512)] for m in msgs]
+    out, st = g.evaluate_batch(cbind.ints_to_array(rows))
+    assert not st.any()
+    for m, o in zip(msgs, out):
+        bits = cbind.array_to_ints(o[1:257])
+        dig = hashlib.sha256(m).digest()
+        assert bits == [(dig[i // 8] >> (7 - i % 8)) & 1 for i in range(256)]
+    # the pure-Python model agrees on one message
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    assert model.evaluate(nodes, rows[1], wit) == cbind.array_to_ints(out[1])
+
+
+def test_random_dags_c_oracle_vs_model():
+    rnd = random.Random(9)
+    for seed in range(12):
+        b = C.build_random_dag(seed, n_ops=250, panic_free=(seed % 3 != 0))
+        data = b.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        g = cbind.Graph(data)
+        rows = [[1] + [rnd.randrange(model.M) if rnd.random() < 0.6 else rnd.randrange(1 << 12) for _ in range(6)] for _ in range(4)]
+        out, st = g.evaluate_batch(cbind.ints_to_array(rows))
+        for r, o, s in zip(rows, out, st):
+            try:
+                want = model.evaluate(nodes, r, wit)
+            except model.ReferencePanic:
+                assert s in (1, 2)
+                continue
+            assert s == 0 and cbind.array_to_ints(o) == want
