@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=1024)
     ap.add_argument("--graph", choices=["authv2", "sha256"], default="authv2")
     ap.add_argument("--tile-width", type=int, default=0, help="0 = library heuristic")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="input sets timed on one host core (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="input sets timed on one host core (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,7 +143,8 @@ def main():
                        "parallelism": "batch shards x%d, program broadcast over RCCL" % world},
             "field_ops_per_sec": value * g.n_op,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": committed_traffic(args.graph, B, tm["tile_width"]), "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_interp_s * 1e3,
                          "pack_kernel_avg_ms": float(np.mean(pack_ms))},
         }
@@ -153,6 +154,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def committed_traffic(graph_kind, batch, tile_width):
+    """HBM bytes per interpreter launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json,
+    collected on this same command line), or None when no committed profile matches this configuration."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+        try:
+            j = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        c = j.get("config", {})
+        if c.get("graph") == graph_kind and c.get("batch_per_gpu") == batch and c.get("tile_width") == tile_width:
+            best = j["kernels"]["interp"]["hbm_bytes_per_launch_corrected"]
+    return best
 
 
 def cpu_baseline(graph_data, rows, d_out, n):
