@@ -241,7 +241,7 @@ class Graph:
         _check(rc, st)
 
     def profile_classes(self, d_inputs, d_witness, d_status):
-        """Diagnostic stamped build: {class: (load_cycles, compute_cycles, store_cycles, bundles)} per sampled wave."""
+        """Diagnostic stamped build: {class: (cycles, cycles_fwd_bundles, fwd_bundles, bundles)} over sampled waves."""
         out = np.zeros(36, dtype=np.uint64)
         st = GwStatus()
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),

@@ -87,8 +87,9 @@ bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err)
             ref[i] = REF_CONST | (uint32_t)(out.consts.size() / 8);
             out.consts.insert(out.consts.end(), m.v, m.v + 8);
         }
+    st.n_const = out.consts.size() / 8;
+    out.consts.insert(out.consts.end(), 8, 0u);  // trailing dummy entry: the table is never empty (prefetch target)
     out.n_const = (uint32_t)(out.consts.size() / 8);
-    st.n_const = out.n_const;
 
     // ---- levels ----
     std::vector<uint32_t> level(N, 0);
@@ -133,89 +134,196 @@ bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err)
     bundle_start.push_back((uint32_t)order.size());
     out.n_bundles = NB;
 
-    // ---- liveness: last bundle that reads each node's value; witness nodes are pinned ----
-    std::vector<uint32_t> last_use(N, 0);
-    std::vector<uint8_t> pinned(N, 0);
-    for (uint32_t i : order) last_use[i] = bundle_of[i];
+    // ---- operand routing -------------------------------------------------------------------------------
+    // A value consumed (as a or b) by the bundle right after its producer is *forwarded*: the consumer lane
+    // takes it from the result registers of the previous bundle (its own lane when the host could give the
+    // consumer its producer's node slot, else ds_bpermute) -- no store -> load round trip.  Every other use goes
+    // through the value slot in memory and is prefetched one bundle ahead.  A value that is neither a witness
+    // element nor read from memory is never given a slot (its store goes to the tile's trash slot).
+    auto forwardable = [&](uint32_t producer, uint32_t consumer, int q) {
+        return q < 2 && g.nodes[producer].kind != N_CONST && bundle_of[consumer] == bundle_of[producer] + 1;
+    };
+    std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
+    std::vector<uint8_t> needs_slot(N, 0);
+    for (uint32_t w : g.witness_signals)
+        if (g.nodes[w].kind != N_CONST) needs_slot[w] = 2;  // pinned
     for (uint32_t i : order) {
         const Node& n = g.nodes[i];
-        int ar = arity_of(n);
-        uint32_t b = bundle_of[i];
-        if (ar >= 1 && g.nodes[n.a].kind != N_CONST) last_use[n.a] = std::max(last_use[n.a], b);
-        if (ar >= 2 && g.nodes[n.b].kind != N_CONST) last_use[n.b] = std::max(last_use[n.b], b);
-        if (ar >= 3 && g.nodes[n.c].kind != N_CONST) last_use[n.c] = std::max(last_use[n.c], b);
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) {
+            const uint32_t o = ops[q];
+            if (g.nodes[o].kind == N_CONST || forwardable(o, i, q)) continue;
+            if (!needs_slot[o]) needs_slot[o] = 1;
+            last_mem_use[o] = std::max(last_mem_use[o], bundle_of[i]);
+        }
     }
-    for (uint32_t w : g.witness_signals) pinned[w] = 1;
+
+    // ---- node slot (lane group) placement: a consumer prefers the node slot of its forwarded producer ----
+    std::vector<uint32_t> pos_in_bundle(N, 0);
+    {
+        std::vector<int32_t> taken(G);
+        std::vector<uint32_t> rest;
+        for (uint32_t b = 0; b < NB; ++b) {
+            const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1];
+            std::fill(taken.begin(), taken.end(), -1);
+            rest.clear();
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t i = order[k];
+                const Node& n = g.nodes[i];
+                int want = -1;
+                if (arity_of(n) >= 1 && forwardable(n.a, i, 0)) want = (int)pos_in_bundle[n.a];
+                else if (arity_of(n) >= 2 && forwardable(n.b, i, 1)) want = (int)pos_in_bundle[n.b];
+                if (want >= 0 && want < (int)(k1 - k0) && taken[want] < 0) {
+                    taken[want] = (int32_t)i;
+                    pos_in_bundle[i] = (uint32_t)want;
+                } else {
+                    rest.push_back(i);
+                }
+            }
+            uint32_t f = 0;
+            for (uint32_t i : rest) {
+                while (taken[f] >= 0) ++f;
+                taken[f] = (int32_t)i;
+                pos_in_bundle[i] = f;
+            }
+            for (uint32_t q = 0; q < k1 - k0; ++q) order[k0 + q] = (uint32_t)taken[q];  // order now follows positions
+        }
+    }
 
     // ---- slot allocation (LIFO free list: a just-freed slot is still hot in cache) + encoding ----
+    const uint64_t slot_bytes = 32ull * T;
+    const uint64_t const_base = 0;  // constants sit at the head of the workspace
     out.hdr.resize(NB);
     out.recs.assign((size_t)NB * G * 4, 0);
     out.crefs.assign((size_t)NB * G, 0);
     std::vector<uint32_t> free_slots;
     std::vector<uint32_t> dying;  // nodes whose slot is released after the current bundle
     uint32_t n_slots = 0;
+    // first pass: assign slots bundle by bundle (needed before encoding because offsets depend on slots only)
+    struct Enc { uint32_t ctrl, dst, a, b, c; };
+    const uint32_t zero_const = (uint32_t)st.n_const;  // index of the trailing dummy (value 0)
+    auto mem_off = [&](uint32_t producer, uint32_t& tile_rel) -> uint32_t {
+        if (g.nodes[producer].kind == N_CONST) {
+            tile_rel = 0;
+            return (uint32_t)(const_base + (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes);
+        }
+        tile_rel = 1;
+        return (uint32_t)((uint64_t)ref[producer] * slot_bytes);
+    };
     for (uint32_t b = 0; b < NB; ++b) {
-        const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1];
+        const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
         const int cl = class_of(g.nodes[order[k0]]);
-        out.hdr[b] = (uint32_t)cl | ((k1 - k0) << 8);
         st.class_bundles[cl]++;
-        st.class_nodes[cl] += k1 - k0;
+        st.class_nodes[cl] += cnt;
         dying.clear();
+        uint32_t fwd_cnt[2] = {0, 0}, fwd_same[2] = {0, 0}, n_add = 0, n_sub = 0;
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k];
             const Node& n = g.nodes[i];
-            uint32_t slot;
-            if (!free_slots.empty()) {
-                slot = free_slots.back();
-                free_slots.pop_back();
-            } else {
-                slot = n_slots++;
+            uint32_t slot = 0xffffffffu;
+            if (needs_slot[i]) {
+                if (!free_slots.empty()) {
+                    slot = free_slots.back();
+                    free_slots.pop_back();
+                } else {
+                    slot = n_slots++;
+                }
             }
-            ref[i] = slot;
+            ref[i] = slot;  // 0xffffffff: no slot (every use forwarded)
             uint32_t* r = &out.recs[((size_t)b * G + (k - k0)) * 4];
+            uint32_t ctrl = CTRL_ACTIVE;
+            // dst offset is patched below once n_slots (the trash slot index) is known: store slot id for now
             r[1] = slot;
+            auto enc_operand = [&](uint32_t producer, int q, uint32_t& off) {
+                if (forwardable(producer, i, q)) {
+                    const uint32_t src = pos_in_bundle[producer];
+                    ctrl |= (q == 0 ? CTRL_A_FWD : CTRL_B_FWD) | (src << (q == 0 ? CTRL_ASRC_SHIFT : CTRL_BSRC_SHIFT));
+                    off = (uint32_t)(const_base + (uint64_t)zero_const * slot_bytes);  // harmless prefetch target
+                    fwd_cnt[q]++;
+                    if (src == k - k0) fwd_same[q]++;
+                } else {
+                    uint32_t rel;
+                    off = mem_off(producer, rel);
+                    if (rel) ctrl |= (q == 0 ? CTRL_A_TILE : CTRL_B_TILE);
+                }
+            };
+            const uint32_t zero_off = (uint32_t)(const_base + (uint64_t)zero_const * slot_bytes);
             switch (n.kind) {
                 case N_INPUT:
                     if (n.a >= n_in_buf) {
                         err = "Input index out of range";
                         return false;
                     }
-                    r[0] = SUB_INPUT;
-                    r[2] = n.a;
+                    ctrl |= (uint32_t)SUB_INPUT << CTRL_SUB_SHIFT;
+                    r[2] = n.a;  // input index (the kernel prefetches nothing for INPUT bundles)
+                    r[3] = 0;
                     break;
-                case N_UNO:
-                    r[0] = SUB_NEG;
-                    r[2] = ref[n.a];
-                    r[3] = ref[n.a];  // kernel convention: Neg carries b = a
+                case N_UNO:  // Neg(a) = 0 - a  (graph.rs:188-194: 0 -> 0, else r - a)
+                    ctrl |= (uint32_t)OP_SUB << CTRL_SUB_SHIFT;
+                    r[2] = zero_off;
+                    enc_operand(n.a, 1, r[3]);
+                    n_sub++;
                     break;
                 case N_DUO:
-                    r[0] = n.op;
-                    r[2] = ref[n.a];
-                    r[3] = ref[n.b];
+                    ctrl |= (uint32_t)n.op << CTRL_SUB_SHIFT;
+                    enc_operand(n.a, 0, r[2]);
+                    enc_operand(n.b, 1, r[3]);
+                    if (n.op == OP_ADD) n_add++;
+                    if (n.op == OP_SUB) n_sub++;
                     break;
-                case N_TRES:
-                    r[0] = SUB_TERN;
-                    r[2] = ref[n.a];
-                    r[3] = ref[n.b];
-                    out.crefs[(size_t)b * G + (k - k0)] = ref[n.c];
+                case N_TRES: {
+                    ctrl |= (uint32_t)SUB_TERN << CTRL_SUB_SHIFT;
+                    enc_operand(n.a, 0, r[2]);
+                    enc_operand(n.b, 1, r[3]);
+                    uint32_t rel;
+                    uint32_t off = mem_off(n.c, rel);  // third operand always through memory
+                    out.crefs[(size_t)b * G + (k - k0)] = off | (rel ? CREF_TILE : 0u);
                     break;
+                }
             }
+            r[0] = ctrl;
             const uint32_t ops[3] = {n.a, n.b, n.c};
             for (int q = 0; q < arity_of(n); ++q) {
                 uint32_t o = ops[q];
-                if (g.nodes[o].kind != N_CONST && !pinned[o] && last_use[o] == b) dying.push_back(o);
+                if (needs_slot[o] == 1 && last_mem_use[o] == b) dying.push_back(o);
             }
-            if (!pinned[i] && last_use[i] == b) dying.push_back(i);  // dead value: release right away
         }
-        for (uint32_t q = k1 - k0; q < G; ++q) {  // inactive node slots: valid operands, store masked off
-            memcpy(&out.recs[((size_t)b * G + q) * 4], &out.recs[(size_t)b * G * 4], 16);
-            out.crefs[(size_t)b * G + q] = out.crefs[(size_t)b * G];
-        }
+        // Neg was encoded with its operand in the b position; its forwarding bookkeeping went to q = 1 already.
+        auto mode_of = [&](int q) -> uint32_t {
+            if (fwd_cnt[q] == 0) return FWD_NONE;
+            if (fwd_same[q] != fwd_cnt[q]) return FWD_PERMUTE;
+            return fwd_cnt[q] == cnt ? FWD_SAME_ALL : FWD_SAME_SOME;
+        };
+        uint32_t lin = LIN_MIXED;
+        if (cl == C_LIN) lin = (n_add == cnt) ? LIN_ALL_ADD : (n_sub == cnt) ? LIN_ALL_SUB : LIN_MIXED;
+        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | (mode_of(0) << HDR_AMODE_SHIFT) | (mode_of(1) << HDR_BMODE_SHIFT) |
+                     (lin << HDR_LIN_SHIFT);
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);
     }
-    out.n_slots = std::max(n_slots, 1u);
+    n_slots = std::max(n_slots, 1u);
+    if (ws_const_bytes(out.n_const, T) + ws_tile_bytes(n_slots, T) > 0xffffffffull) {
+        err = "graph too large: one tile of the value workspace exceeds the 4 GiB buffer range";
+        return false;
+    }
+    // second pass: destination byte offsets (trash slot = n_slots) and inactive padding records
+    for (uint32_t b = 0; b < NB; ++b) {
+        const uint32_t cnt = bundle_start[b + 1] - bundle_start[b];
+        for (uint32_t q = 0; q < cnt; ++q) {
+            uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
+            const uint32_t slot = r[1] == 0xffffffffu ? n_slots : r[1];
+            r[1] = (uint32_t)((uint64_t)slot * slot_bytes);
+        }
+        for (uint32_t q = cnt; q < G; ++q) {  // inactive node slots: record 0 without the ACTIVE bit, store -> trash
+            uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
+            memcpy(r, &out.recs[(size_t)b * G * 4], 16);
+            r[0] &= ~CTRL_ACTIVE;
+            r[1] = (uint32_t)((uint64_t)n_slots * slot_bytes);
+            out.crefs[(size_t)b * G + q] = out.crefs[(size_t)b * G];
+        }
+    }
+    out.n_slots = n_slots;
     out.n_inputs = (uint32_t)n_in_buf;
     out.n_witness = (uint32_t)g.witness_signals.size();
     out.witness_refs.resize(out.n_witness);

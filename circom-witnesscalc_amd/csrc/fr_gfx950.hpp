@@ -110,6 +110,9 @@ FRD Fr fr_neg(const Fr& a) {
 // Montgomery product a*b/2^256 mod r.  Requires b < r; a may be any value < 2^256
 // (result < r after one conditional subtraction since (a*b + m*r)/2^256 < b + r < 2r).
 FRD Fr fr_mul(const Fr& a, const Fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CWC_PORTABLE_FR_MUL)
+#include "fr_mul_gfx950.inc"
+#else
     const uint32_t p[8] = {CWC_P0, CWC_P1, CWC_P2, CWC_P3, CWC_P4, CWC_P5, CWC_P6, CWC_P7};
     uint32_t t[9];
 #pragma unroll
@@ -141,6 +144,7 @@ FRD Fr fr_mul(const Fr& a, const Fr& b) {
     for (int i = 0; i < 8; ++i) r.v[i] = t[i];
     uint32_t br = u256_sub(s, r, fr_p());
     return u256_select(br != 0, r, s);
+#endif
 }
 FRD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 

@@ -25,31 +25,56 @@ __device__ __forceinline__ Fr fr_from_u4(const uint4& lo, const uint4& hi) {
 // wave-wide OR-reduction of a predicate ("does any lane need the slow path")
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
-// PROF = true is a diagnostic build (gwb_profile_classes): s_memtime stamps around the operand loads, the
-// arithmetic and the store of every bundle, summed per bundle class by lane 0 of every 64th tile.  Its
-// waits serialise the loop, so read its shares, not its length; no stamp executes in the product kernel.
+// PROF = true is a diagnostic build (gwb_profile_classes): one s_memtime per bundle, summed per bundle class by
+// lane 0 of every 64th tile: [cycles, cycles of bundles with a forwarded operand, such bundles, bundles].
+// No stamp executes in the product kernel.
+//
+// The program arrays are separate `const __restrict__` kernel arguments (not a by-value struct) so that hipcc can
+// prove them read-only: the wave-uniform header stream then becomes scalar loads (s_load) instead of vector loads
+// + v_readfirstlane, whose early s_waitcnt would expose the latency of the operand prefetch.
+struct InterpDims {
+    uint32_t n_bundles, n_slots, n_inputs, batch, n_const;
+};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int T, bool PROF>
-__global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, const uint4* __restrict__ inputs,
-                                                    uint32_t* __restrict__ status, uint32_t batch,
+__global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
+                                                    const uint32_t* __restrict__ crefs, InterpDims p, void* ws,
+                                                    const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
+    const uint32_t batch = p.batch;
     const int lane = (int)threadIdx.x;
     const int t = lane % T;
     const int j = (G == 1) ? 0 : lane / T;
     const uint32_t tile = blockIdx.x;
     const uint32_t set = tile * T + (uint32_t)t;
     const uint32_t set_c = set < batch ? set : batch - 1;  // padded lanes of the last tile re-evaluate a real set
-    uint4* tv = vals + (size_t)tile * p.n_slots * (2 * T);
-    const uint4* consts = reinterpret_cast<const uint4*>(p.consts);
-    const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
+    // One buffer descriptor over the launch's workspace [constants | tiles]; all operand / destination addresses are
+    // 32-bit byte offsets into it (host-computed, plus this lane's base for tile-relative ones).
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_slots, T);
+    const uint64_t ws_bytes = ws_const_bytes(p.n_const, T) + (uint64_t)gridDim.x * tile_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(uint32_t)ws_bytes, 0x00020000);
+    const uint32_t lane_base = (uint32_t)(ws_const_bytes(p.n_const, T) + (uint64_t)tile * tile_bytes) + 16u * (uint32_t)t;
+    constexpr int HI = 16 * T;  // byte distance between the two 16-byte halves of a value
 
-    auto load = [&](uint32_t ref) -> Fr {
-        const bool k = (ref & REF_CONST) != 0;
-        const uint32_t idx = ref & ~REF_CONST;
-        const uint4* q = k ? consts + (size_t)idx * 2 : tv + (size_t)idx * (2 * T) + t;
-        const uint32_t step = k ? 1u : (uint32_t)T;
-        const uint4 lo = q[0], hi = q[step];
-        return fr_from_u4(lo, hi);
+    auto ld = [&](uint32_t off) -> Fr {
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + HI, 0, 0);
+        return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    auto opnd_off = [&](uint32_t off, uint32_t ctrl, uint32_t tile_bit) -> uint32_t {
+        return off + ((ctrl & tile_bit) ? lane_base : 0u);
+    };
+    auto permute = [&](const Fr& mem, bool fwd, uint32_t src_slot, const Fr& prev) -> Fr {
+        const int src = (int)((src_slot * (uint32_t)T + (uint32_t)t) << 2);  // byte address of the source lane
+        Fr o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)prev.v[i]);
+            o.v[i] = fwd ? v : mem.v[i];
+        }
+        return o;
     };
     uint32_t err_bits = 0;
     unsigned long long pf[C_COUNT][4];
@@ -57,77 +82,78 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
 #pragma unroll
         for (int c = 0; c < (int)C_COUNT; ++c) pf[c][0] = pf[c][1] = pf[c][2] = pf[c][3] = 0;
     }
-    auto stamp = [&]() -> unsigned long long {
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long t = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_sched_barrier(0);
-        return t;
-    };
+    unsigned long long t_prev = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
 
-    // Software pipeline: the header and the records of bundle b+1 are fetched while bundle b computes, so
-    // that only the operand loads (which depend on earlier stores) sit on the critical path.
-    uint32_t h_next = p.n_bundles ? p.hdr[0] : 0u;
-    uint4 rec_next = p.n_bundles ? recs[j] : make_uint4(0, 0, 0, 0);
-    for (uint32_t b = 0; b < p.n_bundles; ++b) {
-        const uint32_t h = h_next;
-        const uint4 rec = rec_next;
-        {
-            const uint32_t nb = b + 1 < p.n_bundles ? b + 1 : b;
-            h_next = p.hdr[nb];
-            rec_next = recs[(size_t)nb * G + j];
-        }
-        const uint32_t cls = h & 0xffu;
-        const uint32_t cnt = h >> 8;
-        const bool active = (uint32_t)j < cnt;  // inactive node slots carry a copy of record 0 (valid operands)
-        const uint32_t sub = rec.x;
+    // Software pipeline.  While bundle b computes: its own memory operands were fetched during bundle b-1, the
+    // memory operands of bundle b+1 and the header + records of bundle b+2 are in flight.  Only forwarded operands
+    // (register reads, same lane or ds_bpermute) and the arithmetic sit on the chain between consecutive bundles.
+    const uint32_t NBND = p.n_bundles;
+    if (NBND == 0) return;
+    auto clampb = [&](uint32_t b) { return b < NBND ? b : NBND - 1; };
+    uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
+    uint4 rec_cur = recs[j], rec_n1 = recs[(size_t)clampb(1) * G + j];
+    Fr ma_cur = ld(opnd_off(rec_cur.z, rec_cur.x, CTRL_A_TILE) & (((h_cur & HDR_CLASS_MASK) == C_INPUT) ? 0u : ~0u));
+    Fr mb_cur = ld(opnd_off(rec_cur.w, rec_cur.x, CTRL_B_TILE));
+    Fr prev = fr_zero();
+    for (uint32_t b = 0; b < NBND; ++b) {
+        const uint32_t h = h_cur;
+        const uint4 rec = rec_cur;
+        const uint32_t ctrl = rec.x;
+        // prefetch: memory operands of bundle b+1 (INPUT records carry an input index in .z: fetch offset 0 instead),
+        // header / records of bundle b+2
+        const uint32_t a_n1 = opnd_off(rec_n1.z, rec_n1.x, CTRL_A_TILE) & (((h_n1 & HDR_CLASS_MASK) == C_INPUT) ? 0u : ~0u);
+        const Fr ma_n1 = ld(a_n1);
+        const Fr mb_n1 = ld(opnd_off(rec_n1.w, rec_n1.x, CTRL_B_TILE));
+        const uint32_t b2 = clampb(b + 2);
+        const uint32_t h_n2 = hdr[b2];
+        const uint4 rec_n2 = recs[(size_t)b2 * G + j];
+
+        const uint32_t cls = h & HDR_CLASS_MASK;
+        const uint32_t amode = (h >> HDR_AMODE_SHIFT) & 3u, bmode = (h >> HDR_BMODE_SHIFT) & 3u;
+        const bool active = (ctrl & CTRL_ACTIVE) != 0;
+        const uint32_t sub = (ctrl >> CTRL_SUB_SHIFT) & 0xffu;
+        Fr a_op = ma_cur, b_op = mb_cur;
+        if (amode == FWD_SAME_ALL) a_op = prev;
+        else if (amode == FWD_SAME_SOME) a_op = u256_select((ctrl & CTRL_A_FWD) != 0, prev, ma_cur);
+        else if (amode == FWD_PERMUTE) a_op = permute(ma_cur, (ctrl & CTRL_A_FWD) != 0, (ctrl >> CTRL_ASRC_SHIFT) & 63u, prev);
+        if (bmode == FWD_SAME_ALL) b_op = prev;
+        else if (bmode == FWD_SAME_SOME) b_op = u256_select((ctrl & CTRL_B_FWD) != 0, prev, mb_cur);
+        else if (bmode == FWD_PERMUTE) b_op = permute(mb_cur, (ctrl & CTRL_B_FWD) != 0, (ctrl >> CTRL_BSRC_SHIFT) & 63u, prev);
         Fr r;
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-        if (PROF) {
-            ts0 = stamp();
-            // touch the operands so that their loads complete before ts1
-            if (cls != C_INPUT) {
-                const Fr a0 = load(rec.z), c0 = load(rec.w);
-                asm volatile("" ::"v"(a0.v[0]), "v"(c0.v[7]));
-            }
-            ts1 = stamp();
-        }
         switch (cls) {
+            case C_MUL: {  // graph.rs:105
+                r = fr_mul(a_op, b_op);
+                break;
+            }
+            case C_LIN: {  // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a
+                const uint32_t lin = (h >> HDR_LIN_SHIFT) & 3u;
+                if (lin == LIN_ALL_ADD) r = fr_add(a_op, b_op);
+                else if (lin == LIN_ALL_SUB) r = fr_sub(a_op, b_op);
+                else {  // a + (+-b): r - b for Sub (b = 0 gives a + r, folded by the final conditional subtraction)
+                    Fr nb;
+                    u256_sub(nb, fr_p(), b_op);
+                    r = fr_add(a_op, u256_select(sub == OP_ADD, b_op, nb));
+                }
+                break;
+            }
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + rec.z) * 2;
                 r = fr_to_mont(fr_from_u4(q[0], q[1]));
                 break;
             }
-            case C_MUL: {  // graph.rs:105
-                const Fr a = load(rec.z), c = load(rec.w);
-                r = fr_mul(a, c);
-                break;
-            }
-            case C_LIN: {  // graph.rs:110-111 Add/Sub, :188-194 Neg (= 0 - a)
-                const Fr a = load(rec.z), c = load(rec.w);  // Neg records carry b = a
-                // one modular addition: x + (+-y), with -y = r - y (0 stays 0)
-                const bool is_neg = sub == SUB_NEG;
-                const Fr x = u256_select(is_neg, fr_zero(), a);
-                const Fr y = u256_select(is_neg, a, c);
-                r = fr_add(x, u256_select(sub == OP_ADD, y, fr_neg(y)));
-                break;
-            }
             case C_DIV: {  // graph.rs:109  b == 0 -> 0 else a / b
-                const Fr a = load(rec.z), c = load(rec.w);
-                const Fr inv = fr_inv(c);  // safegcd divsteps; inv(0) = 0
-                r = u256_select(u256_is_zero(c), fr_zero(), fr_mul(a, inv));
+                const Fr inv = fr_inv(b_op);  // safegcd divsteps; inv(0) = 0
+                r = u256_select(u256_is_zero(b_op), fr_zero(), fr_mul(a_op, inv));
                 break;
             }
             case C_CMPZ: {  // graph.rs:122-129 Eq/Neq, :134-135 Land/Lor
-                const Fr a = load(rec.z), c = load(rec.w);
-                const bool az = u256_is_zero(a), cz = u256_is_zero(c), eq = u256_eq(a, c);
+                const bool az = u256_is_zero(a_op), cz = u256_is_zero(b_op), eq = u256_eq(a_op, b_op);
                 const bool v = sub == OP_EQ ? eq : sub == OP_NEQ ? !eq : sub == OP_LAND ? (!az && !cz) : (!az || !cz);
                 r = u256_select(v, fr_one(), fr_zero());
                 break;
             }
             case C_CMPS: {  // graph.rs:130-133 with u_lt/u_gt/u_lte/u_gte :723-769
-                const Fr x = fr_from_mont(load(rec.z)), y = fr_from_mont(load(rec.w));
+                const Fr x = fr_from_mont(a_op), y = fr_from_mont(b_op);
                 const bool xn = u256_lt(fr_half(), x), yn = u256_lt(fr_half(), y);
                 const bool same = xn == yn;
                 const bool lt = same ? u256_lt(x, y) : xn;
@@ -137,7 +163,7 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
                 break;
             }
             case C_BIT: {  // graph.rs:621-717
-                const Fr x = fr_from_mont(load(rec.z)), y = fr_from_mont(load(rec.w));
+                const Fr x = fr_from_mont(a_op), y = fr_from_mont(b_op);
                 uint32_t hi_or = 0;
 #pragma unroll
                 for (int i = 1; i < 8; ++i) hi_or |= y.v[i];
@@ -173,7 +199,7 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
                 break;
             }
             case C_IDIVMOD: {  // graph.rs:112-121
-                const Fr x = fr_from_mont(load(rec.z)), y = fr_from_mont(load(rec.w));
+                const Fr x = fr_from_mont(a_op), y = fr_from_mont(b_op);
                 const bool yz = u256_is_zero(y);
                 Fr ys = y;
                 ys.v[0] |= yz ? 1u : 0u;
@@ -190,35 +216,38 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
                 r = fr_to_mont(d);
                 break;
             }
-            case C_TERN: {  // graph.rs:221-225  a == 0 ? c : b
-                const Fr a = load(rec.z), x = load(rec.w), y = load(p.crefs[(size_t)b * G + j]);
-                r = u256_select(u256_is_zero(a), y, x);
+            case C_TERN: {  // graph.rs:221-225  a == 0 ? c : b ; the third operand is always a memory reference
+                const uint32_t cr = crefs[(size_t)b * G + j];
+                const Fr y = ld((cr & ~CREF_TILE) + ((cr & CREF_TILE) ? lane_base : 0u));
+                r = u256_select(u256_is_zero(a_op), y, b_op);
                 break;
             }
             default: r = fr_zero(); break;
         }
-        if (PROF) {
-            asm volatile("" ::"v"(r.v[0]), "v"(r.v[7]));
-            ts2 = stamp();
+        {   // unconditional store (the host points values without a slot and inactive node slots at the tile's trash
+            // slot): a fixed number of stores per bundle lets the waitcnt pass count them instead of draining
+            const uint32_t doff = rec.y + lane_base;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[0], r.v[1], r.v[2], r.v[3]}, rsrc, (int)doff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[4], r.v[5], r.v[6], r.v[7]}, rsrc, (int)doff + HI, 0, 0);
         }
-        if (active) {
-            uint4* q = tv + (size_t)rec.y * (2 * T) + t;
-            q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-            q[T] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-        }
-        // Later bundles read these stores from other lanes of this wave; a wave's vector-memory
-        // instructions execute in order, the fence only keeps the compiler from reordering them.
+        prev = r;
+        h_cur = h_n1; rec_cur = rec_n1; ma_cur = ma_n1; mb_cur = mb_n1;
+        h_n1 = h_n2; rec_n1 = rec_n2;
+        // Later bundles read these stores from other lanes of this wave; a wave's vector-memory instructions
+        // execute in order, the fence only keeps the compiler from reordering them.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (PROF) {
-            const unsigned long long ts3 = stamp();
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            const bool fwd = (amode | bmode) != 0;
 #pragma unroll
             for (int c = 0; c < (int)C_COUNT; ++c)
                 if (cls == (uint32_t)c) {
-                    pf[c][0] += ts1 - ts0;
-                    pf[c][1] += ts2 - ts1;
-                    pf[c][2] += ts3 - ts2;
+                    pf[c][0] += t_now - t_prev;              // cycles of this bundle in the pipelined loop
+                    pf[c][1] += fwd ? (t_now - t_prev) : 0;  // ... of which bundles with a forwarded operand
+                    pf[c][2] += fwd ? 1 : 0;
                     pf[c][3] += 1;
                 }
+            t_prev = t_now;
         }
     }
     if (PROF && lane == 0 && (tile % 64u) == 0u) {
@@ -230,20 +259,21 @@ __global__ __launch_bounds__(64) void interp_kernel(ProgramDev p, uint4* vals, c
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, const uint4* __restrict__ vals, uint4* __restrict__ out,
+__global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, const uint4* __restrict__ ws, uint4* __restrict__ out,
                                                    uint32_t batch, uint32_t T) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= p.n_witness) return;
     const uint32_t ref = p.witness_refs[w];
-    const uint4* consts = reinterpret_cast<const uint4*>(p.consts);
+    const uint4* consts = ws;  // head of the workspace
+    const uint4* vals = ws + ws_const_bytes(p.n_const, T) / 16;
     for (uint32_t set = blockIdx.y; set < batch; set += gridDim.y) {
         Fr v;
         if (ref & REF_CONST) {
-            const uint4* q = consts + (size_t)(ref & ~REF_CONST) * 2;
-            v = fr_from_u4(q[0], q[1]);
+            const uint4* q = consts + (size_t)(ref & ~REF_CONST) * (2 * T);
+            v = fr_from_u4(q[0], q[T]);
         } else {
             const uint32_t tile = set / T, t = set % T;
-            const uint4* q = vals + ((size_t)tile * p.n_slots + ref) * (2 * T) + t;
+            const uint4* q = vals + ((size_t)tile * (p.n_slots + 1) + ref) * (2 * T) + t;
             v = fr_from_u4(q[0], q[T]);
         }
         const Fr c = fr_from_mont(v);
@@ -258,12 +288,13 @@ hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void
                          uint32_t batch, hipStream_t stream, unsigned long long* prof) {
     const uint32_t tiles = (batch + T - 1) / T;
     dim3 grid(tiles), block(64);
-    uint4* v = (uint4*)vals;
     const uint4* in = (const uint4*)inputs;
-#define CWC_LAUNCH(TT)                                                                               \
-    case TT:                                                                                         \
-        if (prof) interp_kernel<TT, true><<<grid, block, 0, stream>>>(p, v, in, status, batch, prof); \
-        else interp_kernel<TT, false><<<grid, block, 0, stream>>>(p, v, in, status, batch, nullptr);  \
+    const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const};
+    const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
+#define CWC_LAUNCH(TT)                                                                                              \
+    case TT:                                                                                                        \
+        if (prof) interp_kernel<TT, true><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, vals, in, status, prof);    \
+        else interp_kernel<TT, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, vals, in, status, nullptr);   \
         break;
     switch (T) {
         CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32) CWC_LAUNCH(64)

@@ -27,9 +27,9 @@ struct ProgramStats {
 struct Program {
     uint32_t T = 0, G = 0;
     uint32_t n_bundles = 0, n_slots = 0, n_const = 0, n_inputs = 0, n_witness = 0;
-    std::vector<uint32_t> hdr;           // [n_bundles]      class | count << 8
-    std::vector<uint32_t> recs;          // [n_bundles*G*4]  {subop, dst slot, a ref, b ref}
-    std::vector<uint32_t> crefs;         // [n_bundles*G]    third operand ref (C_TERN), else 0
+    std::vector<uint32_t> hdr;           // [n_bundles]      see program_dev.h (format v2)
+    std::vector<uint32_t> recs;          // [n_bundles*G*4]  {ctrl, dst byte offset, a byte offset, b byte offset}
+    std::vector<uint32_t> crefs;         // [n_bundles*G]    third operand byte offset (C_TERN), else 0
     std::vector<uint32_t> consts;        // [n_const*8]      Montgomery form
     std::vector<uint32_t> witness_refs;  // [n_witness]      slot or REF_CONST|idx
     ProgramStats stats;

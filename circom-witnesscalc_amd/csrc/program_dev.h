@@ -4,6 +4,12 @@
 
 #include "ops.h"
 
+#if defined(__HIPCC__)
+#define CWC_HD __host__ __device__ static inline
+#else
+#define CWC_HD static inline
+#endif
+
 namespace cwc {
 
 // bundle classes (wave-uniform: one scalar branch per bundle, no divergence on op type)
@@ -20,10 +26,30 @@ enum BundleClass : uint32_t {
     C_COUNT = 9
 };
 
-// per-lane sub-op codes inside a record: DuoOp wire codes 0..19 plus
-enum SubOp : uint32_t { SUB_NEG = 32, SUB_TERN = 33, SUB_INPUT = 34 };
+// Program format v2 -- laid out so that the interpreter spends (almost) no instructions on decoding.
+//
+// hdr[bundle] (wave-uniform, fetched with scalar loads):
+//   bits 0-3 class | bits 4-10 node count | bits 11-12 A mode | bits 13-14 B mode | bits 15-16 LIN mode
+// operand modes:   0 memory only   1 some lanes forward through ds_bpermute   2 forwarded lanes read their OWN
+//                  previous result (select)   3 every lane reads its own previous result (no instruction)
+// LIN mode:        0 mixed Add/Sub   1 all Add   2 all Sub          (Neg is compiled as 0 - a)
+//
+// rec[bundle][node slot] = {ctrl, dst, a, b}: dst/a/b are BYTE offsets for raw_buffer_load/store through one
+// descriptor over the workspace [constant table | tile 0 | tile 1 | ...]; offsets flagged tile-relative get the
+// lane's base (tile base + 16*t) added.  ctrl: bit0 a tile-relative, bit1 b tile-relative, bit2 a forwarded,
+// bit3 b forwarded, bits 4-9 / 10-15 source node slot of a / b, bits 16-23 DuoOp code (or SUB_*), bit 24 active.
+static const uint32_t HDR_CLASS_MASK = 0xfu;
+static const int HDR_COUNT_SHIFT = 4, HDR_AMODE_SHIFT = 11, HDR_BMODE_SHIFT = 13, HDR_LIN_SHIFT = 15;
+enum FwdMode : uint32_t { FWD_NONE = 0, FWD_PERMUTE = 1, FWD_SAME_SOME = 2, FWD_SAME_ALL = 3 };
+enum LinMode : uint32_t { LIN_MIXED = 0, LIN_ALL_ADD = 1, LIN_ALL_SUB = 2 };
+static const uint32_t CTRL_A_TILE = 1u << 0, CTRL_B_TILE = 1u << 1, CTRL_A_FWD = 1u << 2, CTRL_B_FWD = 1u << 3,
+                      CTRL_ACTIVE = 1u << 24;
+static const int CTRL_ASRC_SHIFT = 4, CTRL_BSRC_SHIFT = 10, CTRL_SUB_SHIFT = 16;
+// third operand (TernCond) byte offset: bit 31 = tile-relative (always a memory reference)
+static const uint32_t CREF_TILE = 0x80000000u;
+enum SubOp : uint32_t { SUB_TERN = 33, SUB_INPUT = 34 };
 
-// operand reference: bit 31 set -> constant table index, else value slot of the tile
+// witness reference (pack kernel): bit 31 set -> constant table index, else value slot of the tile
 static const uint32_t REF_CONST = 0x80000000u;
 
 // per-set status bits written by the kernels (the reference panics in these cases)
@@ -32,14 +58,21 @@ enum SetStatus : uint32_t {
     ST_BITOP_EQ_R = 2u,    // Bor/Bxor result == r       (graph.rs:701,716)
 };
 
-// Device pointers of an uploaded program (kernel argument).
+// Device pointers of an uploaded program.
 struct ProgramDev {
     const uint32_t* hdr;           // [n_bundles]
     const uint32_t* recs;          // [n_bundles*G*4], 16-byte aligned records
     const uint32_t* crefs;         // [n_bundles*G]
-    const uint32_t* consts;        // [n_const*8], 16-byte aligned halves
+    const uint32_t* consts;        // [n_const*8] Montgomery form; copied to the head of the workspace per launch
     const uint32_t* witness_refs;  // [n_witness]
-    uint32_t n_bundles, n_slots, n_inputs, n_witness;
+    uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
 };
+
+// workspace geometry shared by host and kernels: [constants, padded to 256 B][tiles]
+// tile = (n_slots + 1) slots (the last one is the trash slot) of 32*T bytes: [slot][half][T][16 B].
+// A constant uses the same geometry (32*T bytes apart, halves 16*T apart, only the first 16 bytes of each half
+// used) so that every operand's high half sits at the same fixed distance from its low half.
+CWC_HD uint64_t ws_const_bytes(uint32_t n_const, uint32_t T) { return (((uint64_t)n_const * 32u * T) + 255u) & ~255ull; }
+CWC_HD uint64_t ws_tile_bytes(uint32_t n_slots, uint32_t T) { return ((uint64_t)n_slots + 1u) * 32u * T; }
 
 }  // namespace cwc

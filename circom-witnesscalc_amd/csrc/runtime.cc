@@ -77,12 +77,13 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_slots = p.n_slots;
     dp.dev.n_inputs = p.n_inputs;
     dp.dev.n_witness = p.n_witness;
+    dp.dev.n_const = p.n_const;
     return "";
 }
 
 uint64_t workspace_budget() {
     const char* e = getenv("CWC_WORKSPACE_GB");
-    double gb = e ? atof(e) : 48.0;
+    double gb = e ? atof(e) : 3.9;
     if (gb < 0.25) gb = 0.25;
     return (uint64_t)(gb * (double)(1ull << 30));
 }
@@ -182,13 +183,19 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     std::string err = get_program(g, T, &dp);
     if (!err.empty()) return err;
     const Program& p = dp->host;
-    // chunk the batch so that the value workspace stays within budget
-    const uint64_t bytes_per_tile = (uint64_t)p.n_slots * T * 32;
-    uint64_t max_tiles = workspace_budget() / (bytes_per_tile ? bytes_per_tile : 1);
+    // Workspace of one launch: [constant table | tiles]; addressed with 32-bit byte offsets through one buffer
+    // descriptor, so it must stay below 4 GiB; larger batches are evaluated in chunks.
+    const uint64_t const_bytes = ws_const_bytes(p.n_const, T);
+    const uint64_t bytes_per_tile = ws_tile_bytes(p.n_slots, T);
+    uint64_t budget = workspace_budget();
+    const uint64_t cap = 0xffffffffull - 4096;
+    if (budget > cap) budget = cap;
+    if (const_bytes + bytes_per_tile > cap) return "graph too large for the 4 GiB workspace window";
+    uint64_t max_tiles = budget > const_bytes ? (budget - const_bytes) / bytes_per_tile : 0;
     if (max_tiles == 0) max_tiles = 1;
     const uint64_t tiles_total = (batch + T - 1) / T;
     const uint64_t chunk_tiles = tiles_total < max_tiles ? tiles_total : max_tiles;
-    const size_t need = (size_t)(chunk_tiles * bytes_per_tile);
+    const size_t need = (size_t)(const_bytes + chunk_tiles * bytes_per_tile);
     if (need > g->vals_bytes) {
         if (g->d_vals) HIP_TRY(hipFree(g->d_vals));
         g->d_vals = nullptr;
@@ -196,6 +203,8 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         HIP_TRY(hipMalloc(&g->d_vals, need));
         g->vals_bytes = need;
     }
+    // constants into slot geometry: 16-byte halves, 16*T bytes apart
+    HIP_TRY(hipMemcpy2DAsync(g->d_vals, (size_t)16 * T, dp->dev.consts, 16, 16, (size_t)p.n_const * 2, hipMemcpyDeviceToDevice, stream));
     g->drop_events();
     g->timing = gwb_timing_t{};
     g->timing.tile_width = T;

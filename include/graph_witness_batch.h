@@ -72,8 +72,8 @@ int gwb_calc_witness_batch_host(gwb_graph_t *g, const void *inputs, size_t batch
 /* Kernel times of the last batch call on this handle (synchronizes on its events). */
 int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 
-/* Diagnostic build of the interpreter with in-kernel cycle stamps: out36[class*4 + {operand-load, compute,
- * store, bundles}] in shader cycles summed over the sampled waves.  Serialised -- read shares, not totals. */
+/* Diagnostic build of the interpreter with one in-kernel cycle stamp per bundle: out36[class*4 + {cycles, cycles
+ * of bundles with a forwarded operand, such bundles, bundles}], shader cycles summed over the sampled waves. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out36, gw_status_t *status);
 

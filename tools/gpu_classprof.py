@@ -26,9 +26,9 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     t = g.last_timing()
     prof = g.profile_classes(d_in, d_out, d_st)
     nw = max(1, (B + tw - 1) // tw // 64 + (1 if ((B + tw - 1) // tw) % 64 else 0))
-    tot = sum(sum(v[:3]) for v in prof.values())
+    tot = sum(v[0] for v in prof.values())
     print("T=%d B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw, B, t["interp_ms"], nw, tot / nw))
-    for k, (ld, cp, stc, n) in prof.items():
+    for k, (cyc, cyc_f, n_f, n) in prof.items():
         if n:
-            print("   %-8s bundles/wave %7d  per bundle: load %7.0f  compute %8.0f  store %6.0f cycles   share %.1f%%" % (
-                k, n // nw, ld / n, cp / n, stc / n, 100.0 * (ld + cp + stc) / tot))
+            print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  (forwarded: %6d bundles/wave at %8.0f; others at %8.0f)  share %.1f%%" % (
+                k, n // nw, cyc / n, n_f // nw, cyc_f / max(n_f, 1), (cyc - cyc_f) / max(n - n_f, 1), 100.0 * cyc / tot))
