@@ -229,16 +229,29 @@ FRD int32_t sgcd_divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, Trans2x2& t
     return zeta;
 }
 
+// a*b + c on signed 32-bit factors and a signed 64-bit addend: one v_mad_i64_i32 on the device (hipcc expands the
+// C expression into unsigned mads plus sign fix-ups, ~10 instructions)
+FRD int64_t mad_i64(int32_t a, int32_t b, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d;
+    unsigned long long cy;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return (int64_t)a * b + c;
+#endif
+}
+
 FRD void sgcd_update_fg(S30& f, S30& g, const Trans2x2& t) {
     const int32_t M30 = 0x3fffffff;
-    int64_t cf = (int64_t)t.u * f.v[0] + (int64_t)t.v * g.v[0];
-    int64_t cg = (int64_t)t.q * f.v[0] + (int64_t)t.r * g.v[0];
+    int64_t cf = mad_i64(t.u, f.v[0], mad_i64(t.v, g.v[0], 0));
+    int64_t cg = mad_i64(t.q, f.v[0], mad_i64(t.r, g.v[0], 0));
     cf >>= 30;  // the low 30 bits are zero by construction
     cg >>= 30;
 #pragma unroll
     for (int i = 1; i < 9; ++i) {
-        cf += (int64_t)t.u * f.v[i] + (int64_t)t.v * g.v[i];
-        cg += (int64_t)t.q * f.v[i] + (int64_t)t.r * g.v[i];
+        cf = mad_i64(t.u, f.v[i], mad_i64(t.v, g.v[i], cf));
+        cg = mad_i64(t.q, f.v[i], mad_i64(t.r, g.v[i], cg));
         f.v[i - 1] = (int32_t)cf & M30;
         cf >>= 30;
         g.v[i - 1] = (int32_t)cg & M30;
@@ -256,20 +269,20 @@ FRD void sgcd_update_de(S30& d, S30& e, const Trans2x2& t) {
     const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
     int32_t md = (t.u & sd) + (t.v & se);
     int32_t me = (t.q & sd) + (t.r & se);
-    int64_t cd = (int64_t)t.u * d.v[0] + (int64_t)t.v * e.v[0];
-    int64_t ce = (int64_t)t.q * d.v[0] + (int64_t)t.r * e.v[0];
+    int64_t cd = mad_i64(t.u, d.v[0], mad_i64(t.v, e.v[0], 0));
+    int64_t ce = mad_i64(t.q, d.v[0], mad_i64(t.r, e.v[0], 0));
     md -= (int32_t)((pinv30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
     me -= (int32_t)((pinv30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-    cd += (int64_t)p30[0] * md;
-    ce += (int64_t)p30[0] * me;
+    cd = mad_i64(p30[0], md, cd);
+    ce = mad_i64(p30[0], me, ce);
     cd >>= 30;
     ce >>= 30;
 #pragma unroll
     for (int i = 1; i < 9; ++i) {
-        cd += (int64_t)t.u * d.v[i] + (int64_t)t.v * e.v[i];
-        ce += (int64_t)t.q * d.v[i] + (int64_t)t.r * e.v[i];
-        cd += (int64_t)p30[i] * md;
-        ce += (int64_t)p30[i] * me;
+        cd = mad_i64(t.u, d.v[i], mad_i64(t.v, e.v[i], cd));
+        ce = mad_i64(t.q, d.v[i], mad_i64(t.r, e.v[i], ce));
+        cd = mad_i64(p30[i], md, cd);
+        ce = mad_i64(p30[i], me, ce);
         d.v[i - 1] = (int32_t)cd & M30;
         cd >>= 30;
         e.v[i - 1] = (int32_t)ce & M30;
@@ -277,6 +290,51 @@ FRD void sgcd_update_de(S30& d, S30& e, const Trans2x2& t) {
     }
     d.v[8] = (int32_t)cd;
     e.v[8] = (int32_t)ce;
+}
+
+// Variable-time batch of 30 divsteps (delta = 1 convention, eta = -delta): trailing zeros of g are consumed in one
+// go and up to 6 low bits of g are cancelled per iteration with w = g * f * (f^2 - 2) (f odd: f*(f^2-2) = -1/f mod 64).
+// Lanes iterate until their own 30 steps are used up (exec-masked loop); ~3x fewer instructions than the
+// constant-time batch.  No secrets here, data-dependent time is fine.
+FRD int32_t sgcd_divsteps_30_var(int32_t eta, uint32_t f0, uint32_t g0, Trans2x2& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    uint32_t f = f0, g = g0;
+    int i = 30;
+    for (;;) {
+        // count trailing zeros of g, but at most i (sentinel bit)
+        const uint32_t gs = g | (0xffffffffu << i);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int zeros = __builtin_ctz(gs);
+#else
+        const int zeros = __builtin_ctz(gs);
+#endif
+        g >>= zeros;
+        u <<= zeros;
+        v <<= zeros;
+        eta -= zeros;
+        i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {  // swap roles: (f, g) <- (g, -f), matrix rows alike
+            uint32_t tmp;
+            eta = -eta;
+            tmp = f; f = g; g = 0u - tmp;
+            tmp = u; u = q; q = 0u - tmp;
+            tmp = v; v = r; r = 0u - tmp;
+        }
+        // cancel min(eta + 1, i, 6) low bits of g
+        int limit = eta + 1 > i ? i : eta + 1;
+        limit = limit > 6 ? 6 : limit;
+        const uint32_t m = (1u << limit) - 1u;
+        const uint32_t w = (g * f * (f * f - 2u)) & m;
+        g += f * w;
+        q += u * w;
+        r += v * w;
+    }
+    t.u = (int32_t)u;
+    t.v = (int32_t)v;
+    t.q = (int32_t)q;
+    t.r = (int32_t)r;
+    return eta;
 }
 
 // canonical integer x in [0, r) -> x^-1 mod r (canonical); 0 -> 0
@@ -296,6 +354,7 @@ FRD Fr u256_inv_mod_r(const Fr& x) {
         g.v[i] = (int32_t)((uint32_t)(w >> sh) & (uint32_t)M30);
     }
     e.v[0] = 1;
+#if defined(CWC_CONSTANT_TIME_INVERSE)
     int32_t zeta = -1;
     for (int it = 0; it < 20; ++it) {
         Trans2x2 t;
@@ -303,6 +362,23 @@ FRD Fr u256_inv_mod_r(const Fr& x) {
         sgcd_update_de(d, e, t);
         sgcd_update_fg(f, g, t);
     }
+#else
+    int32_t eta = -1;
+    for (int it = 0; it < 25; ++it) {  // 25 x 30 = 750 >= the 735-divstep bound of the delta = 1 variant
+        Trans2x2 t;
+        eta = sgcd_divsteps_30_var(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        sgcd_update_de(d, e, t);
+        sgcd_update_fg(f, g, t);
+        int32_t gz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gz |= g.v[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__ballot(gz != 0) == 0ull) break;  // every lane of the wave is done (extra batches are harmless: g = 0)
+#else
+        if (gz == 0) break;
+#endif
+    }
+#endif
     // g == 0 now and f == +-1 (x invertible) ; result = d * sign(f), normalised into [0, r)
     const int32_t sign = f.v[8] >> 31;
     int32_t cond_add = d.v[8] >> 31;
