@@ -107,28 +107,95 @@ bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err)
     st.depth = depth;
 
     // ---- schedule: order of evaluated nodes (inputs + ops) and bundle boundaries ----
+    // G == 1: file order (the reference's own loop order; best locality, every bundle is one node anyway).
+    // G  > 1: list scheduling.  One bundle = up to G ready nodes of ONE class; a node is ready when all its
+    // producers sit in earlier bundles.  The class of the next bundle is that of the ready node with the longest
+    // cost-weighted path to a sink (critical path first); nodes with slack wait until their class comes up, so
+    // chains that are at different op classes in the same dependency level share bundles across levels instead
+    // of costing one bundle per (level, class).
     std::vector<uint32_t> order;
     order.reserve(N);
-    for (size_t i = 0; i < N; ++i)
-        if (g.nodes[i].kind != N_CONST) order.push_back((uint32_t)i);
-    if (G > 1) {
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            if (level[x] != level[y]) return level[x] < level[y];
-            return class_of(g.nodes[x]) < class_of(g.nodes[y]);
-        });
-    }
     std::vector<uint32_t> bundle_of(N, 0xffffffffu);
     std::vector<uint32_t> bundle_start;  // index into order
-    for (size_t k = 0; k < order.size();) {
-        size_t e = k + 1;
-        if (G > 1) {
-            const uint32_t lv = level[order[k]];
-            const int cl = class_of(g.nodes[order[k]]);
-            while (e < order.size() && e - k < G && level[order[e]] == lv && class_of(g.nodes[order[e]]) == cl) ++e;
+    if (G == 1) {
+        for (size_t i = 0; i < N; ++i)
+            if (g.nodes[i].kind != N_CONST) {
+                bundle_of[i] = (uint32_t)bundle_start.size();
+                bundle_start.push_back((uint32_t)order.size());
+                order.push_back((uint32_t)i);
+            }
+    } else {
+        // approximate lane-instruction cost of one bundle of each class (measured on gfx950, relative)
+        static const uint32_t class_cost[C_COUNT] = {8, 9, 3, 270, 4, 8, 14, 60, 4};
+        std::vector<uint64_t> height(N, 0);
+        std::vector<uint32_t> n_users_left;  // unused placeholder to keep vectors grouped
+        std::vector<uint32_t> indeg(N, 0);
+        std::vector<std::vector<uint32_t>> users;  // adjacency (only non-const producers)
+        users.resize(N);
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            const uint32_t ops[3] = {n.a, n.b, n.c};
+            uint32_t seen[3];
+            int ns = 0;
+            for (int q = 0; q < arity_of(n); ++q) {
+                const uint32_t o = ops[q];
+                if (g.nodes[o].kind == N_CONST) continue;
+                bool dup = false;
+                for (int z = 0; z < ns; ++z) dup |= seen[z] == o;
+                if (dup) continue;
+                seen[ns++] = o;
+                users[o].push_back((uint32_t)i);
+                indeg[i]++;
+            }
         }
-        for (size_t q = k; q < e; ++q) bundle_of[order[q]] = (uint32_t)bundle_start.size();
-        bundle_start.push_back((uint32_t)k);
-        k = e;
+        for (size_t i = N; i-- > 0;) {
+            if (g.nodes[i].kind == N_CONST) continue;
+            uint64_t h = 0;
+            for (uint32_t u : users[i]) h = std::max(h, height[u]);
+            height[i] = h + class_cost[class_of(g.nodes[i])];
+        }
+        // ready heaps per class, keyed by (height, -index)
+        typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
+        std::vector<std::vector<Key>> heap(C_COUNT);
+        auto push = [&](uint32_t i) {
+            auto& h = heap[class_of(g.nodes[i])];
+            h.push_back(Key(height[i], ~i));
+            std::push_heap(h.begin(), h.end());
+        };
+        for (size_t i = 0; i < N; ++i)
+            if (g.nodes[i].kind != N_CONST && indeg[i] == 0) push((uint32_t)i);
+        std::vector<uint32_t> picked;
+        size_t remaining = 0;
+        for (size_t i = 0; i < N; ++i) remaining += g.nodes[i].kind != N_CONST;
+        while (remaining) {
+            int best = -1;
+            for (int c = 0; c < (int)C_COUNT; ++c)
+                if (!heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
+            if (best < 0) {
+                err = "internal error: scheduler found no ready node";
+                return false;
+            }
+            // INPUT nodes first whenever any is ready (they have no producers and feed everything)
+            if (!heap[C_INPUT].empty()) best = C_INPUT;
+            picked.clear();
+            auto& h = heap[best];
+            while (!h.empty() && picked.size() < G) {
+                std::pop_heap(h.begin(), h.end());
+                picked.push_back(~h.back().second);
+                h.pop_back();
+            }
+            std::sort(picked.begin(), picked.end());
+            const uint32_t b = (uint32_t)bundle_start.size();
+            bundle_start.push_back((uint32_t)order.size());
+            for (uint32_t i : picked) {
+                bundle_of[i] = b;
+                order.push_back(i);
+            }
+            remaining -= picked.size();
+            for (uint32_t i : picked)  // release users only now: a bundle never reads its own results
+                for (uint32_t u : users[i])
+                    if (--indeg[u] == 0) push(u);
+        }
     }
     const uint32_t NB = (uint32_t)bundle_start.size();
     bundle_start.push_back((uint32_t)order.size());
