@@ -100,8 +100,14 @@ struct gwb_graph {
     ProgramStats stats;
     std::map<uint32_t, std::unique_ptr<DeviceProgram>> progs;
     uint32_t forced_T = 0;
-    void* d_vals = nullptr;
-    size_t vals_bytes = 0;
+    // value workspaces: one per concurrently running chunk (a launch addresses its workspace through a 32-bit
+    // buffer window, so large batches run as several < 4 GiB chunks, overlapped on internal streams)
+    static const int kMaxLanes = 8;
+    void* d_vals[kMaxLanes] = {nullptr};
+    size_t vals_bytes[kMaxLanes] = {0};
+    hipStream_t lane_stream[kMaxLanes] = {nullptr};
+    hipEvent_t lane_done[kMaxLanes] = {nullptr};
+    hipEvent_t fork_ev = nullptr;
     bool timing_pending = false;
     gwb_timing_t timing{};
     unsigned long long* d_prof = nullptr;  // diagnostic per-class stamps (gwb_profile_classes), else null
@@ -117,7 +123,12 @@ struct gwb_graph {
     ~gwb_graph() {
         for (auto& kv : progs)
             if (kv.second->d_blob) (void)hipFree(kv.second->d_blob);
-        if (d_vals) (void)hipFree(d_vals);
+        for (int i = 0; i < kMaxLanes; ++i) {
+            if (d_vals[i]) (void)hipFree(d_vals[i]);
+            if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
+            if (lane_done[i]) (void)hipEventDestroy(lane_done[i]);
+        }
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
         drop_events();
     }
 };
@@ -196,35 +207,65 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     const uint64_t tiles_total = (batch + T - 1) / T;
     const uint64_t chunk_tiles = tiles_total < max_tiles ? tiles_total : max_tiles;
     const size_t need = (size_t)(const_bytes + chunk_tiles * bytes_per_tile);
-    if (need > g->vals_bytes) {
-        if (g->d_vals) HIP_TRY(hipFree(g->d_vals));
-        g->d_vals = nullptr;
-        g->vals_bytes = 0;
-        HIP_TRY(hipMalloc(&g->d_vals, need));
-        g->vals_bytes = need;
+    const size_t chunk_sets = (size_t)chunk_tiles * T;
+    const size_t n_chunks = (batch + chunk_sets - 1) / chunk_sets;
+    int lanes = 1;
+    if (n_chunks > 1) {
+        lanes = 4;
+        if (const char* e = getenv("CWC_STREAMS")) lanes = atoi(e);
+        if (lanes < 1) lanes = 1;
+        if (lanes > gwb_graph::kMaxLanes) lanes = gwb_graph::kMaxLanes;
+        if ((size_t)lanes > n_chunks) lanes = (int)n_chunks;
     }
-    // constants into slot geometry: 16-byte halves, 16*T bytes apart
-    HIP_TRY(hipMemcpy2DAsync(g->d_vals, (size_t)16 * T, dp->dev.consts, 16, 16, (size_t)p.n_const * 2, hipMemcpyDeviceToDevice, stream));
+    for (int l = 0; l < lanes; ++l) {
+        if (need > g->vals_bytes[l]) {
+            if (g->d_vals[l]) HIP_TRY(hipFree(g->d_vals[l]));
+            g->d_vals[l] = nullptr;
+            g->vals_bytes[l] = 0;
+            HIP_TRY(hipMalloc(&g->d_vals[l], need));
+            g->vals_bytes[l] = need;
+        }
+        if (lanes > 1 && !g->lane_stream[l]) {
+            HIP_TRY(hipStreamCreateWithFlags(&g->lane_stream[l], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&g->lane_done[l], hipEventDisableTiming));
+        }
+    }
     g->drop_events();
     g->timing = gwb_timing_t{};
     g->timing.tile_width = T;
     g->timing.n_bundles = p.n_bundles;
     g->timing.n_slots = p.n_slots;
     HIP_TRY(hipMemsetAsync(d_status, 0, batch * sizeof(uint32_t), stream));
-    const size_t chunk_sets = (size_t)chunk_tiles * T;
-    for (size_t s0 = 0; s0 < batch; s0 += chunk_sets) {
+    if (lanes > 1) {  // fork: the internal streams start after everything already queued on the caller's stream
+        if (!g->fork_ev) HIP_TRY(hipEventCreateWithFlags(&g->fork_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g->fork_ev, stream));
+        for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(g->lane_stream[l], g->fork_ev, 0));
+    }
+    size_t ci = 0;
+    for (size_t s0 = 0; s0 < batch; s0 += chunk_sets, ++ci) {
         const uint32_t nb = (uint32_t)((batch - s0) < chunk_sets ? (batch - s0) : chunk_sets);
+        const int l = (int)(ci % (size_t)lanes);
+        hipStream_t st = lanes > 1 ? g->lane_stream[l] : stream;
+        void* ws = g->d_vals[l];
         hipEvent_t e0, e1, e2;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
-        HIP_TRY(hipEventRecord(e0, stream));
-        HIP_TRY(launch_interp(T, dp->dev, g->d_vals, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
-        HIP_TRY(hipEventRecord(e1, stream));
-        HIP_TRY(launch_pack(T, dp->dev, g->d_vals, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
-        HIP_TRY(hipEventRecord(e2, stream));
+        // constants into slot geometry at the head of the workspace: 16-byte halves, 16*T bytes apart
+        HIP_TRY(hipMemcpy2DAsync(ws, (size_t)16 * T, dp->dev.consts, 16, 16, (size_t)p.n_const * 2, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipEventRecord(e0, st));
+        HIP_TRY(launch_interp(T, dp->dev, ws, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, st, g->d_prof));
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(launch_pack(T, dp->dev, ws, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, st));
+        HIP_TRY(hipEventRecord(e2, st));
         g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});
         g->timing.n_launches++;
+    }
+    if (lanes > 1) {  // join: the caller's stream continues after every internal stream is done
+        for (int l = 0; l < lanes; ++l) {
+            HIP_TRY(hipEventRecord(g->lane_done[l], g->lane_stream[l]));
+            HIP_TRY(hipStreamWaitEvent(stream, g->lane_done[l], 0));
+        }
     }
     g->timing_pending = true;
     return "";
