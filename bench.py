@@ -43,6 +43,10 @@ def synth_inputs(graph_kind, n_inputs, batch, seed, first_row=None):
 
 
 def main():
+    # Everything except the final JSON line goes to stderr (RCCL prints a version banner on stdout at init).
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -57,9 +61,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    # under torch.distributed.run (RANK set) the distributed path is taken even with a single rank, so that the
+    # RCCL init / program broadcast / import code is exercised on 1-GPU boxes too
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if distributed:
         dist.init_process_group("nccl", device_id=dev)
 
     import cwc_import
@@ -67,7 +74,7 @@ def main():
     if not os.path.exists(pkg.LIB_PATH):
         if rank == 0:
             pkg.build()
-        if world > 1:
+        if distributed:
             dist.barrier()
     from circom_witnesscalc_amd import dist as cdist
     from tools.graphgen import circuits as C
@@ -82,7 +89,7 @@ def main():
         nodes, wit, _ = builder.finalize()
         stats = graph_stats(nodes, wit)
         data = builder.to_bin()
-    if world > 1:
+    if distributed:
         tile = args.tile_width or pkg.pick_tile_width(B)  # same on every rank
         g = cdist.broadcast_graph(pkg, data, tile, src=0, device=dev)
     else:
@@ -103,7 +110,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     interp_ms, pack_ms = [], []
@@ -114,11 +121,11 @@ def main():
         interp_ms.append(tm["interp_ms"])
         pack_ms.append(tm["pack_ms"])
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -140,7 +147,8 @@ def main():
                        "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth,
                        "op_histogram": stats["hist"], "batch_per_gpu": B, "tile_width": tm["tile_width"],
                        "bundles": tm["n_bundles"], "slots": tm["n_slots"], "sets_with_error_status": bad_sets,
-                       "parallelism": "batch shards x%d, program broadcast over RCCL" % world},
+                       "parallelism": "batch shards x%d, program broadcast over RCCL" % world if distributed
+                       else "single process, 1 GPU"},
             "field_ops_per_sec": value * g.n_op,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -150,8 +158,10 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(data, rows, d_out, min(args.cpu_sample, B))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

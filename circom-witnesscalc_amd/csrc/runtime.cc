@@ -133,9 +133,10 @@ struct gwb_graph {
     }
 };
 
-// Tile width heuristic: the interpreter is latency-bound per wave, and measured on MI355X (authV2-class graph)
-// the time per batch is flat up to ~512 waves in flight and rises beyond; so widen the tile (more input sets per
-// wave, fewer node slots) only once there are at least CWC_TARGET_WAVES (default 512) tiles.
+// Tile width heuristic (measured on MI355X, profiles/r01_sweep_batch_tile.txt): a wave's time is set by its
+// instruction stream, so few, narrow tiles win -- T = 1 up to 512 sets, T = 2 up to 2047, T = 4 beyond (wider tiles
+// coalesce better but leave fewer node slots per wave and need more bundles; they are available through
+// gwb_set_tile_width / CWC_TILE_WIDTH).  CWC_TARGET_WAVES (default 512) moves the thresholds.
 extern "C" uint32_t gwb_pick_tile_width(size_t batch) {
     size_t target = 512;
     if (const char* e = getenv("CWC_TARGET_WAVES")) {
@@ -143,7 +144,7 @@ extern "C" uint32_t gwb_pick_tile_width(size_t batch) {
         if (v > 0) target = (size_t)v;
     }
     uint32_t t = 1;
-    while (t < 64 && batch / (t * 2) >= target) t *= 2;
+    while (t < 4 && batch / (t * 2) >= target) t *= 2;
     return t;
 }
 
