@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcircom_witnesscalc_amd.so")
+LIB_PATH = os.environ.get("CWC_LIB_PATH") or os.path.join(_HERE, "libcircom_witnesscalc_amd.so")
 _lib = None
 
 
@@ -242,13 +242,15 @@ class Graph:
 
     def profile_classes(self, d_inputs, d_witness, d_status):
         """Diagnostic stamped build: {class: (cycles, cycles_fwd_bundles, fwd_bundles, bundles)} over sampled waves."""
-        out = np.zeros(36, dtype=np.uint64)
+        out = np.zeros(40, dtype=np.uint64)
         st = GwStatus()
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),
                                        d_status.data_ptr(), out.ctypes.data, ctypes.byref(st))
         _check(rc, st)
         names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN"]
-        return {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
+        res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
+        res["_probe"] = tuple(int(x) for x in out[36:40])  # (const-line, fresh-slot, far-record latency sums; count)
+        return res
 
     def last_timing(self):
         t = Timing()

@@ -83,10 +83,17 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         for (int c = 0; c < (int)C_COUNT; ++c) pf[c][0] = pf[c][1] = pf[c][2] = pf[c][3] = 0;
     }
     unsigned long long t_prev = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long probe[4] = {0, 0, 0, 0};
 
     // Software pipeline.  While bundle b computes: its own memory operands were fetched during bundle b-1, the
     // memory operands of bundle b+1 and the header + records of bundle b+2 are in flight.  Only forwarded operands
     // (register reads, same lane or ds_bpermute) and the arithmetic sit on the chain between consecutive bundles.
+#if defined(CWC_EXP_SECTIONS)  // timing experiment only: where inside an iteration does the time go
+    unsigned long long sec[4] = {0, 0, 0, 0};
+#define CWC_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define CWC_STAMP(var)
+#endif
     const uint32_t NBND = p.n_bundles;
     if (NBND == 0) return;
     auto clampb = [&](uint32_t b) { return b < NBND ? b : NBND - 1; };
@@ -96,14 +103,21 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
     Fr mb_cur = ld(opnd_off(rec_cur.w, rec_cur.x, CTRL_B_TILE));
     Fr prev = fr_zero();
     for (uint32_t b = 0; b < NBND; ++b) {
+        CWC_STAMP(st0);
         const uint32_t h = h_cur;
         const uint4 rec = rec_cur;
         const uint32_t ctrl = rec.x;
         // prefetch: memory operands of bundle b+1 (INPUT records carry an input index in .z: fetch offset 0 instead),
         // header / records of bundle b+2
         const uint32_t a_n1 = opnd_off(rec_n1.z, rec_n1.x, CTRL_A_TILE) & (((h_n1 & HDR_CLASS_MASK) == C_INPUT) ? 0u : ~0u);
+#if defined(CWC_EXP_NOLOAD)  // timing experiment only (wrong results)
+        Fr ma_n1 = fr_one(), mb_n1 = fr_one();
+        ma_n1.v[0] ^= a_n1;
+        mb_n1.v[0] ^= rec_n1.w;
+#else
         const Fr ma_n1 = ld(a_n1);
         const Fr mb_n1 = ld(opnd_off(rec_n1.w, rec_n1.x, CTRL_B_TILE));
+#endif
         const uint32_t b2 = clampb(b + 2);
         const uint32_t h_n2 = hdr[b2];
         const uint4 rec_n2 = recs[(size_t)b2 * G + j];
@@ -112,38 +126,43 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         const uint32_t amode = (h >> HDR_AMODE_SHIFT) & 3u, bmode = (h >> HDR_BMODE_SHIFT) & 3u;
         const bool active = (ctrl & CTRL_ACTIVE) != 0;
         const uint32_t sub = (ctrl >> CTRL_SUB_SHIFT) & 0xffu;
-        Fr a_op = ma_cur, b_op = mb_cur;
-        if (amode == FWD_SAME_ALL) a_op = prev;
-        else if (amode == FWD_SAME_SOME) a_op = u256_select((ctrl & CTRL_A_FWD) != 0, prev, ma_cur);
-        else if (amode == FWD_PERMUTE) a_op = permute(ma_cur, (ctrl & CTRL_A_FWD) != 0, (ctrl >> CTRL_ASRC_SHIFT) & 63u, prev);
-        if (bmode == FWD_SAME_ALL) b_op = prev;
-        else if (bmode == FWD_SAME_SOME) b_op = u256_select((ctrl & CTRL_B_FWD) != 0, prev, mb_cur);
-        else if (bmode == FWD_PERMUTE) b_op = permute(mb_cur, (ctrl & CTRL_B_FWD) != 0, (ctrl >> CTRL_BSRC_SHIFT) & 63u, prev);
+        // Operand selection without branches on the common path (a taken branch costs a lone wave an instruction
+        // refetch): forwarded lanes take their own previous result by select; only bundles in which some lane must
+        // read ANOTHER lane's result (mode PERMUTE) take the single, wave-uniform ds_bpermute branch.
+        Fr a_op = u256_select((ctrl & CTRL_A_FWD) != 0, prev, ma_cur);
+        Fr b_op = u256_select((ctrl & CTRL_B_FWD) != 0, prev, mb_cur);
+        if (__builtin_expect(amode == FWD_PERMUTE || bmode == FWD_PERMUTE, 0)) {
+            if (amode == FWD_PERMUTE) a_op = permute(ma_cur, (ctrl & CTRL_A_FWD) != 0, (ctrl >> CTRL_ASRC_SHIFT) & 63u, prev);
+            if (bmode == FWD_PERMUTE) b_op = permute(mb_cur, (ctrl & CTRL_B_FWD) != 0, (ctrl >> CTRL_BSRC_SHIFT) & 63u, prev);
+        }
+        CWC_STAMP(st1);
         Fr r;
+        if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
+#if defined(CWC_EXP_NOMUL)  // timing experiment only (wrong results)
+            r = fr_add(a_op, b_op);
+#else
+            r = fr_mul(a_op, b_op);
+#endif
+        } else if (__builtin_expect(cls == C_LIN, 1)) {
+            // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a.  Branch-free: a + (+-b) with -b = r - b
+            // (b = 0 gives a + r, folded by the conditional subtraction of fr_add).
+            Fr nb;
+            u256_sub(nb, fr_p(), b_op);
+            r = fr_add(a_op, u256_select(sub == OP_ADD, b_op, nb));
+        } else
         switch (cls) {
-            case C_MUL: {  // graph.rs:105
-                r = fr_mul(a_op, b_op);
-                break;
-            }
-            case C_LIN: {  // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a
-                const uint32_t lin = (h >> HDR_LIN_SHIFT) & 3u;
-                if (lin == LIN_ALL_ADD) r = fr_add(a_op, b_op);
-                else if (lin == LIN_ALL_SUB) r = fr_sub(a_op, b_op);
-                else {  // a + (+-b): r - b for Sub (b = 0 gives a + r, folded by the final conditional subtraction)
-                    Fr nb;
-                    u256_sub(nb, fr_p(), b_op);
-                    r = fr_add(a_op, u256_select(sub == OP_ADD, b_op, nb));
-                }
-                break;
-            }
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + rec.z) * 2;
                 r = fr_to_mont(fr_from_u4(q[0], q[1]));
                 break;
             }
             case C_DIV: {  // graph.rs:109  b == 0 -> 0 else a / b
+#if defined(CWC_EXP_NODIV)  // timing experiment only (wrong results)
+                r = fr_add(a_op, b_op);
+#else
                 const Fr inv = fr_inv(b_op);  // safegcd divsteps; inv(0) = 0
                 r = u256_select(u256_is_zero(b_op), fr_zero(), fr_mul(a_op, inv));
+#endif
                 break;
             }
             case C_CMPZ: {  // graph.rs:122-129 Eq/Neq, :134-135 Land/Lor
@@ -224,11 +243,16 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
             }
             default: r = fr_zero(); break;
         }
+        CWC_STAMP(st2);
         {   // unconditional store (the host points values without a slot and inactive node slots at the tile's trash
             // slot): a fixed number of stores per bundle lets the waitcnt pass count them instead of draining
             const uint32_t doff = rec.y + lane_base;
+#if !defined(CWC_EXP_NOSTORE)  // timing experiment only (wrong results)
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[0], r.v[1], r.v[2], r.v[3]}, rsrc, (int)doff, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[4], r.v[5], r.v[6], r.v[7]}, rsrc, (int)doff + HI, 0, 0);
+#else
+            asm volatile("" ::"v"(doff), "v"(r.v[0]), "v"(r.v[7]));
+#endif
         }
         prev = r;
         h_cur = h_n1; rec_cur = rec_n1; ma_cur = ma_n1; mb_cur = mb_n1;
@@ -236,6 +260,29 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         // Later bundles read these stores from other lanes of this wave; a wave's vector-memory instructions
         // execute in order, the fence only keeps the compiler from reordering them.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if defined(CWC_EXP_SECTIONS)
+        {
+            CWC_STAMP(st3);
+            asm volatile("" ::"v"(ma_cur.v[0]), "v"(mb_cur.v[7]), "v"(rec_cur.x), "v"(rec_n1.w), "s"(h_cur), "s"(h_n1));
+            sec[0] += st1 - st0; sec[1] += st2 - st1; sec[2] += st3 - st2; sec[3] += 1;
+        }
+#endif
+        if (PROF && (b & 63u) == 63u) {
+            // latency probes (diagnostic only): a constant-table line, and the slot this bundle has just stored
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+            const Fr pc = ld(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(pc.v[0]), "v"(pc.v[7]) : "memory");
+            const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+            const Fr ps = ld(rec.y + lane_base);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(ps.v[0]), "v"(ps.v[7]) : "memory");
+            const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+            const uint4 pr = recs[(size_t)clampb(b + 40) * G + j];
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr.x), "v"(pr.w) : "memory");
+            const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+            probe[0] += q1 - q0; probe[1] += q2 - q1; probe[2] += q3 - q2; probe[3] += 1;
+            t_prev += q3 - q0;  // keep the probes out of the per-class figures
+        }
         if (PROF) {
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();
             const bool fwd = (amode | bmode) != 0;
@@ -255,7 +302,15 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         for (int c = 0; c < (int)C_COUNT; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) atomicAdd(&prof[c * 4 + q], pf[c][q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&prof[36 + q], probe[q]);
     }
+#if defined(CWC_EXP_SECTIONS)
+    if (tile == 0 && lane == 0) {
+        for (int q = 0; q < 4; ++q) { status[2 * q] = (uint32_t)sec[q]; status[2 * q + 1] = (uint32_t)(sec[q] >> 32); }
+        return;
+    }
+#endif
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }
 

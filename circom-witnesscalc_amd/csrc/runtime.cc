@@ -469,12 +469,12 @@ int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void
     std::string err = check_device();
     if (!err.empty()) return fail(status, err);
     unsigned long long* d = nullptr;
-    if (hipMalloc(&d, 36 * 8) != hipSuccess || hipMemset(d, 0, 36 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
+    if (hipMalloc(&d, 40 * 8) != hipSuccess || hipMemset(d, 0, 40 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
     g->d_prof = d;
     err = run_device(g, d_inputs, batch, d_witness, d_set_status, nullptr);
     g->d_prof = nullptr;
     if (err.empty() && hipDeviceSynchronize() != hipSuccess) err = "hipDeviceSynchronize failed";
-    if (err.empty() && hipMemcpy(out36, d, 36 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
+    if (err.empty() && hipMemcpy(out36, d, 40 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
     (void)hipFree(d);
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");

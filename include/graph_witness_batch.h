@@ -73,7 +73,8 @@ int gwb_calc_witness_batch_host(gwb_graph_t *g, const void *inputs, size_t batch
 int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 
 /* Diagnostic build of the interpreter with one in-kernel cycle stamp per bundle: out36[class*4 + {cycles, cycles
- * of bundles with a forwarded operand, such bundles, bundles}], shader cycles summed over the sampled waves. */
+ * of bundles with a forwarded operand, such bundles, bundles}], shader cycles summed over the sampled waves;
+ * out36 must hold 40 words: [36..39] = load-latency probes (constant line, just-stored slot, far record; count). */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out36, gw_status_t *status);
 

@@ -26,6 +26,9 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     t = g.last_timing()
     prof = g.profile_classes(d_in, d_out, d_st)
     nw = max(1, (B + tw - 1) // tw // 64 + (1 if ((B + tw - 1) // tw) % 64 else 0))
+    probe = prof.pop("_probe")
+    if probe[3]:
+        print("   load-latency probes (cycles): constant line %.0f, just-stored slot %.0f, record 40 bundles ahead %.0f" % tuple(x / probe[3] for x in probe[:3]))
     tot = sum(v[0] for v in prof.values())
     print("T=%d B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw, B, t["interp_ms"], nw, tot / nw))
     for k, (cyc, cyc_f, n_f, n) in prof.items():
