@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "gw_calc_witness", "gwb_graph_load", "gwb_graph_free", "gwb_graph_info", "gwb_graph_serialize",
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
-    "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width",
+    "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width", "gwb_inputs_from_json_batch", "gwb_wtns_save_batch",
 ]
 
 
@@ -88,6 +88,8 @@ def lib():
         L.gwb_graph_import.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
         L.gwb_free_status.argtypes = [stp]
         L.gwb_profile_classes.argtypes = [vp, vp, sz, vp, vp, vp, stp]
+        L.gwb_inputs_from_json_batch.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), stp]
+        L.gwb_wtns_save_batch.argtypes = [vp, sz, sz, ctypes.c_char_p, stp]
         L.gwb_pick_tile_width.restype = ctypes.c_uint32
         L.gwb_pick_tile_width.argtypes = [sz]
         _lib = L
@@ -108,6 +110,14 @@ def _check(rc, st):
     msg = _take_status(st)
     if rc != 0:
         raise WitnessCalcError(msg or "call failed")
+
+
+def wtns_save_batch(witness, path_pattern):
+    """One `.wtns` file per input set; witness uint8 [B, W, 32]; path_pattern with one %lu (gwb_wtns_save_batch)."""
+    witness = np.ascontiguousarray(witness, dtype=np.uint8)
+    st = GwStatus()
+    rc = lib().gwb_wtns_save_batch(witness.ctypes.data, witness.shape[1], witness.shape[0], path_pattern.encode(), ctypes.byref(st))
+    _check(rc, st)
 
 
 def pick_tile_width(batch):
@@ -212,6 +222,22 @@ class Graph:
         rc = lib().gwb_inputs_from_json(self._h, inputs_json, row.ctypes.data, ctypes.byref(st))
         _check(rc, st)
         return row
+
+    def inputs_from_json_batch(self, text):
+        """JSON array of input objects or NDJSON -> uint8 [B, n_inputs, 32] (gwb_inputs_from_json_batch)."""
+        if isinstance(text, str):
+            text = text.encode("utf-8")
+        n = ctypes.c_size_t()
+        st = GwStatus()
+        lib().gwb_inputs_from_json_batch(self._h, text, len(text), None, 0, ctypes.byref(n), ctypes.byref(st))
+        msg = _take_status(st)
+        if "rows buffer too small" not in msg and msg:
+            raise WitnessCalcError(msg)
+        rows = np.zeros((n.value, self.n_inputs, 32), dtype=np.uint8)
+        st = GwStatus()
+        rc = lib().gwb_inputs_from_json_batch(self._h, text, len(text), rows.ctypes.data, n.value, ctypes.byref(n), ctypes.byref(st))
+        _check(rc, st)
+        return rows
 
     def calc_witness_batch(self, inputs):
         """Host buffers: inputs uint8 [B, n_inputs, 32] -> (witness uint8 [B, W, 32], status uint32 [B])."""

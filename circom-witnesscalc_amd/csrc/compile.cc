@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_map>
 
 #include "program.hpp"
 
@@ -29,18 +30,72 @@ static int class_of(const Node& n) {
 
 static int arity_of(const Node& n) { return n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0; }
 
-bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err) {
+// Exact strength reduction done before scheduling: Idiv(x, 2^k) == Shr(x, k) and Mod(x, 2^k) == Band(x, 2^k - 1) on the
+// canonical integers the reference divides (src/graph.rs:112-121 vs :637-672, :674-687), for every x < r and k <= 253.
+// The replacement constants are appended behind the last node (constants have no dependencies).
+static void rewrite_pow2_divisions(Graph& g) {
+    std::unordered_map<uint32_t, uint32_t> shift_const, mask_const;  // k -> node index
+    const size_t N = g.nodes.size();
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind != N_DUO || (n.op != OP_IDIV && n.op != OP_MOD)) continue;
+        const Node& d = g.nodes[n.b];
+        if (d.kind != N_CONST) continue;
+        const Fr& v = g.const_values[d.a];
+        int k = -1, bits = 0;
+        for (int w = 0; w < 8; ++w)
+            if (v.v[w]) {
+                bits += __builtin_popcount(v.v[w]);
+                k = 32 * w + __builtin_ctz(v.v[w]);
+            }
+        if (bits != 1 || k > 253) continue;
+        auto& table = n.op == OP_IDIV ? shift_const : mask_const;
+        auto it = table.find((uint32_t)k);
+        if (it == table.end()) {
+            Fr c = fr_zero();
+            if (n.op == OP_IDIV) {
+                c.v[0] = (uint32_t)k;
+            } else {
+                for (int w = 0; w < 8; ++w) c.v[w] = k >= 32 * (w + 1) ? 0xffffffffu : (k > 32 * w ? ((1u << (k - 32 * w)) - 1u) : 0u);
+            }
+            const uint32_t idx = (uint32_t)g.nodes.size();
+            g.nodes.push_back(Node{N_CONST, 0, (uint32_t)g.const_values.size(), 0, 0});
+            g.const_values.push_back(c);
+            it = table.emplace((uint32_t)k, idx).first;
+        }
+        Node& n2 = g.nodes[i];  // (push_back may have moved the vector)
+        n2.op = n2.op == OP_IDIV ? OP_SHR : OP_BAND;
+        n2.b = it->second;
+    }
+}
+
+bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& err) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
     }
+    // validate operand order on the graph as loaded, then work on a rewritten copy
+    for (size_t i = 0; i < g_in.nodes.size(); ++i) {
+        const Node& n = g_in.nodes[i];
+        const int ar = arity_of(n);
+        if ((ar >= 1 && n.a >= i) || (ar >= 2 && n.b >= i) || (ar >= 3 && n.c >= i)) {
+            err = "node " + std::to_string(i) + " references a node that is not before it";
+            return false;
+        }
+        if (n.kind == N_CONST && n.a >= g_in.const_values.size()) {
+            err = "node " + std::to_string(i) + ": bad constant index";
+            return false;
+        }
+    }
+    Graph g = g_in;
+    rewrite_pow2_divisions(g);
     const size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
     out = Program();
     out.T = T;
     out.G = G;
     ProgramStats& st = out.stats;
-    st.n_nodes = N;
+    st.n_nodes = g_in.nodes.size();
     st.n_witness = g.witness_signals.size();
 
     // ---- validate (assert_valid, reference src/graph.rs:343-356; evaluate() itself does not check) ----
@@ -49,20 +104,12 @@ bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err)
     for (size_t i = 0; i < N; ++i) {
         const Node& n = g.nodes[i];
         int ar = arity_of(n);
-        if ((ar >= 1 && n.a >= i) || (ar >= 2 && n.b >= i) || (ar >= 3 && n.c >= i)) {
-            err = "node " + std::to_string(i) + " references a node that is not before it";
-            return false;
-        }
         if (n.kind == N_DUO && n.op == OP_POW) {  // graph.rs:141-142 unimplemented!
             err = "node " + std::to_string(i) + ": operator Pow not implemented for Montgomery";
             return false;
         }
         if (n.kind == N_UNO && n.op != UOP_NEG) {  // graph.rs:195
             err = "node " + std::to_string(i) + ": uno operator Id not implemented for Montgomery";
-            return false;
-        }
-        if (n.kind == N_CONST && n.a >= g.const_values.size()) {
-            err = "node " + std::to_string(i) + ": bad constant index";
             return false;
         }
         if (ar) {
@@ -73,7 +120,7 @@ bool compile_program(const Graph& g, uint32_t T, Program& out, std::string& err)
         }
     }
     for (uint32_t w : g.witness_signals)
-        if (w >= N) {
+        if (w >= g_in.nodes.size()) {
             err = "witness signal references node " + std::to_string(w) + " beyond the graph";
             return false;
         }

@@ -493,14 +493,16 @@ FRD uint32_t u256_bitlen(const Fr& a) {
 }
 
 // q = a / b, rem = a % b on canonical integers (ruint U256 / and %), b != 0.
-// Restoring shift-subtract from bit `top` (exclusive) downwards; callers pass top = bit length of a
-// (or a wave-wide maximum of it, so that control flow stays uniform).
+// Restoring shift-subtract over the low `top` bits of a, the bits above them pre-loaded into the remainder.
+// Callers pass top >= bitlen(a) - bitlen(b) + 1 (clamped at 0; wave-wide maximum so that control flow stays
+// uniform): then a >> top < 2^(bitlen(b)-1) <= b, the loop invariant rem < b holds from the start, and only the
+// quotient's own length is iterated instead of the whole numerator.
 FRD void u256_divrem(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t top) {
-    // (rem : num) is one 512-bit shift register; num starts as a aligned so that bit top-1 is bit 255.
-    // All indices are static (runtime-indexed register arrays would spill to scratch on the GPU).
+    // (rem : num) is one 512-bit shift register.  All indices are static (runtime-indexed register arrays would
+    // spill to scratch on the GPU).
     Fr num = top ? u256_shl(a, 256u - top) : fr_zero();
+    rem = top >= 256u ? fr_zero() : u256_shr(a, top);
     q = fr_zero();
-    rem = fr_zero();
     for (uint32_t i = 0; i < top; ++i) {
         uint32_t carry = num.v[7] >> 31;
 #pragma unroll

@@ -629,6 +629,42 @@ bool deserialize_inputs(const char* json, size_t len, InputList& out, std::strin
     return true;
 }
 
+bool split_inputs_batch(const char* text, size_t len, std::vector<std::pair<size_t, size_t>>& spans, std::string& err) {
+    spans.clear();
+    Json j{text, len, 0, ""};
+    j.ws();
+    if (j.pos < len && text[j.pos] == '[') {  // JSON array of objects
+        ++j.pos;
+        j.ws();
+        if (j.pos < len && text[j.pos] == ']') {
+            ++j.pos;
+        } else {
+            for (;;) {
+                j.ws();
+                const size_t b = j.pos;
+                if (!j.skip_value(1)) { err = "invalid JSON: " + j.err; return false; }
+                spans.emplace_back(b, j.pos);
+                j.ws();
+                if (j.pos < len && text[j.pos] == ',') { ++j.pos; continue; }
+                if (j.pos < len && text[j.pos] == ']') { ++j.pos; break; }
+                err = "invalid JSON: expected ',' or ']' at byte " + std::to_string(j.pos);
+                return false;
+            }
+        }
+        j.ws();
+        if (j.pos != len) { err = "invalid JSON: trailing characters at byte " + std::to_string(j.pos); return false; }
+        return true;
+    }
+    // NDJSON: a sequence of values separated by whitespace / newlines
+    while (j.pos < len) {
+        const size_t b = j.pos;
+        if (!j.skip_value(0)) { err = "invalid JSON: " + j.err; return false; }
+        spans.emplace_back(b, j.pos);
+        j.ws();
+    }
+    return true;
+}
+
 bool populate_inputs(const InputList& inputs, const Graph& g, uint8_t* buf, size_t n_inputs, std::string& err) {
     memset(buf, 0, n_inputs * 32);
     if (n_inputs) buf[0] = 1;  // get_inputs_buffer, lib.rs:177-181

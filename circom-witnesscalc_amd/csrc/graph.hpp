@@ -54,6 +54,9 @@ size_t inputs_buffer_size(const Graph& g);
 typedef std::vector<std::pair<std::string, std::vector<Fr>>> InputList;  // insertion order, unique keys
 // lib.rs:195-247.  Error strings follow the reference's Error Debug output.
 bool deserialize_inputs(const char* json, size_t len, InputList& out, std::string& err);
+// Batched front-end: splits either a top-level JSON array of input objects or NDJSON (one object per
+// line, blank lines ignored) into [begin, end) spans, each of which is then parsed by deserialize_inputs.
+bool split_inputs_batch(const char* text, size_t len, std::vector<std::pair<size_t, size_t>>& spans, std::string& err);
 // lib.rs:177-181 + 154-168: buf = n_inputs x 32-byte canonical LE, buf[0] = 1.
 bool populate_inputs(const InputList& inputs, const Graph& g, uint8_t* buf, size_t n_inputs, std::string& err);
 

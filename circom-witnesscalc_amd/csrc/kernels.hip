@@ -222,7 +222,9 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
                 const bool yz = u256_is_zero(y);
                 Fr ys = y;
                 ys.v[0] |= yz ? 1u : 0u;
-                uint32_t top = u256_bitlen(x);
+                // trip count = length of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 (0 when x < y)
+                const uint32_t lx = u256_bitlen(x), ly = u256_bitlen(ys);
+                uint32_t top = lx >= ly ? lx - ly + 1u : 0u;
 #pragma unroll
                 for (int off = 32; off; off >>= 1) {
                     const uint32_t o = (uint32_t)__shfl_xor((int)top, off);

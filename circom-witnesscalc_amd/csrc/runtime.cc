@@ -411,6 +411,46 @@ int gwb_inputs_from_json(const gwb_graph_t* g, const char* json, void* row, gw_s
     return 0;
 }
 
+int gwb_inputs_from_json_batch(const gwb_graph_t* g, const char* text, size_t text_len, void* rows, size_t max_rows,
+                               size_t* n_rows, gw_status_t* status) {
+    if (!g || !text || !n_rows || (!rows && max_rows)) return fail(status, "null argument");
+    std::vector<std::pair<size_t, size_t>> spans;
+    std::string err;
+    if (!split_inputs_batch(text, text_len, spans, err)) return fail(status, "Failed to calculate witness: " + err);
+    *n_rows = spans.size();
+    if (spans.size() > max_rows) return fail(status, "rows buffer too small: " + std::to_string(spans.size()) + " input sets");
+    Graph meta;
+    meta.inputs = g->inputs;
+    meta.input_index = g->input_index;
+    InputList list;
+    for (size_t i = 0; i < spans.size(); ++i) {
+        if (!deserialize_inputs(text + spans[i].first, spans[i].second - spans[i].first, list, err) ||
+            !populate_inputs(list, meta, (uint8_t*)rows + i * (size_t)g->n_inputs * 32, g->n_inputs, err))
+            return fail(status, "Failed to calculate witness: input set " + std::to_string(i) + ": " + err);
+    }
+    set_status(status, OK, "");
+    return 0;
+}
+
+int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, const char* path_pattern, gw_status_t* status) {
+    // one `.wtns` file per input set; path_pattern must contain one %zu / %lu-style conversion for the set index
+    if ((!witness && batch) || !path_pattern) return fail(status, "null argument");
+    std::vector<uint8_t> hdr(76);
+    wtns_write_header(hdr.data(), n_witness);
+    char path[4096];
+    for (size_t i = 0; i < batch; ++i) {
+        const int n = snprintf(path, sizeof path, path_pattern, (unsigned long)i);
+        if (n <= 0 || (size_t)n >= sizeof path) return fail(status, "bad path pattern");
+        FILE* f = fopen(path, "wb");
+        if (!f) return fail(status, std::string("cannot open ") + path);
+        const bool ok = fwrite(hdr.data(), 1, 76, f) == 76 &&
+                        fwrite((const uint8_t*)witness + i * n_witness * 32, 1, n_witness * 32, f) == n_witness * 32;
+        if (fclose(f) != 0 || !ok) return fail(status, std::string("short write to ") + path);
+    }
+    set_status(status, OK, "");
+    return 0;
+}
+
 int gwb_set_tile_width(gwb_graph_t* g, uint32_t T) {
     if (!g || T > 64 || (T & (T - 1))) return 1;
     g->forced_T = T;

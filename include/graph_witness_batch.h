@@ -54,6 +54,14 @@ int gwb_graph_serialize(const gwb_graph_t *g, void **out, size_t *out_len, gw_st
  * (deserialize_inputs + get_inputs_buffer + populate_inputs, src/lib.rs:195-247, 177-181, 154-168). */
 int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *row, gw_status_t *status);
 
+/* Batched front-end: `text` is a JSON array of input objects or NDJSON (one object per line); fills up to max_rows
+ * rows of n_inputs x 32 bytes, *n_rows = number of input sets found (also set when the buffer is too small). */
+int gwb_inputs_from_json_batch(const gwb_graph_t *g, const char *text, size_t text_len, void *rows, size_t max_rows,
+                               size_t *n_rows, gw_status_t *status);
+/* Write one `.wtns` file per input set (76-byte header + row, src/lib.rs:114-123); path_pattern takes the set index
+ * through one %lu conversion, e.g. "out/witness_%05lu.wtns". */
+int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, const char *path_pattern, gw_status_t *status);
+
 /* 0 = choose from the batch size (default); else a power of two in 1..64 */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
 /* the tile width (input sets per wavefront) the library chooses for a batch of this size */

@@ -258,3 +258,22 @@ def test_replica_from_broadcast_blob(pkg):
     b2, sb = rep.calc_witness_batch(rows)
     assert np.array_equal(a, b2) and np.array_equal(sa, sb)
     assert np.array_equal(rep.inputs_from_json('{"x": "9", "arr": [1,2,3,4]}'), g.inputs_from_json('{"x": "9", "arr": [1,2,3,4]}'))
+
+
+def test_bigint_class_graph(pkg):
+    """BASELINE config 5 class (Idiv/Mod/Lt/TernCond-heavy, synthetic) at reduced size."""
+    rnd = random.Random(21)
+    b = C.build_bigint_class(k=8, rounds=6)
+    rows = [_rand_row(rnd, 18, 0.2) for _ in range(40)]
+    _check(pkg, b.to_bin(), rows, tiles=(1, 4, 64))
+
+
+def test_power_of_two_division_rewrite_on_gpu(pkg):
+    b = Builder()
+    (x,) = b.input("x"); (y,) = b.input("y")
+    for k in (0, 1, 31, 32, 33, 64, 128, 200, 253):
+        b.signal(b.op("Idiv", x, b.const(1 << k)))
+        b.signal(b.op("Mod", x, b.const(1 << k)))
+    b.signal(b.op("Idiv", x, y)); b.signal(b.op("Mod", x, y)); b.signal(b.op("Idiv", y, x)); b.signal(b.op("Mod", y, x))
+    rows = [[1, a, c] for a in EDGE for c in (0, 1, 3, 1 << 64, M - 1, (1 << 100) + 7)]
+    _check(pkg, b.to_bin(), rows, tiles=(1, 16, 64))

@@ -152,7 +152,8 @@ def test_wtns_framing(pkg):
 def test_graph_compiler_emulated(pkg, tile):
     """Level scheduling, bundling, slot reuse and operand encoding for every tile width (host logic only)."""
     rnd = random.Random(tile)
-    cases = [(C.build_gadgets(), 7), (C.build_poseidon(2), 3)] + [(C.build_random_dag(s, n_ops=250, panic_free=(s % 2 == 0)), 7) for s in range(6)]
+    cases = [(C.build_gadgets(), 7), (C.build_poseidon(2), 3), (C.build_bigint_class(k=3, rounds=2), 8)] + \
+            [(C.build_random_dag(s, n_ops=250, panic_free=(s % 2 == 0)), 7) for s in range(6)]
     for b, n_in in cases:
         data = b.to_bin()
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
@@ -189,3 +190,43 @@ def test_cli_usage(pkg):
     exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "calc-witness")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "Usage:" in r.stderr and "<graph.bin> <inputs.json> <witness.wtns>" in r.stderr
+
+
+def test_batched_json_front_end_and_wtns_writer(pkg, tmp_path):
+    """JSON array / NDJSON of input objects -> packed rows; one .wtns per set."""
+    g = pkg.Graph(C.build_gadgets().to_bin())
+    objs = ['{"x": "%d", "y": %d, "arr": ["1", 2, "%d", 4]}' % (7 ** k, k, 10 ** k) for k in range(5)]
+    want = np.stack([g.inputs_from_json(o) for o in objs])
+    assert np.array_equal(g.inputs_from_json_batch("[" + ",\n".join(objs) + "]"), want)
+    assert np.array_equal(g.inputs_from_json_batch("\n".join(objs) + "\n\n"), want)
+    assert g.inputs_from_json_batch("[]").shape == (0, g.n_inputs, 32)
+    for bad in ('[{"x": 1}, {"x": -1}]', '[{"x": 1},]', '{"x": 1} {"x": ', '[{"nope": 1}]'):
+        with pytest.raises(pkg.WitnessCalcError):
+            g.inputs_from_json_batch(bad)
+    rnd = random.Random(3)
+    wit = np.frombuffer(bytes(rnd.getrandbits(8) for _ in range(3 * 4 * 32)), dtype=np.uint8).reshape(3, 4, 32)
+    pkg.wtns_save_batch(wit, str(tmp_path / "w_%03lu.wtns"))
+    for i in range(3):
+        vals = [int.from_bytes(wit[i, k].tobytes(), "little") for k in range(4)]
+        assert (tmp_path / ("w_%03d.wtns" % i)).read_bytes() == model.wtns_from_witness(vals)
+
+
+def test_power_of_two_division_rewrite_is_exact(pkg):
+    """Idiv/Mod by a constant 2^k are compiled as Shr/Band (compile.cc rewrite_pow2_divisions): same values."""
+    from tools.graphgen.builder import Builder
+    b = Builder()
+    (x,) = b.input("x")
+    ks = [0, 1, 31, 32, 33, 64, 128, 200, 253]
+    for k in ks:
+        b.signal(b.op("Idiv", x, b.const(1 << k)))
+        b.signal(b.op("Mod", x, b.const(1 << k)))
+    b.signal(b.op("Idiv", x, b.const(3)))          # not a power of two: stays a division
+    b.signal(b.op("Mod", x, b.const((1 << 70) + 1)))
+    g = pkg.Graph(b.to_bin())
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(b.to_bin())
+    blob = pe.Blob(g.export_blob(4))
+    classes = [pe.CLASS_NAMES[h & 0xF] for h in blob.hdr]
+    assert "BIT" in classes and "IDIVMOD" in classes
+    M = model.M
+    for xv in (0, 1, 5, (1 << 64) - 1, 1 << 200, M - 1, M // 2, (1 << 253) + 12345):
+        assert pe.run(blob, [1, xv])[0] == model.evaluate(nodes, [1, xv], wit)

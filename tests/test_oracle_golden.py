@@ -146,3 +146,16 @@ def test_random_dags_c_oracle_vs_model():
                 assert s in (1, 2)
                 continue
             assert s == 0 and cbind.array_to_ints(o) == want
+
+
+def test_bigint_class_graph_oracles_agree():
+    rnd = random.Random(31)
+    b = C.build_bigint_class(k=4, rounds=3)
+    data = b.to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    g = cbind.Graph(data)
+    rows = [[1] + [rnd.randrange(model.M) if rnd.random() < 0.7 else rnd.randrange(1 << 40) for _ in range(9)] for _ in range(6)]
+    out, st = g.evaluate_batch(cbind.ints_to_array(rows))
+    assert not st.any()
+    for r, o in zip(rows, out):
+        assert model.evaluate(nodes, r, wit) == cbind.array_to_ints(o)

@@ -649,3 +649,57 @@ def build_random_dag(seed, n_ops=400, n_inputs=6, ops=None, panic_free=True):
             b.signal(h)
     b.signal(pool[-1])
     return b
+
+
+def build_bigint_class(k=8, n_bits=64, rounds=4, seed="bigint"):
+    """bigint / long_div-class synthetic graph (BASELINE config 5; the reference front-end cannot compile such
+    circuits at this commit, README.md:21, so this is synthetic by necessity): `rounds` iterations of
+      * schoolbook k x k limb multiplication with witness-hint carries  (Mul, Add, Idiv by 2^n, Mod 2^n),
+      * long division of the 2k-limb product by a single limb          (Mul, Add, Idiv, Mod per limb),
+      * limb-wise comparison and conditional subtraction               (Lt, Sub, TernCond),
+    chained so that every round depends on the previous one.  Values stay below 2^(2n+log k), far below r.
+    Node count ~ rounds * (6 k^2 + 12 k)."""
+    b = Builder()
+    a_in = b.input("a", k)
+    b_in = b.input("b", k)
+    (d_in,) = b.input("d")
+    base = b.const(1 << n_bits)
+    mask = b.const((1 << n_bits) - 1)
+    one = b.const(1)
+    zero = b.const(0)
+    # normalise inputs to n_bits limbs (they may be arbitrary field elements in synthetic batches)
+    x = [b.signal(b.op("Band", v, mask)) for v in a_in]
+    y = [b.signal(b.op("Band", v, mask)) for v in b_in]
+    d = b.signal(b.add(b.op("Band", d_in, mask), one))  # divisor limb in [1, 2^n]
+    for _ in range(rounds):
+        # product columns
+        cols = [None] * (2 * k)
+        for i in range(k):
+            for j in range(k):
+                pr = b.mul(x[i], y[j])
+                cols[i + j] = pr if cols[i + j] is None else b.add(cols[i + j], pr)
+        cols[2 * k - 1] = zero
+        # carry propagation: limb = col % 2^n ; carry = col \ 2^n
+        carry = zero
+        prod = []
+        for c in range(2 * k):
+            t = b.add(cols[c], carry)
+            prod.append(b.signal(b.op("Mod", t, base)))
+            carry = b.signal(b.op("Idiv", t, base))
+        # long division of prod by the single limb d (most significant limb first)
+        rem = zero
+        quo = [None] * (2 * k)
+        for c in range(2 * k - 1, -1, -1):
+            t = b.add(b.mul(rem, base), prod[c])
+            quo[c] = b.signal(b.op("Idiv", t, d))
+            rem = b.signal(b.op("Mod", t, d))
+        # compare-and-select: next x = quo low limbs, next y = limb-wise min(y, quo high) + rem folded in
+        nx, ny = [], []
+        for i in range(k):
+            lt = b.signal(b.op("Lt", quo[i + k], y[i]))
+            sel = b.signal(b.tern(lt, quo[i + k], y[i]))
+            nx.append(b.signal(b.op("Band", b.add(quo[i], rem), mask)))
+            ny.append(b.signal(b.op("Band", b.add(sel, one), mask)))
+        x, y = nx, ny
+        d = b.signal(b.add(b.op("Band", b.add(d, rem), mask), one))
+    return b
