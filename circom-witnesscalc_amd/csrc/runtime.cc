@@ -84,7 +84,7 @@ std::string upload_program(DeviceProgram& dp) {
 uint64_t workspace_budget() {
     const char* e = getenv("CWC_WORKSPACE_GB");
     double gb = e ? atof(e) : 3.9;
-    if (gb < 0.25) gb = 0.25;
+    if (gb < 1e-4) gb = 1e-4;  // tiny budgets are allowed (tests use them to force chunking); one tile is the floor
     return (uint64_t)(gb * (double)(1ull << 30));
 }
 

@@ -232,18 +232,23 @@ def test_authv2_class_full_size_batch_1024(pkg):
 
 
 def test_workspace_chunking_gives_identical_bytes(pkg, monkeypatch):
+    """Batches whose value workspace exceeds the budget run as several launches, overlapped on internal streams
+    (runtime.cc); the witnesses must not depend on the chunking."""
     rnd = random.Random(12)
     data = C.build_poseidon(2).to_bin()
-    rows = [_rand_row(rnd, 3, 0) for _ in range(300)]
+    rows = cbind.ints_to_array([_rand_row(rnd, 3, 0) for _ in range(301)])
     g = pkg.Graph(data)
     g.set_tile_width(4)
-    a, _ = g.calc_witness_batch(cbind.ints_to_array(rows))
-    monkeypatch.setenv("CWC_WORKSPACE_GB", "0.0001")  # clamped to 0.25 GiB minimum -> still one chunk; use tiny graph budget
-    g2 = pkg.Graph(data)
-    g2.set_tile_width(4)
-    b2, _ = g2.calc_witness_batch(cbind.ints_to_array(rows))
-    assert np.array_equal(a, b2)
-    assert g2.last_timing()["n_launches"] >= 1
+    a, sa = g.calc_witness_batch(rows)
+    assert g.last_timing()["n_launches"] == 1
+    for streams in ("1", "3"):
+        monkeypatch.setenv("CWC_WORKSPACE_GB", "0.0005")  # ~0.5 MB: a few tiles per launch
+        monkeypatch.setenv("CWC_STREAMS", streams)
+        g2 = pkg.Graph(data)
+        g2.set_tile_width(4)
+        b2, sb = g2.calc_witness_batch(rows)
+        assert g2.last_timing()["n_launches"] > 4
+        assert np.array_equal(a, b2) and np.array_equal(sa, sb)
 
 
 def test_replica_from_broadcast_blob(pkg):
