@@ -249,30 +249,13 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     out.n_bundles = NB;
 
     // ---- operand routing -------------------------------------------------------------------------------
-    // A value consumed (as a or b) by the bundle right after its producer is *forwarded*: the consumer lane
-    // takes it from the result registers of the previous bundle (its own lane when the host could give the
-    // consumer its producer's node slot, else ds_bpermute) -- no store -> load round trip.  Every other use goes
-    // through the value slot in memory and is prefetched one bundle ahead.  A value that is neither a witness
-    // element nor read from memory is never given a slot (its store goes to the tile's trash slot).
-    auto forwardable = [&](uint32_t producer, uint32_t consumer, int q) {
-        return q < 2 && g.nodes[producer].kind != N_CONST && bundle_of[consumer] == bundle_of[producer] + 1;
-    };
-    std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
-    std::vector<uint8_t> needs_slot(N, 0);
-    for (uint32_t w : g.witness_signals)
-        if (g.nodes[w].kind != N_CONST) needs_slot[w] = 2;  // pinned
-    for (uint32_t i : order) {
-        const Node& n = g.nodes[i];
-        const uint32_t ops[3] = {n.a, n.b, n.c};
-        for (int q = 0; q < arity_of(n); ++q) {
-            const uint32_t o = ops[q];
-            if (g.nodes[o].kind == N_CONST || forwardable(o, i, q)) continue;
-            if (!needs_slot[o]) needs_slot[o] = 1;
-            last_mem_use[o] = std::max(last_mem_use[o], bundle_of[i]);
-        }
-    }
-
-    // ---- node slot (lane group) placement: a consumer prefers the node slot of its forwarded producer ----
+    // PREV: produced by the previous bundle in the consumer's own node slot -> result registers, free.
+    // LDS : produced 1..RING-1 bundles ago (any node slot) -> read from the wave's result ring in LDS.
+    // MEM : everything else (older values, constants, every third operand) -> value slot / constant table in
+    //       global memory, prefetched one bundle ahead.  A value that is neither a witness element nor read
+    //       through MEM is never given a slot (its store goes to the tile's trash slot).
+    // Node slot placement comes first (it decides PREV vs LDS): a consumer prefers the slot of a producer that sits
+    // in the previous bundle.
     std::vector<uint32_t> pos_in_bundle(N, 0);
     {
         std::vector<int32_t> taken(G);
@@ -285,8 +268,9 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 const uint32_t i = order[k];
                 const Node& n = g.nodes[i];
                 int want = -1;
-                if (arity_of(n) >= 1 && forwardable(n.a, i, 0)) want = (int)pos_in_bundle[n.a];
-                else if (arity_of(n) >= 2 && forwardable(n.b, i, 1)) want = (int)pos_in_bundle[n.b];
+                auto prev_bundle = [&](uint32_t o) { return g.nodes[o].kind != N_CONST && bundle_of[o] + 1 == b; };
+                if (arity_of(n) >= 1 && prev_bundle(n.a)) want = (int)pos_in_bundle[n.a];
+                else if (arity_of(n) >= 2 && prev_bundle(n.b)) want = (int)pos_in_bundle[n.b];
                 if (want >= 0 && want < (int)(k1 - k0) && taken[want] < 0) {
                     taken[want] = (int32_t)i;
                     pos_in_bundle[i] = (uint32_t)want;
@@ -301,6 +285,28 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 pos_in_bundle[i] = f;
             }
             for (uint32_t q = 0; q < k1 - k0; ++q) order[k0 + q] = (uint32_t)taken[q];  // order now follows positions
+        }
+    }
+    auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
+        if (q >= 2 || g.nodes[producer].kind == N_CONST) return SRC_MEM;
+        const uint32_t d = bundle_of[consumer] - bundle_of[producer];
+        if (d == 1 && pos_in_bundle[producer] == pos_in_bundle[consumer]) return SRC_PREV;
+        if (d >= 1 && d <= RING_BUNDLES - 1) return SRC_LDS;
+        return SRC_MEM;
+    };
+    std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
+    std::vector<uint8_t> needs_slot(N, 0);
+    for (uint32_t w : g.witness_signals)
+        if (g.nodes[w].kind != N_CONST) needs_slot[w] = 2;  // pinned
+    for (uint32_t i : order) {
+        const Node& n = g.nodes[i];
+        // Neg is encoded as 0 - a: its operand travels in the b position
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) {
+            const uint32_t o = ops[q];
+            if (g.nodes[o].kind == N_CONST || route(o, i, q) != SRC_MEM) continue;
+            if (!needs_slot[o]) needs_slot[o] = 1;
+            last_mem_use[o] = std::max(last_mem_use[o], bundle_of[i]);
         }
     }
 
@@ -330,7 +336,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
         st.class_bundles[cl]++;
         st.class_nodes[cl] += cnt;
         dying.clear();
-        uint32_t fwd_cnt[2] = {0, 0}, fwd_same[2] = {0, 0}, n_add = 0, n_sub = 0;
+        bool any_prev[2] = {false, false}, any_lds[2] = {false, false};
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k];
             const Node& n = g.nodes[i];
@@ -349,12 +355,14 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
             // dst offset is patched below once n_slots (the trash slot index) is known: store slot id for now
             r[1] = slot;
             auto enc_operand = [&](uint32_t producer, int q, uint32_t& off) {
-                if (forwardable(producer, i, q)) {
-                    const uint32_t src = pos_in_bundle[producer];
-                    ctrl |= (q == 0 ? CTRL_A_FWD : CTRL_B_FWD) | (src << (q == 0 ? CTRL_ASRC_SHIFT : CTRL_BSRC_SHIFT));
-                    off = (uint32_t)(const_base + (uint64_t)zero_const * slot_bytes);  // harmless prefetch target
-                    fwd_cnt[q]++;
-                    if (src == k - k0) fwd_same[q]++;
+                const uint32_t src = route(producer, i, q);
+                ctrl |= src << (q == 0 ? CTRL_ASRC_SHIFT : CTRL_BSRC_SHIFT);
+                if (src == SRC_PREV) {
+                    off = 0;  // (the prefetch of this lane then reads a harmless constant-table address)
+                    any_prev[q] = true;
+                } else if (src == SRC_LDS) {
+                    off = (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
+                    any_lds[q] = true;
                 } else {
                     uint32_t rel;
                     off = mem_off(producer, rel);
@@ -376,14 +384,11 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                     ctrl |= (uint32_t)OP_SUB << CTRL_SUB_SHIFT;
                     r[2] = zero_off;
                     enc_operand(n.a, 1, r[3]);
-                    n_sub++;
                     break;
                 case N_DUO:
                     ctrl |= (uint32_t)n.op << CTRL_SUB_SHIFT;
                     enc_operand(n.a, 0, r[2]);
                     enc_operand(n.b, 1, r[3]);
-                    if (n.op == OP_ADD) n_add++;
-                    if (n.op == OP_SUB) n_sub++;
                     break;
                 case N_TRES: {
                     ctrl |= (uint32_t)SUB_TERN << CTRL_SUB_SHIFT;
@@ -402,16 +407,8 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 if (needs_slot[o] == 1 && last_mem_use[o] == b) dying.push_back(o);
             }
         }
-        // Neg was encoded with its operand in the b position; its forwarding bookkeeping went to q = 1 already.
-        auto mode_of = [&](int q) -> uint32_t {
-            if (fwd_cnt[q] == 0) return FWD_NONE;
-            if (fwd_same[q] != fwd_cnt[q]) return FWD_PERMUTE;
-            return fwd_cnt[q] == cnt ? FWD_SAME_ALL : FWD_SAME_SOME;
-        };
-        uint32_t lin = LIN_MIXED;
-        if (cl == C_LIN) lin = (n_add == cnt) ? LIN_ALL_ADD : (n_sub == cnt) ? LIN_ALL_SUB : LIN_MIXED;
-        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | (mode_of(0) << HDR_AMODE_SHIFT) | (mode_of(1) << HDR_BMODE_SHIFT) |
-                     (lin << HDR_LIN_SHIFT);
+        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | (any_prev[0] ? HDR_A_PREV : 0u) | (any_lds[0] ? HDR_A_LDS : 0u) |
+                     (any_prev[1] ? HDR_B_PREV : 0u) | (any_lds[1] ? HDR_B_LDS : 0u);
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);

@@ -39,7 +39,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int T, bool PROF>
 __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
-                                                    const uint32_t* __restrict__ crefs, InterpDims p, void* ws,
+                                                    const uint32_t* __restrict__ crefs, InterpDims p, WsTable wst,
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
@@ -53,10 +53,17 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
     // One buffer descriptor over the launch's workspace [constants | tiles]; all operand / destination addresses are
     // 32-bit byte offsets into it (host-computed, plus this lane's base for tile-relative ones).
     const uint64_t tile_bytes = ws_tile_bytes(p.n_slots, T);
-    const uint64_t ws_bytes = ws_const_bytes(p.n_const, T) + (uint64_t)gridDim.x * tile_bytes;
+    const uint32_t chunk = tile / wst.tiles_per_chunk, tile_in_chunk = tile % wst.tiles_per_chunk;
+    void* ws = wst.base[chunk];
+    const uint64_t ws_bytes = ws_const_bytes(p.n_const, T) + (uint64_t)wst.tiles_per_chunk * tile_bytes;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(uint32_t)ws_bytes, 0x00020000);
-    const uint32_t lane_base = (uint32_t)(ws_const_bytes(p.n_const, T) + (uint64_t)tile * tile_bytes) + 16u * (uint32_t)t;
+    const uint32_t lane_base = (uint32_t)(ws_const_bytes(p.n_const, T) + (uint64_t)tile_in_chunk * tile_bytes) + 16u * (uint32_t)t;
     constexpr int HI = 16 * T;  // byte distance between the two 16-byte halves of a value
+    // Result ring (one wave per block): slot (bundle mod RING) holds the 64 lane results of that bundle as
+    // [half][lane][16 B], so the wave's ds_write_b128 / ds_read_b128 are conflict-free and any lane can read any
+    // other lane's recent result (host-computed byte offset + 16*t).
+    __shared__ uint4 ring[RING_BUNDLES * 128];
+    const uint32_t lds_t = 16u * (uint32_t)t;
 
     auto ld = [&](uint32_t off) -> Fr {
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
@@ -66,15 +73,10 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
     auto opnd_off = [&](uint32_t off, uint32_t ctrl, uint32_t tile_bit) -> uint32_t {
         return off + ((ctrl & tile_bit) ? lane_base : 0u);
     };
-    auto permute = [&](const Fr& mem, bool fwd, uint32_t src_slot, const Fr& prev) -> Fr {
-        const int src = (int)((src_slot * (uint32_t)T + (uint32_t)t) << 2);  // byte address of the source lane
-        Fr o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)prev.v[i]);
-            o.v[i] = fwd ? v : mem.v[i];
-        }
-        return o;
+    auto ld_ring = [&](uint32_t off) -> Fr {  // off: byte offset of the low half inside the ring
+        const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ring) + off);
+        const uint4 lo = q[0], hi = q[RING_HALF_BYTES / 16];
+        return fr_from_u4(lo, hi);
     };
     uint32_t err_bits = 0;
     unsigned long long pf[C_COUNT][4];
@@ -123,19 +125,16 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         const uint4 rec_n2 = recs[(size_t)b2 * G + j];
 
         const uint32_t cls = h & HDR_CLASS_MASK;
-        const uint32_t amode = (h >> HDR_AMODE_SHIFT) & 3u, bmode = (h >> HDR_BMODE_SHIFT) & 3u;
         const bool active = (ctrl & CTRL_ACTIVE) != 0;
         const uint32_t sub = (ctrl >> CTRL_SUB_SHIFT) & 0xffu;
-        // Operand selection without branches on the common path (a taken branch costs a lone wave an instruction
-        // refetch): forwarded lanes take their own previous result by select; only bundles in which some lane must
-        // read ANOTHER lane's result (mode PERMUTE) take the single, wave-uniform ds_bpermute branch.
-        Fr a_op = u256_select((ctrl & CTRL_A_FWD) != 0, prev, ma_cur);
-        Fr b_op = u256_select((ctrl & CTRL_B_FWD) != 0, prev, mb_cur);
-        if (__builtin_expect(amode == FWD_PERMUTE || bmode == FWD_PERMUTE, 0)) {
-            if (amode == FWD_PERMUTE) a_op = permute(ma_cur, (ctrl & CTRL_A_FWD) != 0, (ctrl >> CTRL_ASRC_SHIFT) & 63u, prev);
-            if (bmode == FWD_PERMUTE) b_op = permute(mb_cur, (ctrl & CTRL_B_FWD) != 0, (ctrl >> CTRL_BSRC_SHIFT) & 63u, prev);
-        }
-        CWC_STAMP(st1);
+        // Operand selection: memory operands were prefetched during the previous bundle; PREV lanes take their own
+        // last result; LDS lanes read the result ring (wave-uniform header bits skip what no lane needs).
+        const uint32_t asrc = (ctrl >> CTRL_ASRC_SHIFT) & 3u, bsrc = (ctrl >> CTRL_BSRC_SHIFT) & 3u;
+        Fr a_op = ma_cur, b_op = mb_cur;
+        if (h & HDR_A_LDS) a_op = u256_select(asrc == SRC_LDS, ld_ring(rec.z + lds_t), a_op);
+        if (h & HDR_B_LDS) b_op = u256_select(bsrc == SRC_LDS, ld_ring(rec.w + lds_t), b_op);
+        if (h & HDR_A_PREV) a_op = u256_select(asrc == SRC_PREV, prev, a_op);
+        if (h & HDR_B_PREV) b_op = u256_select(bsrc == SRC_PREV, prev, b_op);
         Fr r;
         if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
 #if defined(CWC_EXP_NOMUL)  // timing experiment only (wrong results)
@@ -256,6 +255,11 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
             asm volatile("" ::"v"(doff), "v"(r.v[0]), "v"(r.v[7]));
 #endif
         }
+        {   // publish the results of this bundle in the ring (read by later bundles of this wave, in order)
+            uint4* q = ring + (b & (RING_BUNDLES - 1u)) * 128u + (uint32_t)lane;
+            q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+            q[64] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+        }
         prev = r;
         h_cur = h_n1; rec_cur = rec_n1; ma_cur = ma_n1; mb_cur = mb_n1;
         h_n1 = h_n2; rec_n1 = rec_n2;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         }
         if (PROF) {
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();
-            const bool fwd = (amode | bmode) != 0;
+            const bool fwd = (h & (HDR_A_PREV | HDR_A_LDS | HDR_B_PREV | HDR_B_LDS)) != 0;
 #pragma unroll
             for (int c = 0; c < (int)C_COUNT; ++c)
                 if (cls == (uint32_t)c) {
@@ -316,21 +320,21 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, const uint4* __restrict__ ws, uint4* __restrict__ out,
-                                                   uint32_t batch, uint32_t T) {
+__global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= p.n_witness) return;
     const uint32_t ref = p.witness_refs[w];
-    const uint4* consts = ws;  // head of the workspace
-    const uint4* vals = ws + ws_const_bytes(p.n_const, T) / 16;
     for (uint32_t set = blockIdx.y; set < batch; set += gridDim.y) {
+        const uint32_t tile = set / T, t = set % T;
+        const uint4* ws = reinterpret_cast<const uint4*>(wst.base[tile / wst.tiles_per_chunk]);
+        const uint4* consts = ws;  // head of the chunk's workspace
+        const uint4* vals = ws + ws_const_bytes(p.n_const, T) / 16;
         Fr v;
         if (ref & REF_CONST) {
             const uint4* q = consts + (size_t)(ref & ~REF_CONST) * (2 * T);
             v = fr_from_u4(q[0], q[T]);
         } else {
-            const uint32_t tile = set / T, t = set % T;
-            const uint4* q = vals + ((size_t)tile * (p.n_slots + 1) + ref) * (2 * T) + t;
+            const uint4* q = vals + ((size_t)(tile % wst.tiles_per_chunk) * (p.n_slots + 1) + ref) * (2 * T) + t;
             v = fr_from_u4(q[0], q[T]);
         }
         const Fr c = fr_from_mont(v);
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, const uint4* __
 }
 
 // ---- launchers (called from runtime.cc) -----------------------------------------------------------
-hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void* inputs, uint32_t* status,
+hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
                          uint32_t batch, hipStream_t stream, unsigned long long* prof) {
     const uint32_t tiles = (batch + T - 1) / T;
     dim3 grid(tiles), block(64);
@@ -350,8 +354,8 @@ hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
 #define CWC_LAUNCH(TT)                                                                                              \
     case TT:                                                                                                        \
-        if (prof) interp_kernel<TT, true><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, vals, in, status, prof);    \
-        else interp_kernel<TT, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, vals, in, status, nullptr);   \
+        if (prof) interp_kernel<TT, true><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);    \
+        else interp_kernel<TT, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, nullptr);   \
         break;
     switch (T) {
         CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32) CWC_LAUNCH(64)
@@ -361,10 +365,10 @@ hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void
     return hipGetLastError();
 }
 
-hipError_t launch_pack(uint32_t T, const ProgramDev& p, const void* vals, void* out, uint32_t batch, hipStream_t stream) {
+hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream) {
     if (p.n_witness == 0 || batch == 0) return hipSuccess;
     dim3 grid((p.n_witness + 255) / 256, batch < 32768u ? batch : 32768u), block(256);
-    pack_kernel<<<grid, block, 0, stream>>>(p, (const uint4*)vals, (uint4*)out, batch, T);
+    pack_kernel<<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
     return hipGetLastError();
 }
 

@@ -26,25 +26,31 @@ enum BundleClass : uint32_t {
     C_COUNT = 9
 };
 
-// Program format v2 -- laid out so that the interpreter spends (almost) no instructions on decoding.
+// Program format v3 -- laid out so that the interpreter spends (almost) no instructions on decoding.
 //
 // hdr[bundle] (wave-uniform, fetched with scalar loads):
-//   bits 0-3 class | bits 4-10 node count | bits 11-12 A mode | bits 13-14 B mode | bits 15-16 LIN mode
-// operand modes:   0 memory only   1 some lanes forward through ds_bpermute   2 forwarded lanes read their OWN
-//                  previous result (select)   3 every lane reads its own previous result (no instruction)
-// LIN mode:        0 mixed Add/Sub   1 all Add   2 all Sub          (Neg is compiled as 0 - a)
+//   bits 0-3 class | bits 4-10 node count | bit 11 some a operand is PREV | bit 12 some a operand is LDS |
+//   bit 13 some b operand is PREV | bit 14 some b operand is LDS
+// operand sources (per lane, in ctrl):
+//   MEM   constant table or value slot in the workspace (global memory, prefetched one bundle ahead)
+//   PREV  the lane's own result of the previous bundle (register, no instruction)
+//   LDS   the result ring: every bundle writes its 64 lane results into ring slot (bundle mod RING) of the wave's
+//         LDS; any value produced at most RING-1 bundles ago is read back from there, whatever lane produced it
 //
-// rec[bundle][node slot] = {ctrl, dst, a, b}: dst/a/b are BYTE offsets for raw_buffer_load/store through one
-// descriptor over the workspace [constant table | tile 0 | tile 1 | ...]; offsets flagged tile-relative get the
-// lane's base (tile base + 16*t) added.  ctrl: bit0 a tile-relative, bit1 b tile-relative, bit2 a forwarded,
-// bit3 b forwarded, bits 4-9 / 10-15 source node slot of a / b, bits 16-23 DuoOp code (or SUB_*), bit 24 active.
+// rec[bundle][node slot] = {ctrl, dst, a, b}: dst is a BYTE offset (tile-relative) for the store; a/b are byte offsets
+// for raw_buffer_load through one descriptor over the workspace [constant table | tile 0 | tile 1 | ...] (MEM; offsets
+// flagged tile-relative get the lane's base added) or byte offsets into the wave's LDS ring (LDS; the lane adds
+// 16*t).  ctrl: bit0 a tile-relative, bit1 b tile-relative, bits 2-3 a source, bits 4-5 b source, bits 16-23 DuoOp
+// code (or SUB_*), bit 24 active.
 static const uint32_t HDR_CLASS_MASK = 0xfu;
-static const int HDR_COUNT_SHIFT = 4, HDR_AMODE_SHIFT = 11, HDR_BMODE_SHIFT = 13, HDR_LIN_SHIFT = 15;
-enum FwdMode : uint32_t { FWD_NONE = 0, FWD_PERMUTE = 1, FWD_SAME_SOME = 2, FWD_SAME_ALL = 3 };
-enum LinMode : uint32_t { LIN_MIXED = 0, LIN_ALL_ADD = 1, LIN_ALL_SUB = 2 };
-static const uint32_t CTRL_A_TILE = 1u << 0, CTRL_B_TILE = 1u << 1, CTRL_A_FWD = 1u << 2, CTRL_B_FWD = 1u << 3,
-                      CTRL_ACTIVE = 1u << 24;
-static const int CTRL_ASRC_SHIFT = 4, CTRL_BSRC_SHIFT = 10, CTRL_SUB_SHIFT = 16;
+static const int HDR_COUNT_SHIFT = 4;
+static const uint32_t HDR_A_PREV = 1u << 11, HDR_A_LDS = 1u << 12, HDR_B_PREV = 1u << 13, HDR_B_LDS = 1u << 14;
+enum OperandSource : uint32_t { SRC_MEM = 0, SRC_PREV = 1, SRC_LDS = 2 };
+static const uint32_t CTRL_A_TILE = 1u << 0, CTRL_B_TILE = 1u << 1, CTRL_ACTIVE = 1u << 24;
+static const int CTRL_ASRC_SHIFT = 2, CTRL_BSRC_SHIFT = 4, CTRL_SUB_SHIFT = 16;
+// result ring in LDS: RING bundles x [half][64 lanes][16 B] = RING * 2 KiB per wave
+static const uint32_t RING_BUNDLES = 8;
+static const uint32_t RING_SLOT_BYTES = 2048, RING_HALF_BYTES = 1024;
 // third operand (TernCond) byte offset: bit 31 = tile-relative (always a memory reference)
 static const uint32_t CREF_TILE = 0x80000000u;
 enum SubOp : uint32_t { SUB_TERN = 33, SUB_INPUT = 34 };
@@ -66,6 +72,15 @@ struct ProgramDev {
     const uint32_t* consts;        // [n_const*8] Montgomery form; copied to the head of the workspace per launch
     const uint32_t* witness_refs;  // [n_witness]
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
+};
+
+// A launch covers up to WS_MAX_CHUNKS workspaces of < 4 GiB each (the 32-bit buffer window is per descriptor, not per
+// launch): tile i lives in chunk i / tiles_per_chunk, every chunk starts with its own copy of the constant table.
+static const uint32_t WS_MAX_CHUNKS = 32;
+struct WsTable {
+    void* base[WS_MAX_CHUNKS];
+    uint32_t tiles_per_chunk;
+    uint32_t n_chunks;
 };
 
 // workspace geometry shared by host and kernels: [constants, padded to 256 B][tiles]

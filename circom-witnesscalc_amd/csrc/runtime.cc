@@ -18,9 +18,9 @@
 #include "program.hpp"
 
 namespace cwc {
-hipError_t launch_interp(uint32_t T, const ProgramDev& p, void* vals, const void* inputs, uint32_t* status,
+hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
                          uint32_t batch, hipStream_t stream, unsigned long long* prof);
-hipError_t launch_pack(uint32_t T, const ProgramDev& p, const void* vals, void* out, uint32_t batch, hipStream_t stream);
+hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream);
 }  // namespace cwc
 
 using namespace cwc;
@@ -100,14 +100,11 @@ struct gwb_graph {
     ProgramStats stats;
     std::map<uint32_t, std::unique_ptr<DeviceProgram>> progs;
     uint32_t forced_T = 0;
-    // value workspaces: one per concurrently running chunk (a launch addresses its workspace through a 32-bit
-    // buffer window, so large batches run as several < 4 GiB chunks, overlapped on internal streams)
-    static const int kMaxLanes = 8;
+    // value workspaces ("chunks"): a wave addresses its chunk through a 32-bit buffer window, so a large batch is
+    // spread over several < 4 GiB chunks, all covered by ONE launch (the kernel picks the chunk per tile)
+    static const int kMaxLanes = (int)WS_MAX_CHUNKS;
     void* d_vals[kMaxLanes] = {nullptr};
     size_t vals_bytes[kMaxLanes] = {0};
-    hipStream_t lane_stream[kMaxLanes] = {nullptr};
-    hipEvent_t lane_done[kMaxLanes] = {nullptr};
-    hipEvent_t fork_ev = nullptr;
     bool timing_pending = false;
     gwb_timing_t timing{};
     unsigned long long* d_prof = nullptr;  // diagnostic per-class stamps (gwb_profile_classes), else null
@@ -123,28 +120,26 @@ struct gwb_graph {
     ~gwb_graph() {
         for (auto& kv : progs)
             if (kv.second->d_blob) (void)hipFree(kv.second->d_blob);
-        for (int i = 0; i < kMaxLanes; ++i) {
+        for (int i = 0; i < kMaxLanes; ++i)
             if (d_vals[i]) (void)hipFree(d_vals[i]);
-            if (lane_stream[i]) (void)hipStreamDestroy(lane_stream[i]);
-            if (lane_done[i]) (void)hipEventDestroy(lane_done[i]);
-        }
-        if (fork_ev) (void)hipEventDestroy(fork_ev);
         drop_events();
     }
 };
 
-// Tile width heuristic (measured on MI355X, profiles/r01_sweep_batch_tile.txt): a wave's time is set by its
-// instruction stream, so few, narrow tiles win -- T = 1 up to 512 sets, T = 2 up to 2047, T = 4 beyond (wider tiles
-// coalesce better but leave fewer node slots per wave and need more bundles; they are available through
-// gwb_set_tile_width / CWC_TILE_WIDTH).  CWC_TARGET_WAVES (default 512) moves the thresholds.
+// Tile width heuristic (measured on MI355X, profiles/r01_sweep_batch_tile.txt).  The kernel needs 178 VGPRs, so a
+// SIMD holds two waves and the chip 2048; a wave's time is set by its instruction stream (bundles), and wider tiles
+// mean better lane use but more bundles.  Best measured: T = 1 up to 512 sets, T = 2 up to 4095, then the widest
+// tile that still leaves about 2048 waves in flight (8192 sets -> 4, 16384 -> 8, 32768 -> 16, ...).
+// CWC_TARGET_WAVES (default 2048) moves the large-batch rule; gwb_set_tile_width / CWC_TILE_WIDTH override it.
 extern "C" uint32_t gwb_pick_tile_width(size_t batch) {
-    size_t target = 512;
+    size_t target = 2048;
     if (const char* e = getenv("CWC_TARGET_WAVES")) {
         long v = atol(e);
         if (v > 0) target = (size_t)v;
     }
-    uint32_t t = 1;
-    while (t < 4 && batch / (t * 2) >= target) t *= 2;
+    if (batch <= 512) return 1;
+    uint32_t t = 2;
+    while (t < 64 && batch / (t * 2) >= target) t *= 2;
     return t;
 }
 
@@ -210,25 +205,20 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     const size_t need = (size_t)(const_bytes + chunk_tiles * bytes_per_tile);
     const size_t chunk_sets = (size_t)chunk_tiles * T;
     const size_t n_chunks = (batch + chunk_sets - 1) / chunk_sets;
-    int lanes = 1;
-    if (n_chunks > 1) {
-        lanes = 4;
-        if (const char* e = getenv("CWC_STREAMS")) lanes = atoi(e);
-        if (lanes < 1) lanes = 1;
-        if (lanes > gwb_graph::kMaxLanes) lanes = gwb_graph::kMaxLanes;
-        if ((size_t)lanes > n_chunks) lanes = (int)n_chunks;
+    // chunks per launch: all of them when they fit the table and the memory cap (CWC_STREAMS keeps its old meaning of
+    // "chunks in flight"); otherwise several launches, one after the other
+    size_t per_launch = n_chunks < WS_MAX_CHUNKS ? n_chunks : WS_MAX_CHUNKS;
+    if (const char* e = getenv("CWC_STREAMS")) {
+        const long v = atol(e);
+        if (v >= 1 && (size_t)v < per_launch) per_launch = (size_t)v;
     }
-    for (int l = 0; l < lanes; ++l) {
+    for (size_t l = 0; l < per_launch; ++l) {
         if (need > g->vals_bytes[l]) {
             if (g->d_vals[l]) HIP_TRY(hipFree(g->d_vals[l]));
             g->d_vals[l] = nullptr;
             g->vals_bytes[l] = 0;
             HIP_TRY(hipMalloc(&g->d_vals[l], need));
             g->vals_bytes[l] = need;
-        }
-        if (lanes > 1 && !g->lane_stream[l]) {
-            HIP_TRY(hipStreamCreateWithFlags(&g->lane_stream[l], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&g->lane_done[l], hipEventDisableTiming));
         }
     }
     g->drop_events();
@@ -237,36 +227,29 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     g->timing.n_bundles = p.n_bundles;
     g->timing.n_slots = p.n_slots;
     HIP_TRY(hipMemsetAsync(d_status, 0, batch * sizeof(uint32_t), stream));
-    if (lanes > 1) {  // fork: the internal streams start after everything already queued on the caller's stream
-        if (!g->fork_ev) HIP_TRY(hipEventCreateWithFlags(&g->fork_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(g->fork_ev, stream));
-        for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(g->lane_stream[l], g->fork_ev, 0));
-    }
-    size_t ci = 0;
-    for (size_t s0 = 0; s0 < batch; s0 += chunk_sets, ++ci) {
-        const uint32_t nb = (uint32_t)((batch - s0) < chunk_sets ? (batch - s0) : chunk_sets);
-        const int l = (int)(ci % (size_t)lanes);
-        hipStream_t st = lanes > 1 ? g->lane_stream[l] : stream;
-        void* ws = g->d_vals[l];
+    const size_t launch_sets = per_launch * chunk_sets;
+    for (size_t s0 = 0; s0 < batch; s0 += launch_sets) {
+        const uint32_t nb = (uint32_t)((batch - s0) < launch_sets ? (batch - s0) : launch_sets);
+        WsTable wst;
+        memset(&wst, 0, sizeof wst);
+        wst.tiles_per_chunk = (uint32_t)chunk_tiles;
+        wst.n_chunks = (uint32_t)((nb + chunk_sets - 1) / chunk_sets);
+        for (uint32_t l = 0; l < wst.n_chunks; ++l) {
+            wst.base[l] = g->d_vals[l];
+            // constants into slot geometry at the head of each chunk: 16-byte halves, 16*T bytes apart
+            HIP_TRY(hipMemcpy2DAsync(g->d_vals[l], (size_t)16 * T, dp->dev.consts, 16, 16, (size_t)p.n_const * 2, hipMemcpyDeviceToDevice, stream));
+        }
         hipEvent_t e0, e1, e2;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
-        // constants into slot geometry at the head of the workspace: 16-byte halves, 16*T bytes apart
-        HIP_TRY(hipMemcpy2DAsync(ws, (size_t)16 * T, dp->dev.consts, 16, 16, (size_t)p.n_const * 2, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipEventRecord(e0, st));
-        HIP_TRY(launch_interp(T, dp->dev, ws, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, st, g->d_prof));
-        HIP_TRY(hipEventRecord(e1, st));
-        HIP_TRY(launch_pack(T, dp->dev, ws, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, st));
-        HIP_TRY(hipEventRecord(e2, st));
+        HIP_TRY(hipEventRecord(e0, stream));
+        HIP_TRY(launch_interp(T, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
+        HIP_TRY(hipEventRecord(e1, stream));
+        HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
+        HIP_TRY(hipEventRecord(e2, stream));
         g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});
         g->timing.n_launches++;
-    }
-    if (lanes > 1) {  // join: the caller's stream continues after every internal stream is done
-        for (int l = 0; l < lanes; ++l) {
-            HIP_TRY(hipEventRecord(g->lane_done[l], g->lane_stream[l]));
-            HIP_TRY(hipStreamWaitEvent(stream, g->lane_done[l], 0));
-        }
     }
     g->timing_pending = true;
     return "";

@@ -9,9 +9,10 @@ from oracle import model
 
 REF_CONST = 0x80000000
 CREF_TILE = 0x80000000
-CTRL_A_TILE, CTRL_B_TILE, CTRL_A_FWD, CTRL_B_FWD, CTRL_ACTIVE = 1, 2, 4, 8, 1 << 24
-FWD_NONE, FWD_PERMUTE, FWD_SAME_SOME, FWD_SAME_ALL = 0, 1, 2, 3
-LIN_MIXED, LIN_ALL_ADD, LIN_ALL_SUB = 0, 1, 2
+CTRL_A_TILE, CTRL_B_TILE, CTRL_ACTIVE = 1, 2, 1 << 24
+SRC_MEM, SRC_PREV, SRC_LDS = 0, 1, 2
+HDR_A_PREV, HDR_A_LDS, HDR_B_PREV, HDR_B_LDS = 1 << 11, 1 << 12, 1 << 13, 1 << 14
+RING_BUNDLES, RING_SLOT_BYTES = 8, 2048
 SUB_TERN, SUB_INPUT = 33, 34
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
@@ -46,15 +47,16 @@ class Blob:
 
 
 def run(blob: Blob, inputs_row):
-    """Evaluate one input set (list of ints) through the format-v2 program; returns (witness ints, status bits).
-    Raises on any read of a slot that was never written (use-before-def = scheduling bug) and checks the
-    wave-uniform header fields against the per-record control bits."""
+    """Evaluate one input set (list of ints) through the format-v3 program; returns (witness ints, status bits).
+    Raises on any read of a slot / ring entry that was never written or already overwritten (scheduling bug) and
+    checks the wave-uniform header bits against the per-record control bits."""
     T, G = blob.T, blob.G
     slot_bytes = 32 * T
     trash = blob.n_slots * slot_bytes
     slots = {}
     status = 0
-    prev = []  # register results of the previous bundle, by node slot
+    prev = []   # register results of the previous bundle, by node slot
+    ring = {}   # (ring slot, node slot) -> (bundle that wrote it, value)
 
     def mem(off, tile_rel):
         if not tile_rel:
@@ -66,29 +68,33 @@ def run(blob: Blob, inputs_row):
     for b in range(blob.n_bundles):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
-        amode, bmode, lin = (h >> 11) & 3, (h >> 13) & 3, (h >> 15) & 3
         assert 1 <= cnt <= G
         name = CLASS_NAMES[cls]
         results = []
-        fwd = [[], []]  # per operand: list of (lane, src) for forwarded lanes
-        subs = []
+        seen = {HDR_A_PREV: False, HDR_A_LDS: False, HDR_B_PREV: False, HDR_B_LDS: False}
         for j in range(cnt):
             ctrl, dst, a, bb = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
             assert ctrl & CTRL_ACTIVE
             sub = (ctrl >> 16) & 0xFF
-            subs.append(sub)
             if name == "INPUT":
                 assert sub == SUB_INPUT
                 v = inputs_row[a] % model.M
             else:
                 ops = []
-                for q, (off, tbit, fbit, sh) in enumerate(((a, CTRL_A_TILE, CTRL_A_FWD, 4), (bb, CTRL_B_TILE, CTRL_B_FWD, 10))):
-                    if ctrl & fbit:
-                        src = (ctrl >> sh) & 63
-                        fwd[q].append((j, src))
-                        assert blob.consts[off // slot_bytes] == 0  # harmless prefetch target
-                        ops.append(prev[src])  # IndexError = forwarded from a node slot the previous bundle left empty
+                for q, (off, tbit, sh, hp, hl) in enumerate(((a, CTRL_A_TILE, 2, HDR_A_PREV, HDR_A_LDS), (bb, CTRL_B_TILE, 4, HDR_B_PREV, HDR_B_LDS))):
+                    src = (ctrl >> sh) & 3
+                    if src == SRC_PREV:
+                        seen[hp] = True
+                        ops.append(prev[j])  # IndexError = the previous bundle had no node in this slot
+                    elif src == SRC_LDS:
+                        seen[hl] = True
+                        rs, rem = divmod(off, RING_SLOT_BYTES)
+                        assert rs < RING_BUNDLES and rem % (16 * T) == 0 and rem // (16 * T) < G
+                        wb, val = ring[(rs, rem // (16 * T))]
+                        assert 1 <= b - wb <= RING_BUNDLES - 1, "ring entry too old or from the future"
+                        ops.append(val)
                     else:
+                        assert src == SRC_MEM
                         ops.append(mem(off, bool(ctrl & tbit)))
                 if name == "TERN":
                     assert sub == SUB_TERN
@@ -107,20 +113,9 @@ def run(blob: Blob, inputs_row):
                         status |= 1 if op == "Shl" else 2
                         v = 0
             results.append((dst, v))
-        # header modes must describe the records
-        if name != "INPUT":
-            for q, mode in enumerate((amode, bmode)):
-                f = fwd[q]
-                if not f:
-                    want = FWD_NONE
-                elif any(j != src for j, src in f):
-                    want = FWD_PERMUTE
-                else:
-                    want = FWD_SAME_ALL if len(f) == cnt else FWD_SAME_SOME
-                assert mode == want, (b, q, mode, want)
-        if name == "LIN":
-            want = LIN_ALL_ADD if all(x == 2 for x in subs) else LIN_ALL_SUB if all(x == 3 for x in subs) else LIN_MIXED
-            assert lin == want
+        if name != "INPUT":  # header bits must describe the records
+            for bit, s_ in seen.items():
+                assert bool(h & bit) == s_, (b, bit)
         for j in range(cnt, G):  # padding: record 0 without ACTIVE, stored to the trash slot
             r0 = blob.recs[b * G * 4:b * G * 4 + 4]
             rj = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
@@ -132,6 +127,10 @@ def run(blob: Blob, inputs_row):
             if d != trash:
                 slots[d // slot_bytes] = v
         prev = [v for _, v in results]
+        for j, (_, v) in enumerate(results):
+            ring[(b % RING_BUNDLES, j)] = (b, v)
+        for j in range(cnt, G):
+            ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the entry with garbage
 
     def wit(r):
         return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else slots[r]

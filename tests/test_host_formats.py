@@ -225,7 +225,7 @@ def test_power_of_two_division_rewrite_is_exact(pkg):
     g = pkg.Graph(b.to_bin())
     nodes, wit, _ = model.deserialize_witnesscalc_graph(b.to_bin())
     blob = pe.Blob(g.export_blob(4))
-    classes = [pe.CLASS_NAMES[h & 0xF] for h in blob.hdr]
+    classes = [pe.CLASS_NAMES[h & 0xF] for h in blob.hdr]  # noqa
     assert "BIT" in classes and "IDIVMOD" in classes
     M = model.M
     for xv in (0, 1, 5, (1 << 64) - 1, 1 << 200, M - 1, M // 2, (1 << 253) + 12345):

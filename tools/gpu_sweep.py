@@ -37,6 +37,9 @@ def run(kind, builder, cases):
 
 which = os.environ.get("SWEEP", "authv2,sha256").split(",")
 if "authv2" in which:
-    run("authv2", C.build_authv2_class(), [(1024, (1, 2, 4)), (4096, (2, 4, 8)), (8192, (4, 8, 16)), (16384, (8, 16, 32))])
+    cases = [(1024, (1, 2, 4)), (4096, (2, 4, 8)), (8192, (4, 8, 16)), (16384, (8, 16, 32))]
+    if os.environ.get("SWEEP_BIG"):
+        cases = [(8192, (4, 8)), (16384, (4, 8, 16)), (32768, (8, 16, 32))]
+    run("authv2", C.build_authv2_class(), cases)
 if "sha256" in which:
     run("sha256", C.build_sha256(512), [(1024, (1, 2, 4)), (4096, (2, 4, 8, 16)), (16384, (8, 16, 32))])
