@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--graph", choices=["authv2", "sha256"], default="authv2")
     ap.add_argument("--tile-width", type=int, default=0, help="0 = library heuristic")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="input sets timed on one host core (0 = skip)")
+    ap.add_argument("--extra-batch", type=int, default=8192,
+                    help="also report (outside `value`) the throughput at this per-GPU batch, N=1 only; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,12 +160,37 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(data, rows, d_out, min(args.cpu_sample, B))
+        if world == 1 and args.extra_batch > B:
+            out["large_batch"] = large_batch_point(pkg, g, args.graph, args.extra_batch, dev)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def large_batch_point(pkg, g, graph_kind, batch, dev):
+    """Informational only (never part of `value`): the same kernel at the per-GPU batch of BASELINE config 4
+    (65536 sets over 8 GPUs = 8192 per GPU), device-resident, library-chosen tile width."""
+    rows = synth_inputs(graph_kind, g.n_inputs, batch, 0xC1C00004)
+    d_in = torch.from_numpy(rows).to(dev)
+    d_out = torch.empty((batch, g.n_witness, 32), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(batch, dtype=torch.int32, device=dev)
+    g.set_tile_width(0)
+    g.calc_witness_batch_device(d_in, d_out, d_st)
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.calc_witness_batch_device(d_in, d_out, d_st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tm = g.last_timing()
+    achieved = g.algorithmic_bytes_per_set * batch / (tm["interp_ms"] * 1e-3) / 1e9
+    return {"batch_per_gpu": batch, "value": batch / dt, "unit": "witnesses/s", "ms_per_step": dt * 1e3,
+            "tile_width": tm["tile_width"], "launches": tm["n_launches"],
+            "roofline_frac": achieved / HBM_PEAK_GBS, "sets_with_error_status": int((d_st != 0).sum().item())}
 
 
 def committed_traffic(graph_kind, batch, tile_width):

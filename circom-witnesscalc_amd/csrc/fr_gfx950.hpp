@@ -168,6 +168,9 @@ FRD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 FRD Fr fr_to_mont(const Fr& x) { return fr_mul(x, fr_r2()); }
 // Montgomery -> canonical (into_bigint): Montgomery reduction of x alone
 FRD Fr fr_from_mont(const Fr& x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CWC_PORTABLE_FR_MUL)
+#include "fr_from_mont_gfx950.inc"
+#else
     const uint32_t p[8] = {CWC_P0, CWC_P1, CWC_P2, CWC_P3, CWC_P4, CWC_P5, CWC_P6, CWC_P7};
     uint32_t t[8];
 #pragma unroll
@@ -190,6 +193,7 @@ FRD Fr fr_from_mont(const Fr& x) {
     for (int i = 0; i < 8; ++i) r.v[i] = t[i];
     uint32_t br = u256_sub(s, r, fr_p());  // x < r  =>  result < r already; kept for x in [r, 2^256)
     return u256_select(br != 0, r, s);
+#endif
 }
 
 // a^-1 (Montgomery in, Montgomery out) by Fermat: a^(r-2).  a != 0 expected (0 -> 0).

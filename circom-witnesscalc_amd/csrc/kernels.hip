@@ -320,27 +320,28 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }
 
+// Block = 64 witness indices x min(T, 4) sets of ONE tile: the waves of a block read the same 128-byte lines of the
+// tile's slots ([slot][half][T][16 B]) at the same time, so each line comes from HBM once instead of once per set.
 __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t w = blockIdx.x * 64u + threadIdx.x;
     if (w >= p.n_witness) return;
     const uint32_t ref = p.witness_refs[w];
-    for (uint32_t set = blockIdx.y; set < batch; set += gridDim.y) {
-        const uint32_t tile = set / T, t = set % T;
+    const uint32_t n_tiles = (batch + T - 1) / T;
+    for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
         const uint4* ws = reinterpret_cast<const uint4*>(wst.base[tile / wst.tiles_per_chunk]);
-        const uint4* consts = ws;  // head of the chunk's workspace
-        const uint4* vals = ws + ws_const_bytes(p.n_const, T) / 16;
-        Fr v;
-        if (ref & REF_CONST) {
-            const uint4* q = consts + (size_t)(ref & ~REF_CONST) * (2 * T);
-            v = fr_from_u4(q[0], q[T]);
-        } else {
-            const uint4* q = vals + ((size_t)(tile % wst.tiles_per_chunk) * (p.n_slots + 1) + ref) * (2 * T) + t;
-            v = fr_from_u4(q[0], q[T]);
+        const uint4* q0 = (ref & REF_CONST)
+                              ? ws + (size_t)(ref & ~REF_CONST) * (2 * T)  // constants: head of the chunk's workspace
+                              : ws + ws_const_bytes(p.n_const, T) / 16 +
+                                    ((size_t)(tile % wst.tiles_per_chunk) * (p.n_slots + 1) + ref) * (2 * T);
+        for (uint32_t t = threadIdx.y; t < T; t += blockDim.y) {
+            const uint32_t set = tile * T + t;
+            if (set >= batch) break;
+            const uint4* q = (ref & REF_CONST) ? q0 : q0 + t;
+            const Fr c = fr_from_mont(fr_from_u4(q[0], q[T]));
+            uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
+            o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+            o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
         }
-        const Fr c = fr_from_mont(v);
-        uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
-        o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
-        o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
     }
 }
 
@@ -367,7 +368,8 @@ hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, co
 
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream) {
     if (p.n_witness == 0 || batch == 0) return hipSuccess;
-    dim3 grid((p.n_witness + 255) / 256, batch < 32768u ? batch : 32768u), block(256);
+    const uint32_t n_tiles = (batch + T - 1) / T;
+    dim3 grid((p.n_witness + 63) / 64, n_tiles < 32768u ? n_tiles : 32768u), block(64, T < 4 ? T : 4);
     pack_kernel<<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
     return hipGetLastError();
 }
