@@ -267,15 +267,16 @@ class Graph:
         _check(rc, st)
 
     def profile_classes(self, d_inputs, d_witness, d_status):
-        """Diagnostic stamped build: {class: (cycles, cycles_fwd_bundles, fwd_bundles, bundles)} over sampled waves."""
-        out = np.zeros(40, dtype=np.uint64)
+        """Diagnostic stamped build: {class: (cycles, 0, 0, bundles)} over sampled waves, plus "_sections":
+        {"MUL" / "LIN": (top + staged-operand wait, LDS reads, staging issue, arithmetic, stores + ring, bundles)}."""
+        out = np.zeros(64, dtype=np.uint64)
         st = GwStatus()
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),
                                        d_status.data_ptr(), out.ctypes.data, ctypes.byref(st))
         _check(rc, st)
         names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN"]
         res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
-        res["_probe"] = tuple(int(x) for x in out[36:40])  # (const-line, fresh-slot, far-record latency sums; count)
+        res["_sections"] = {"MUL": tuple(int(x) for x in out[40:46]), "LIN": tuple(int(x) for x in out[48:54])}
         return res
 
     def last_timing(self):

@@ -249,50 +249,21 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     out.n_bundles = NB;
 
     // ---- operand routing -------------------------------------------------------------------------------
-    // PREV: produced by the previous bundle in the consumer's own node slot -> result registers, free.
-    // LDS : produced 1..RING-1 bundles ago (any node slot) -> read from the wave's result ring in LDS.
-    // MEM : everything else (older values, constants, every third operand) -> value slot / constant table in
-    //       global memory, prefetched one bundle ahead.  A value that is neither a witness element nor read
-    //       through MEM is never given a slot (its store goes to the tile's trash slot).
-    // Node slot placement comes first (it decides PREV vs LDS): a consumer prefers the slot of a producer that sits
-    // in the previous bundle.
+    // RING: produced at most RING_BUNDLES bundles ago (any node slot) -> read from the wave's result ring in LDS.
+    // MEM : everything else (older values, constants, every third operand) -> its slot in the tile, staged into LDS
+    //       OPND_AHEAD bundles ahead.  The staging load of bundle b is issued while bundle b - OPND_AHEAD runs, i.e.
+    //       before that bundle stores: a MEM operand must be at least OPND_AHEAD + 1 bundles old, which the ring
+    //       depth guarantees.  A value that is neither a witness element nor read through MEM is never given a
+    //       slot (its store goes to the tile's trash slot).
+    static_assert(RING_BUNDLES >= OPND_AHEAD, "values younger than the staging distance must come from the ring");
     std::vector<uint32_t> pos_in_bundle(N, 0);
-    {
-        std::vector<int32_t> taken(G);
-        std::vector<uint32_t> rest;
-        for (uint32_t b = 0; b < NB; ++b) {
-            const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1];
-            std::fill(taken.begin(), taken.end(), -1);
-            rest.clear();
-            for (uint32_t k = k0; k < k1; ++k) {
-                const uint32_t i = order[k];
-                const Node& n = g.nodes[i];
-                int want = -1;
-                auto prev_bundle = [&](uint32_t o) { return g.nodes[o].kind != N_CONST && bundle_of[o] + 1 == b; };
-                if (arity_of(n) >= 1 && prev_bundle(n.a)) want = (int)pos_in_bundle[n.a];
-                else if (arity_of(n) >= 2 && prev_bundle(n.b)) want = (int)pos_in_bundle[n.b];
-                if (want >= 0 && want < (int)(k1 - k0) && taken[want] < 0) {
-                    taken[want] = (int32_t)i;
-                    pos_in_bundle[i] = (uint32_t)want;
-                } else {
-                    rest.push_back(i);
-                }
-            }
-            uint32_t f = 0;
-            for (uint32_t i : rest) {
-                while (taken[f] >= 0) ++f;
-                taken[f] = (int32_t)i;
-                pos_in_bundle[i] = f;
-            }
-            for (uint32_t q = 0; q < k1 - k0; ++q) order[k0 + q] = (uint32_t)taken[q];  // order now follows positions
-        }
-    }
+    for (uint32_t b = 0; b < NB; ++b)
+        for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k]] = k - bundle_start[b];
+    enum { SRC_MEM = 0, SRC_RING = 1 };
     auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
         if (q >= 2 || g.nodes[producer].kind == N_CONST) return SRC_MEM;
         const uint32_t d = bundle_of[consumer] - bundle_of[producer];
-        if (d == 1 && pos_in_bundle[producer] == pos_in_bundle[consumer]) return SRC_PREV;
-        if (d >= 1 && d <= RING_BUNDLES - 1) return SRC_LDS;
-        return SRC_MEM;
+        return (d >= 1 && d <= RING_BUNDLES) ? SRC_RING : SRC_MEM;
     };
     std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
     std::vector<uint8_t> needs_slot(N, 0);
@@ -311,35 +282,44 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     }
 
     // ---- slot allocation (LIFO free list: a just-freed slot is still hot in cache) + encoding ----
+    // Slot numbering inside a tile: constants first (index = constant index), then value slots, then the trash slot.
     const uint64_t slot_bytes = 32ull * T;
-    const uint64_t const_base = 0;  // constants sit at the head of the workspace
+    const uint32_t NC = out.n_const;
     out.hdr.resize(NB);
     out.recs.assign((size_t)NB * G * 4, 0);
     out.crefs.assign((size_t)NB * G, 0);
     std::vector<uint32_t> free_slots;
     std::vector<uint32_t> dying;  // nodes whose slot is released after the current bundle
     uint32_t n_slots = 0;
-    // first pass: assign slots bundle by bundle (needed before encoding because offsets depend on slots only)
-    struct Enc { uint32_t ctrl, dst, a, b, c; };
     const uint32_t zero_const = (uint32_t)st.n_const;  // index of the trailing dummy (value 0)
-    auto mem_off = [&](uint32_t producer, uint32_t& tile_rel) -> uint32_t {
-        if (g.nodes[producer].kind == N_CONST) {
-            tile_rel = 0;
-            return (uint32_t)(const_base + (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes);
-        }
-        tile_rel = 1;
-        return (uint32_t)((uint64_t)ref[producer] * slot_bytes);
+    const uint32_t zero_off = (uint32_t)((uint64_t)zero_const * slot_bytes);
+    auto mem_off = [&](uint32_t producer) -> uint64_t {
+        if (g.nodes[producer].kind == N_CONST) return (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes;
+        return ((uint64_t)NC + ref[producer]) * slot_bytes;
     };
+    auto sub_of = [&](uint8_t op) -> uint32_t {
+        switch (op) {
+            case OP_ADD: return SUB_ADD;   case OP_SUB: return SUB_SUB;
+            case OP_EQ: return SUB_EQ;     case OP_NEQ: return SUB_NEQ;   case OP_LAND: return SUB_LAND; case OP_LOR: return SUB_LOR;
+            case OP_LT: return SUB_LT;     case OP_GT: return SUB_GT;     case OP_LEQ: return SUB_LEQ;   case OP_GEQ: return SUB_GEQ;
+            case OP_SHL: return SUB_SHL;   case OP_SHR: return SUB_SHR;   case OP_BOR: return SUB_BOR;   case OP_BAND: return SUB_BAND;
+            case OP_BXOR: return SUB_BXOR; case OP_IDIV: return SUB_IDIV; case OP_MOD: return SUB_MOD;
+            default: return 0;  // Mul, Div: the class says it all
+        }
+    };
+    // first pass: slots bundle by bundle; r = {a_off, b_off, slot id (patched below) , a_lds | b_lds << 16}, ctrl kept aside
+    std::vector<uint8_t> ctrl_of((size_t)NB * G, 0);
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
         const int cl = class_of(g.nodes[order[k0]]);
         st.class_bundles[cl]++;
         st.class_nodes[cl] += cnt;
         dying.clear();
-        bool any_prev[2] = {false, false}, any_lds[2] = {false, false};
+        const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k];
             const Node& n = g.nodes[i];
+            const uint32_t js = k - k0;  // node slot
             uint32_t slot = 0xffffffffu;
             if (needs_slot[i]) {
                 if (!free_slots.empty()) {
@@ -349,88 +329,79 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                     slot = n_slots++;
                 }
             }
-            ref[i] = slot;  // 0xffffffff: no slot (every use forwarded)
-            uint32_t* r = &out.recs[((size_t)b * G + (k - k0)) * 4];
-            uint32_t ctrl = CTRL_ACTIVE;
-            // dst offset is patched below once n_slots (the trash slot index) is known: store slot id for now
-            r[1] = slot;
-            auto enc_operand = [&](uint32_t producer, int q, uint32_t& off) {
-                const uint32_t src = route(producer, i, q);
-                ctrl |= src << (q == 0 ? CTRL_ASRC_SHIFT : CTRL_BSRC_SHIFT);
-                if (src == SRC_PREV) {
-                    off = 0;  // (the prefetch of this lane then reads a harmless constant-table address)
-                    any_prev[q] = true;
-                } else if (src == SRC_LDS) {
-                    off = (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
-                    any_lds[q] = true;
+            ref[i] = slot;  // 0xffffffff: no slot (every use comes from the ring)
+            uint32_t* r = &out.recs[((size_t)b * G + js) * 4];
+            r[2] = slot;
+            // default: both operands unused -> staging loads of the zero constant, LDS reads of the own stage cells
+            uint32_t off[2] = {zero_off, zero_off};
+            uint32_t lds[2] = {stage + js * T * 16u, stage + 2u * LDS_HALF_BYTES + js * T * 16u};
+            auto enc_operand = [&](uint32_t producer, int q) {
+                if (route(producer, i, q) == SRC_RING) {
+                    lds[q] = LDS_RING_OFF + (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
                 } else {
-                    uint32_t rel;
-                    off = mem_off(producer, rel);
-                    if (rel) ctrl |= (q == 0 ? CTRL_A_TILE : CTRL_B_TILE);
+                    const uint64_t o = mem_off(producer);
+                    off[q] = (uint32_t)o;
                 }
             };
-            const uint32_t zero_off = (uint32_t)(const_base + (uint64_t)zero_const * slot_bytes);
+            uint32_t ctrl = CTRL_ACTIVE;
             switch (n.kind) {
                 case N_INPUT:
                     if (n.a >= n_in_buf) {
                         err = "Input index out of range";
                         return false;
                     }
-                    ctrl |= (uint32_t)SUB_INPUT << CTRL_SUB_SHIFT;
-                    r[2] = n.a;  // input index (the kernel prefetches nothing for INPUT bundles)
-                    r[3] = 0;
+                    out.crefs[(size_t)b * G + js] = n.a;  // input index
                     break;
-                case N_UNO:  // Neg(a) = 0 - a  (graph.rs:188-194: 0 -> 0, else r - a)
-                    ctrl |= (uint32_t)OP_SUB << CTRL_SUB_SHIFT;
-                    r[2] = zero_off;
-                    enc_operand(n.a, 1, r[3]);
+                case N_UNO:  // Neg(a) = 0 - a  (graph.rs:188-194: 0 -> 0, else r - a); a travels in the b position
+                    ctrl |= SUB_SUB;
+                    enc_operand(n.a, 1);
                     break;
                 case N_DUO:
-                    ctrl |= (uint32_t)n.op << CTRL_SUB_SHIFT;
-                    enc_operand(n.a, 0, r[2]);
-                    enc_operand(n.b, 1, r[3]);
+                    ctrl |= sub_of(n.op);
+                    enc_operand(n.a, 0);
+                    enc_operand(n.b, 1);
                     break;
-                case N_TRES: {
-                    ctrl |= (uint32_t)SUB_TERN << CTRL_SUB_SHIFT;
-                    enc_operand(n.a, 0, r[2]);
-                    enc_operand(n.b, 1, r[3]);
-                    uint32_t rel;
-                    uint32_t off = mem_off(n.c, rel);  // third operand always through memory
-                    out.crefs[(size_t)b * G + (k - k0)] = off | (rel ? CREF_TILE : 0u);
+                case N_TRES:
+                    enc_operand(n.a, 0);
+                    enc_operand(n.b, 1);
+                    out.crefs[(size_t)b * G + js] = (uint32_t)mem_off(n.c);  // third operand always through memory
                     break;
-                }
             }
-            r[0] = ctrl;
+            r[0] = off[0];
+            r[1] = off[1];
+            r[3] = lds[0] | (lds[1] << 16);
+            ctrl_of[(size_t)b * G + js] = (uint8_t)ctrl;
             const uint32_t ops[3] = {n.a, n.b, n.c};
             for (int q = 0; q < arity_of(n); ++q) {
                 uint32_t o = ops[q];
                 if (needs_slot[o] == 1 && last_mem_use[o] == b) dying.push_back(o);
             }
         }
-        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | (any_prev[0] ? HDR_A_PREV : 0u) | (any_lds[0] ? HDR_A_LDS : 0u) |
-                     (any_prev[1] ? HDR_B_PREV : 0u) | (any_lds[1] ? HDR_B_LDS : 0u);
+        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT);
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);
     }
     n_slots = std::max(n_slots, 1u);
-    if (ws_const_bytes(out.n_const, T) + ws_tile_bytes(n_slots, T) > 0xffffffffull) {
+    if (ws_tile_bytes(NC, n_slots, T) > 0xffffffffull) {
         err = "graph too large: one tile of the value workspace exceeds the 4 GiB buffer range";
         return false;
     }
-    // second pass: destination byte offsets (trash slot = n_slots) and inactive padding records
+    // second pass: destination byte offsets (trash slot = n_slots) + ctrl, and inactive padding records
+    const uint32_t trash_off = (uint32_t)(((uint64_t)NC + n_slots) * slot_bytes);
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t cnt = bundle_start[b + 1] - bundle_start[b];
+        const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         for (uint32_t q = 0; q < cnt; ++q) {
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
-            const uint32_t slot = r[1] == 0xffffffffu ? n_slots : r[1];
-            r[1] = (uint32_t)((uint64_t)slot * slot_bytes);
+            const uint32_t d = r[2] == 0xffffffffu ? trash_off : (uint32_t)(((uint64_t)NC + r[2]) * slot_bytes);
+            r[2] = d | ctrl_of[(size_t)b * G + q];
         }
-        for (uint32_t q = cnt; q < G; ++q) {  // inactive node slots: record 0 without the ACTIVE bit, store -> trash
+        for (uint32_t q = cnt; q < G; ++q) {  // inactive node slots: harmless operands, store -> trash, not ACTIVE
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
-            memcpy(r, &out.recs[(size_t)b * G * 4], 16);
-            r[0] &= ~CTRL_ACTIVE;
-            r[1] = (uint32_t)((uint64_t)n_slots * slot_bytes);
+            r[0] = r[1] = zero_off;
+            r[2] = trash_off | (ctrl_of[(size_t)b * G] & CTRL_SUB_MASK);
+            r[3] = (stage + q * T * 16u) | ((stage + 2u * LDS_HALF_BYTES + q * T * 16u) << 16);
             out.crefs[(size_t)b * G + q] = out.crefs[(size_t)b * G];
         }
     }
@@ -453,7 +424,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 1;
+    h.version = 4;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.stats = p.stats;
@@ -467,7 +438,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 1 || h.T == 0 || h.T > 64 || h.G != 64 / h.T) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 4 || h.T == 0 || h.T > 64 || h.G != 64 / h.T) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

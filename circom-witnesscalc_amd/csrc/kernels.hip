@@ -6,11 +6,14 @@
 //   pack_kernel       -- output gather: out[i] = into_bigint(values[outputs[i]]) as 32-byte LE rows
 //                        (src/graph.rs:385-388, src/lib.rs:170-173), i.e. the `.wtns` section-2 body.
 //
+//   fill_consts_kernel -- writes each tile's copy of the constant table (once per workspace).
+//
 // One wavefront = one tile of T input sets x G = 64/T node slots.  The bundle class is wave-uniform
 // (scalar branch); per-lane sub-ops inside a class are resolved with selects.  Values live in HBM as
-// [tile][slot][half][T][16 B]: every global_load/store_dwordx4 of a lane group touches T*16 contiguous
-// bytes (1 KiB per wave-instruction at T = 64).  No MFMA: this is 256-bit modular integer arithmetic
-// on v_mad_u64_u32.
+// [tile][slot][half][T][16 B]: every 16-byte access of a lane group touches T*16 contiguous bytes (1 KiB per
+// wave-instruction at T = 64).  Operands reach the arithmetic through LDS only: memory operands by direct-to-LDS
+// buffer loads two bundles ahead, recent results through a ring (program_dev.h, format v4).  No MFMA: this is
+// 256-bit modular integer arithmetic on v_mad_u64_u32.
 #include <hip/hip_runtime.h>
 
 #include "fr_gfx950.hpp"
@@ -26,16 +29,29 @@ __device__ __forceinline__ Fr fr_from_u4(const uint4& lo, const uint4& hi) {
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // PROF = true is a diagnostic build (gwb_profile_classes): one s_memtime per bundle, summed per bundle class by
-// lane 0 of every 64th tile: [cycles, cycles of bundles with a forwarded operand, such bundles, bundles].
-// No stamp executes in the product kernel.
+// lane 0 of every 64th tile (prof[class*4 + {0: cycles, 3: bundles}]), and for MUL and LIN bundles five sections of
+// the iteration (prof[40 + 8*{MUL, LIN} + section]).  No stamp executes in the product kernel.
 //
 // The program arrays are separate `const __restrict__` kernel arguments (not a by-value struct) so that hipcc can
-// prove them read-only: the wave-uniform header stream then becomes scalar loads (s_load) instead of vector loads
-// + v_readfirstlane, whose early s_waitcnt would expose the latency of the operand prefetch.
+// prove them read-only: the wave-uniform header stream then becomes scalar loads (s_load).
 struct InterpDims {
     uint32_t n_bundles, n_slots, n_inputs, batch, n_const;
 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+// Direct-to-LDS load: 16 bytes per lane from buffer[voff + soff] to LDS[lds_addr + lane * 16].  No VGPR destination,
+// so nothing waits on it; completion is counted by hand (s_waitcnt vmcnt) in the interpreter loop.  M0 (the LDS base
+// of the load) is written inside the same statement.
+__device__ __forceinline__ void dma16(uint32_t lds_addr, uint32_t voff, const i32x4& rsrc, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
 
 template <int T, bool PROF>
 __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
@@ -43,130 +59,123 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
+    constexpr uint32_t HI = 16u * T;  // byte distance between the two 16-byte halves of a value in a slot
     const uint32_t batch = p.batch;
-    const int lane = (int)threadIdx.x;
-    const int t = lane % T;
-    const int j = (G == 1) ? 0 : lane / T;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = lane % T;
+    const uint32_t j = (G == 1) ? 0u : lane / T;
     const uint32_t tile = blockIdx.x;
-    const uint32_t set = tile * T + (uint32_t)t;
+    const uint32_t set = tile * T + t;
     const uint32_t set_c = set < batch ? set : batch - 1;  // padded lanes of the last tile re-evaluate a real set
-    // One buffer descriptor over the launch's workspace [constants | tiles]; all operand / destination addresses are
-    // 32-bit byte offsets into it (host-computed, plus this lane's base for tile-relative ones).
-    const uint64_t tile_bytes = ws_tile_bytes(p.n_slots, T);
+    // One buffer descriptor per tile: every operand / destination is a 32-bit tile-relative byte offset.
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
     const uint32_t chunk = tile / wst.tiles_per_chunk, tile_in_chunk = tile % wst.tiles_per_chunk;
-    void* ws = wst.base[chunk];
-    const uint64_t ws_bytes = ws_const_bytes(p.n_const, T) + (uint64_t)wst.tiles_per_chunk * tile_bytes;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(uint32_t)ws_bytes, 0x00020000);
-    const uint32_t lane_base = (uint32_t)(ws_const_bytes(p.n_const, T) + (uint64_t)tile_in_chunk * tile_bytes) + 16u * (uint32_t)t;
-    constexpr int HI = 16 * T;  // byte distance between the two 16-byte halves of a value
-    // Result ring (one wave per block): slot (bundle mod RING) holds the 64 lane results of that bundle as
-    // [half][lane][16 B], so the wave's ds_write_b128 / ds_read_b128 are conflict-free and any lane can read any
-    // other lane's recent result (host-computed byte offset + 16*t).
-    __shared__ uint4 ring[RING_BUNDLES * 128];
-    const uint32_t lds_t = 16u * (uint32_t)t;
+    char* tile_base = reinterpret_cast<char*>(wst.base[chunk]) + (uint64_t)tile_in_chunk * tile_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
+    const i32x4 rsrc_w = make_rsrc_words(tile_base, (uint32_t)tile_bytes);
+    const i32x4 rsrc_rec = make_rsrc_words(recs, p.n_bundles * (uint32_t)G * 16u);
+    __shared__ uint4 lds[LDS_BYTES / 16];  // the only LDS object of the kernel: host-computed addresses are offsets into it
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)(char*)lds;
+    const uint32_t t16 = 16u * t, lane16 = 16u * lane, j16 = 16u * j;
+    char* const ldsb = reinterpret_cast<char*>(lds);
 
-    auto ld = [&](uint32_t off) -> Fr {
+    auto ld = [&](uint32_t off) -> Fr {  // synchronous load of a slot (third operands only)
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
-        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + HI, 0, 0);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + (int)HI, 0, 0);
         return Fr{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
     };
-    auto opnd_off = [&](uint32_t off, uint32_t ctrl, uint32_t tile_bit) -> uint32_t {
-        return off + ((ctrl & tile_bit) ? lane_base : 0u);
-    };
-    auto ld_ring = [&](uint32_t off) -> Fr {  // off: byte offset of the low half inside the ring
-        const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ring) + off);
-        const uint4 lo = q[0], hi = q[RING_HALF_BYTES / 16];
+    auto ld_lds = [&](uint32_t addr) -> Fr {  // addr: LDS byte address of the low half
+        const uint4* q = reinterpret_cast<const uint4*>(ldsb + addr);
+        const uint4 lo = q[0], hi = q[LDS_HALF_BYTES / 16];
         return fr_from_u4(lo, hi);
     };
-    uint32_t err_bits = 0;
-    unsigned long long pf[C_COUNT][4];
-    if (PROF) {
-#pragma unroll
-        for (int c = 0; c < (int)C_COUNT; ++c) pf[c][0] = pf[c][1] = pf[c][2] = pf[c][3] = 0;
-    }
-    unsigned long long t_prev = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned long long probe[4] = {0, 0, 0, 0};
-
-    // Software pipeline.  While bundle b computes: its own memory operands were fetched during bundle b-1, the
-    // memory operands of bundle b+1 and the header + records of bundle b+2 are in flight.  Only forwarded operands
-    // (register reads, same lane or ds_bpermute) and the arithmetic sit on the chain between consecutive bundles.
-#if defined(CWC_EXP_SECTIONS)  // timing experiment only: where inside an iteration does the time go
-    unsigned long long sec[4] = {0, 0, 0, 0};
-#define CWC_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
-#else
-#define CWC_STAMP(var)
-#endif
+    auto ld_rec2 = [&](uint32_t bundle, uint32_t half) -> uint2 {  // one half of this lane's staged record
+        return *reinterpret_cast<const uint2*>(ldsb + LDS_REC_OFF + (bundle % REC_AHEAD) * REC_BYTES + lane16 + 8u * half);
+    };
     const uint32_t NBND = p.n_bundles;
     if (NBND == 0) return;
     auto clampb = [&](uint32_t b) { return b < NBND ? b : NBND - 1; };
+    auto stage_rec = [&](uint32_t bundle) {  // records of `bundle` -> REC ring (the same record for the T lanes of a node slot)
+        dma16(lds0 + LDS_REC_OFF + (bundle % REC_AHEAD) * REC_BYTES, j16, rsrc_rec, clampb(bundle) * (uint32_t)G * 16u);
+    };
+    auto stage_operands = [&](uint32_t bundle, const uint2& offs) {  // memory operands of `bundle` -> STAGE ring
+        const uint32_t s = lds0 + LDS_STAGE_OFF + (bundle % OPND_AHEAD) * STAGE_BYTES;
+        const uint32_t ao = offs.x + t16, bo = offs.y + t16;
+        dma16(s, ao, rsrc_w, 0);
+        dma16(s + LDS_HALF_BYTES, ao, rsrc_w, HI);
+        dma16(s + 2 * LDS_HALF_BYTES, bo, rsrc_w, 0);
+        dma16(s + 3 * LDS_HALF_BYTES, bo, rsrc_w, HI);
+    };
+    uint32_t err_bits = 0;
+    unsigned long long pf[C_COUNT][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
+    if (PROF) {
+#pragma unroll
+        for (int c = 0; c < (int)C_COUNT; ++c) pf[c][0] = pf[c][1] = 0;
+    }
+#define CWC_STAMP(var) unsigned long long var = 0; if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+
+    // Software pipeline, everything through LDS.  While bundle b computes: its operands sit in STAGE[b mod 2] / the
+    // RING; the memory operands of bundle b+1 are landing in STAGE[(b+1) mod 2]; those of bundle b+2 are requested as
+    // soon as bundle b has read its own (same STAGE cell); records run REC_AHEAD bundles ahead.  Vector-memory
+    // operations per iteration, in issue order: 4 operand loads, 1 record load, 2 stores -- the counted wait at the
+    // top of iteration b (vmcnt(9)) retires the operand loads of bundle b and the record load of bundle b+2, both issued
+    // in iteration b-2, and leaves the 9 younger operations in flight.
+    static_assert(OPND_AHEAD == 2 && REC_AHEAD == 4, "the counted waits below are written for this pipeline depth");
+#pragma unroll
+    for (uint32_t q = 0; q < REC_AHEAD; ++q) stage_rec(q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_operands(0, ld_rec2(0, 0));
+    stage_operands(1, ld_rec2(1, 0));
+    uint2 rec_hi = ld_rec2(0, 1);  // {dst | ctrl, a_lds | b_lds << 16} of the current bundle
     uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
-    uint4 rec_cur = recs[j], rec_n1 = recs[(size_t)clampb(1) * G + j];
-    Fr ma_cur = ld(opnd_off(rec_cur.z, rec_cur.x, CTRL_A_TILE) & (((h_cur & HDR_CLASS_MASK) == C_INPUT) ? 0u : ~0u));
-    Fr mb_cur = ld(opnd_off(rec_cur.w, rec_cur.x, CTRL_B_TILE));
-    Fr prev = fr_zero();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t b = 0; b < NBND; ++b) {
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
-        const uint4 rec = rec_cur;
-        const uint32_t ctrl = rec.x;
-        // prefetch: memory operands of bundle b+1 (INPUT records carry an input index in .z: fetch offset 0 instead),
-        // header / records of bundle b+2
-        const uint32_t a_n1 = opnd_off(rec_n1.z, rec_n1.x, CTRL_A_TILE) & (((h_n1 & HDR_CLASS_MASK) == C_INPUT) ? 0u : ~0u);
-#if defined(CWC_EXP_NOLOAD)  // timing experiment only (wrong results)
-        Fr ma_n1 = fr_one(), mb_n1 = fr_one();
-        ma_n1.v[0] ^= a_n1;
-        mb_n1.v[0] ^= rec_n1.w;
-#else
-        const Fr ma_n1 = ld(a_n1);
-        const Fr mb_n1 = ld(opnd_off(rec_n1.w, rec_n1.x, CTRL_B_TILE));
-#endif
-        const uint32_t b2 = clampb(b + 2);
-        const uint32_t h_n2 = hdr[b2];
-        const uint4 rec_n2 = recs[(size_t)b2 * G + j];
+        const uint32_t h_n2 = hdr[clampb(b + 2)];
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        CWC_STAMP(st1);
+        const uint32_t ctrl = rec_hi.x & CTRL_MASK;
+        const uint32_t doff = (rec_hi.x & ~CTRL_MASK) | t16;
+        const uint32_t la = rec_hi.y + (t16 | (t16 << 16));
+        const Fr a_op = ld_lds(la & 0xffffu), b_op = ld_lds(la >> 16);
+        const uint2 rec_n2 = ld_rec2(b + 2, 0);    // {a_off, b_off} of bundle b+2
+        const uint2 rec_hi_n1 = ld_rec2(b + 1, 1);
+        // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2] / REC[b mod 4]
+        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n1.x) : "memory");
+        CWC_STAMP(st2);
+        stage_operands(b + 2, rec_n2);
+        stage_rec(b + 4);
+        CWC_STAMP(st3);
 
         const uint32_t cls = h & HDR_CLASS_MASK;
         const bool active = (ctrl & CTRL_ACTIVE) != 0;
-        const uint32_t sub = (ctrl >> CTRL_SUB_SHIFT) & 0xffu;
-        // Operand selection: memory operands were prefetched during the previous bundle; PREV lanes take their own
-        // last result; LDS lanes read the result ring (wave-uniform header bits skip what no lane needs).
-        const uint32_t asrc = (ctrl >> CTRL_ASRC_SHIFT) & 3u, bsrc = (ctrl >> CTRL_BSRC_SHIFT) & 3u;
-        Fr a_op = ma_cur, b_op = mb_cur;
-        if (h & HDR_A_LDS) a_op = u256_select(asrc == SRC_LDS, ld_ring(rec.z + lds_t), a_op);
-        if (h & HDR_B_LDS) b_op = u256_select(bsrc == SRC_LDS, ld_ring(rec.w + lds_t), b_op);
-        if (h & HDR_A_PREV) a_op = u256_select(asrc == SRC_PREV, prev, a_op);
-        if (h & HDR_B_PREV) b_op = u256_select(bsrc == SRC_PREV, prev, b_op);
+        const uint32_t sub = ctrl & CTRL_SUB_MASK;
         Fr r;
         if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
-#if defined(CWC_EXP_NOMUL)  // timing experiment only (wrong results)
-            r = fr_add(a_op, b_op);
-#else
             r = fr_mul(a_op, b_op);
-#endif
         } else if (__builtin_expect(cls == C_LIN, 1)) {
             // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a.  Branch-free: a + (+-b) with -b = r - b
             // (b = 0 gives a + r, folded by the conditional subtraction of fr_add).
             Fr nb;
             u256_sub(nb, fr_p(), b_op);
-            r = fr_add(a_op, u256_select(sub == OP_ADD, b_op, nb));
+            r = fr_add(a_op, u256_select(sub == SUB_ADD, b_op, nb));
         } else
         switch (cls) {
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
-                const uint4* q = inputs + ((size_t)set_c * p.n_inputs + rec.z) * 2;
+                const uint32_t idx = crefs[(size_t)b * G + j];
+                const uint4* q = inputs + ((size_t)set_c * p.n_inputs + idx) * 2;
                 r = fr_to_mont(fr_from_u4(q[0], q[1]));
                 break;
             }
             case C_DIV: {  // graph.rs:109  b == 0 -> 0 else a / b
-#if defined(CWC_EXP_NODIV)  // timing experiment only (wrong results)
-                r = fr_add(a_op, b_op);
-#else
                 const Fr inv = fr_inv(b_op);  // safegcd divsteps; inv(0) = 0
                 r = u256_select(u256_is_zero(b_op), fr_zero(), fr_mul(a_op, inv));
-#endif
                 break;
             }
             case C_CMPZ: {  // graph.rs:122-129 Eq/Neq, :134-135 Land/Lor
                 const bool az = u256_is_zero(a_op), cz = u256_is_zero(b_op), eq = u256_eq(a_op, b_op);
-                const bool v = sub == OP_EQ ? eq : sub == OP_NEQ ? !eq : sub == OP_LAND ? (!az && !cz) : (!az || !cz);
+                const bool v = sub == SUB_EQ ? eq : sub == SUB_NEQ ? !eq : sub == SUB_LAND ? (!az && !cz) : (!az || !cz);
                 r = u256_select(v, fr_one(), fr_zero());
                 break;
             }
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
                 const bool same = xn == yn;
                 const bool lt = same ? u256_lt(x, y) : xn;
                 const bool gt = same ? u256_lt(y, x) : yn;
-                const bool v = sub == OP_LT ? lt : sub == OP_GT ? gt : sub == OP_LEQ ? !gt : !lt;
+                const bool v = sub == SUB_LT ? lt : sub == SUB_GT ? gt : sub == SUB_LEQ ? !gt : !lt;
                 r = u256_select(v, fr_one(), fr_zero());
                 break;
             }
@@ -188,18 +197,18 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
                 const bool big = hi_or != 0 || y.v[0] >= 254u;  // b >= MODULUS_BIT_SIZE -> 0
                 const uint32_t n = big ? 0u : y.v[0];
                 Fr d;
-                if (sub == OP_SHL || sub == OP_SHR) {
+                if (sub == SUB_SHL || sub == SUB_SHR) {
                     const Fr sl = u256_shl(x, n), sr = u256_shr(x, n);
-                    d = u256_select(sub == OP_SHL, sl, sr);
+                    d = u256_select(sub == SUB_SHL, sl, sr);
                     d = u256_select(big, fr_zero(), d);
-                    if (sub == OP_SHL && !u256_lt(d, fr_p())) {  // graph.rs:634 unwrap on None
+                    if (sub == SUB_SHL && !u256_lt(d, fr_p())) {  // graph.rs:634 unwrap on None
                         if (active) err_bits |= ST_SHL_OVERFLOW;
                         d = fr_zero();
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        d.v[i] = sub == OP_BAND ? (x.v[i] & y.v[i]) : sub == OP_BOR ? (x.v[i] | y.v[i]) : (x.v[i] ^ y.v[i]);
+                        d.v[i] = sub == SUB_BAND ? (x.v[i] & y.v[i]) : sub == SUB_BOR ? (x.v[i] | y.v[i]) : (x.v[i] ^ y.v[i]);
                     Fr dm;
                     const uint32_t br = u256_sub(dm, d, fr_p());  // br == 1 iff d < r
                     if (br == 0) {                                // d >= r: one subtraction (d < 2^254 < 2r)
@@ -232,92 +241,80 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
                 top = (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
                 Fr q, rem;
                 u256_divrem(q, rem, x, ys, top);
-                const Fr d = u256_select(yz, fr_zero(), u256_select(sub == OP_IDIV, q, rem));
+                const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));
                 r = fr_to_mont(d);
                 break;
             }
             case C_TERN: {  // graph.rs:221-225  a == 0 ? c : b ; the third operand is always a memory reference
                 const uint32_t cr = crefs[(size_t)b * G + j];
-                const Fr y = ld((cr & ~CREF_TILE) + ((cr & CREF_TILE) ? lane_base : 0u));
+                const Fr y = ld(cr + t16);
                 r = u256_select(u256_is_zero(a_op), y, b_op);
                 break;
             }
             default: r = fr_zero(); break;
         }
-        CWC_STAMP(st2);
-        {   // unconditional store (the host points values without a slot and inactive node slots at the tile's trash
-            // slot): a fixed number of stores per bundle lets the waitcnt pass count them instead of draining
-            const uint32_t doff = rec.y + lane_base;
-#if !defined(CWC_EXP_NOSTORE)  // timing experiment only (wrong results)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[0], r.v[1], r.v[2], r.v[3]}, rsrc, (int)doff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[4], r.v[5], r.v[6], r.v[7]}, rsrc, (int)doff + HI, 0, 0);
-#else
-            asm volatile("" ::"v"(doff), "v"(r.v[0]), "v"(r.v[7]));
-#endif
-        }
+        CWC_STAMP(st4);
+        // unconditional store (values without a slot and inactive node slots go to the tile's trash slot): a fixed
+        // number of vector-memory operations per bundle is what makes the counted wait above possible
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[0], r.v[1], r.v[2], r.v[3]}, rsrc, (int)doff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[4], r.v[5], r.v[6], r.v[7]}, rsrc, (int)doff + (int)HI, 0, 0);
         {   // publish the results of this bundle in the ring (read by later bundles of this wave, in order)
-            uint4* q = ring + (b & (RING_BUNDLES - 1u)) * 128u + (uint32_t)lane;
+            uint4* q = reinterpret_cast<uint4*>(ldsb + LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES + lane16);
             q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-            q[64] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+            q[LDS_HALF_BYTES / 16] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
         }
-        prev = r;
-        h_cur = h_n1; rec_cur = rec_n1; ma_cur = ma_n1; mb_cur = mb_n1;
-        h_n1 = h_n2; rec_n1 = rec_n2;
+        rec_hi = rec_hi_n1;
+        h_cur = h_n1;
+        h_n1 = h_n2;
         // Later bundles read these stores from other lanes of this wave; a wave's vector-memory instructions
         // execute in order, the fence only keeps the compiler from reordering them.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if defined(CWC_EXP_SECTIONS)
-        {
-            CWC_STAMP(st3);
-            asm volatile("" ::"v"(ma_cur.v[0]), "v"(mb_cur.v[7]), "v"(rec_cur.x), "v"(rec_n1.w), "s"(h_cur), "s"(h_n1));
-            sec[0] += st1 - st0; sec[1] += st2 - st1; sec[2] += st3 - st2; sec[3] += 1;
-        }
-#endif
-        if (PROF && (b & 63u) == 63u) {
-            // latency probes (diagnostic only): a constant-table line, and the slot this bundle has just stored
-            __builtin_amdgcn_s_waitcnt(0);
-            const unsigned long long q0 = __builtin_amdgcn_s_memtime();
-            const Fr pc = ld(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(pc.v[0]), "v"(pc.v[7]) : "memory");
-            const unsigned long long q1 = __builtin_amdgcn_s_memtime();
-            const Fr ps = ld(rec.y + lane_base);
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(ps.v[0]), "v"(ps.v[7]) : "memory");
-            const unsigned long long q2 = __builtin_amdgcn_s_memtime();
-            const uint4 pr = recs[(size_t)clampb(b + 40) * G + j];
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(pr.x), "v"(pr.w) : "memory");
-            const unsigned long long q3 = __builtin_amdgcn_s_memtime();
-            probe[0] += q1 - q0; probe[1] += q2 - q1; probe[2] += q3 - q2; probe[3] += 1;
-            t_prev += q3 - q0;  // keep the probes out of the per-class figures
-        }
         if (PROF) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring write belongs to this bundle
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();
-            const bool fwd = (h & (HDR_A_PREV | HDR_A_LDS | HDR_B_PREV | HDR_B_LDS)) != 0;
 #pragma unroll
             for (int c = 0; c < (int)C_COUNT; ++c)
                 if (cls == (uint32_t)c) {
-                    pf[c][0] += t_now - t_prev;              // cycles of this bundle in the pipelined loop
-                    pf[c][1] += fwd ? (t_now - t_prev) : 0;  // ... of which bundles with a forwarded operand
-                    pf[c][2] += fwd ? 1 : 0;
-                    pf[c][3] += 1;
+                    pf[c][0] += t_now - st0;  // cycles of this bundle in the pipelined loop (stamp bookkeeping excluded)
+                    pf[c][1] += 1;
                 }
-            t_prev = t_now;
+            if (cls == C_MUL || cls == C_LIN) {
+                unsigned long long* q = psec[cls == C_MUL ? 0 : 1];
+                q[0] += st1 - st0;    // top of the loop + counted wait for the staged operands
+                q[1] += st2 - st1;    // operand / record reads from LDS
+                q[2] += st3 - st2;    // issuing the staging loads
+                q[3] += st4 - st3;    // class dispatch + arithmetic
+                q[4] += t_now - st4;  // stores, ring write
+                q[5] += 1;
+            }
         }
     }
     if (PROF && lane == 0 && (tile % 64u) == 0u) {
 #pragma unroll
-        for (int c = 0; c < (int)C_COUNT; ++c)
+        for (int c = 0; c < (int)C_COUNT; ++c) {
+            atomicAdd(&prof[c * 4 + 0], pf[c][0]);
+            atomicAdd(&prof[c * 4 + 3], pf[c][1]);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(&prof[c * 4 + q], pf[c][q]);
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomicAdd(&prof[36 + q], probe[q]);
+            for (int q = 0; q < 6; ++q) atomicAdd(&prof[40 + 8 * k + q], psec[k][q]);
     }
-#if defined(CWC_EXP_SECTIONS)
-    if (tile == 0 && lane == 0) {
-        for (int q = 0; q < 4; ++q) { status[2 * q] = (uint32_t)sec[q]; status[2 * q + 1] = (uint32_t)(sec[q] >> 32); }
-        return;
-    }
-#endif
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
+}
+
+// Writes every tile's copy of the constants: the constant area of a tile is n_const slots = n_const*2*T pieces of 16
+// bytes, piece e = (constant e / 2T, half (e / T) % 2, set e % T).  Once per (workspace, program).
+__global__ __launch_bounds__(256) void fill_consts_kernel(ProgramDev p, WsTable wst, uint32_t n_tiles, uint32_t T) {
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t pieces = p.n_const * 2u * T;
+    if (e >= pieces) return;
+    const uint4 v = reinterpret_cast<const uint4*>(p.consts)[(size_t)(e / (2u * T)) * 2u + (e / T) % 2u];
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
+    for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+        char* tb = reinterpret_cast<char*>(wst.base[tile / wst.tiles_per_chunk]) + (uint64_t)(tile % wst.tiles_per_chunk) * tile_bytes;
+        reinterpret_cast<uint4*>(tb)[e] = v;
+    }
 }
 
 // Block = 64 witness indices x min(T, 4) sets of ONE tile: the waves of a block read the same 128-byte lines of the
@@ -327,16 +324,15 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
     if (w >= p.n_witness) return;
     const uint32_t ref = p.witness_refs[w];
     const uint32_t n_tiles = (batch + T - 1) / T;
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
+    const uint32_t slot = (ref & REF_CONST) ? (ref & ~REF_CONST) : p.n_const + ref;  // every tile holds the constants too
     for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
-        const uint4* ws = reinterpret_cast<const uint4*>(wst.base[tile / wst.tiles_per_chunk]);
-        const uint4* q0 = (ref & REF_CONST)
-                              ? ws + (size_t)(ref & ~REF_CONST) * (2 * T)  // constants: head of the chunk's workspace
-                              : ws + ws_const_bytes(p.n_const, T) / 16 +
-                                    ((size_t)(tile % wst.tiles_per_chunk) * (p.n_slots + 1) + ref) * (2 * T);
+        const char* tb = reinterpret_cast<const char*>(wst.base[tile / wst.tiles_per_chunk]) + (uint64_t)(tile % wst.tiles_per_chunk) * tile_bytes;
+        const uint4* q0 = reinterpret_cast<const uint4*>(tb) + (size_t)slot * (2 * T);
         for (uint32_t t = threadIdx.y; t < T; t += blockDim.y) {
             const uint32_t set = tile * T + t;
             if (set >= batch) break;
-            const uint4* q = (ref & REF_CONST) ? q0 : q0 + t;
+            const uint4* q = q0 + t;
             const Fr c = fr_from_mont(fr_from_u4(q[0], q[T]));
             uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
             o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
@@ -363,6 +359,13 @@ hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, co
         default: return hipErrorInvalidValue;
     }
 #undef CWC_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream) {
+    if (n_tiles == 0 || p.n_const == 0) return hipSuccess;
+    dim3 grid((p.n_const * 2u * T + 255u) / 256u, n_tiles < 16384u ? n_tiles : 16384u), block(256);
+    fill_consts_kernel<<<grid, block, 0, stream>>>(p, wst, n_tiles, T);
     return hipGetLastError();
 }
 

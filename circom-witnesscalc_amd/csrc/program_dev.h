@@ -26,34 +26,43 @@ enum BundleClass : uint32_t {
     C_COUNT = 9
 };
 
-// Program format v3 -- laid out so that the interpreter spends (almost) no instructions on decoding.
+// Program format v4 -- every operand of a bundle is read from the wave's LDS at a host-computed address, and the
+// interpreter spends no vector instruction on decoding or address arithmetic beyond adding the lane's 16*t.
 //
-// hdr[bundle] (wave-uniform, fetched with scalar loads):
-//   bits 0-3 class | bits 4-10 node count | bit 11 some a operand is PREV | bit 12 some a operand is LDS |
-//   bit 13 some b operand is PREV | bit 14 some b operand is LDS
-// operand sources (per lane, in ctrl):
-//   MEM   constant table or value slot in the workspace (global memory, prefetched one bundle ahead)
-//   PREV  the lane's own result of the previous bundle (register, no instruction)
-//   LDS   the result ring: every bundle writes its 64 lane results into ring slot (bundle mod RING) of the wave's
-//         LDS; any value produced at most RING-1 bundles ago is read back from there, whatever lane produced it
+// hdr[bundle] (wave-uniform, fetched with scalar loads): bits 0-3 class | bits 4-10 node count
 //
-// rec[bundle][node slot] = {ctrl, dst, a, b}: dst is a BYTE offset (tile-relative) for the store; a/b are byte offsets
-// for raw_buffer_load through one descriptor over the workspace [constant table | tile 0 | tile 1 | ...] (MEM; offsets
-// flagged tile-relative get the lane's base added) or byte offsets into the wave's LDS ring (LDS; the lane adds
-// 16*t).  ctrl: bit0 a tile-relative, bit1 b tile-relative, bits 2-3 a source, bits 4-5 b source, bits 16-23 DuoOp
-// code (or SUB_*), bit 24 active.
+// LDS of a wave (one wave per workgroup), byte addresses:
+//   RING   [LDS_RING_OFF  + (bundle mod RING_BUNDLES) * 2 KiB]  results of the last RING_BUNDLES bundles,
+//          [half][64 lanes][16 B]: any lane's recent result, whatever lane produced it
+//   STAGE  [LDS_STAGE_OFF + (bundle mod OPND_AHEAD) * 4 KiB]    memory operands of a bundle, fetched OPND_AHEAD bundles
+//          ahead by direct-to-LDS buffer loads (no VGPRs, no waiting): [a lo | a hi | b lo | b hi][64 lanes][16 B]
+//   REC    [LDS_REC_OFF   + (bundle mod REC_AHEAD) * 1 KiB]     the bundle's records, fetched REC_AHEAD bundles ahead
+// operand sources: a value produced at most RING_BUNDLES bundles ago comes from the RING, everything else (older
+// values, constants, every third operand) from its slot in the tile (MEM, staged through STAGE).
+//
+// rec[bundle][node slot] = {a_off, b_off, dst | ctrl, a_lds | b_lds << 16}
+//   a_off/b_off  tile-relative byte offset of the operand's slot (the lane adds 16*t) for the staging load; operands
+//                that come from the RING point at the zero constant (the load still happens, its result is unused)
+//   dst          tile-relative byte offset of the destination slot (trash slot when the value needs none);
+//                low 4 bits = ctrl: bits 0-2 sub-op within the class (SubOp), bit 3 active
+//   a_lds/b_lds  LDS byte address of the operand's low half for t = 0 (the lane adds 16*t): its STAGE cell or a RING cell
+// crefs[bundle][node slot]: TernCond third operand (tile-relative byte offset, always MEM, loaded in place);
+//                           INPUT bundles: index into the set's input row.
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
-static const uint32_t HDR_A_PREV = 1u << 11, HDR_A_LDS = 1u << 12, HDR_B_PREV = 1u << 13, HDR_B_LDS = 1u << 14;
-enum OperandSource : uint32_t { SRC_MEM = 0, SRC_PREV = 1, SRC_LDS = 2 };
-static const uint32_t CTRL_A_TILE = 1u << 0, CTRL_B_TILE = 1u << 1, CTRL_ACTIVE = 1u << 24;
-static const int CTRL_ASRC_SHIFT = 2, CTRL_BSRC_SHIFT = 4, CTRL_SUB_SHIFT = 16;
-// result ring in LDS: RING bundles x [half][64 lanes][16 B] = RING * 2 KiB per wave
-static const uint32_t RING_BUNDLES = 8;
-static const uint32_t RING_SLOT_BYTES = 2048, RING_HALF_BYTES = 1024;
-// third operand (TernCond) byte offset: bit 31 = tile-relative (always a memory reference)
-static const uint32_t CREF_TILE = 0x80000000u;
-enum SubOp : uint32_t { SUB_TERN = 33, SUB_INPUT = 34 };
+static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
+static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
+static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;
+static const uint32_t LDS_RING_OFF = 0, LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES,
+                      LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES, LDS_BYTES = LDS_REC_OFF + REC_AHEAD * REC_BYTES;
+// sub-ops inside a class (3 bits)
+enum SubOp : uint32_t {
+    SUB_ADD = 0, SUB_SUB = 1,                                      // C_LIN (Neg is 0 - a)
+    SUB_EQ = 0, SUB_NEQ = 1, SUB_LAND = 2, SUB_LOR = 3,            // C_CMPZ
+    SUB_LT = 0, SUB_GT = 1, SUB_LEQ = 2, SUB_GEQ = 3,              // C_CMPS
+    SUB_SHL = 0, SUB_SHR = 1, SUB_BOR = 2, SUB_BAND = 3, SUB_BXOR = 4,  // C_BIT
+    SUB_IDIV = 0, SUB_MOD = 1,                                     // C_IDIVMOD
+};
 
 // witness reference (pack kernel): bit 31 set -> constant table index, else value slot of the tile
 static const uint32_t REF_CONST = 0x80000000u;
@@ -69,13 +78,12 @@ struct ProgramDev {
     const uint32_t* hdr;           // [n_bundles]
     const uint32_t* recs;          // [n_bundles*G*4], 16-byte aligned records
     const uint32_t* crefs;         // [n_bundles*G]
-    const uint32_t* consts;        // [n_const*8] Montgomery form; copied to the head of the workspace per launch
+    const uint32_t* consts;        // [n_const*8] Montgomery form (the last entry is a dummy zero)
     const uint32_t* witness_refs;  // [n_witness]
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
 };
 
-// A launch covers up to WS_MAX_CHUNKS workspaces of < 4 GiB each (the 32-bit buffer window is per descriptor, not per
-// launch): tile i lives in chunk i / tiles_per_chunk, every chunk starts with its own copy of the constant table.
+// A launch covers up to WS_MAX_CHUNKS separately allocated workspaces: tile i lives in chunk i / tiles_per_chunk.
 static const uint32_t WS_MAX_CHUNKS = 32;
 struct WsTable {
     void* base[WS_MAX_CHUNKS];
@@ -83,11 +91,10 @@ struct WsTable {
     uint32_t n_chunks;
 };
 
-// workspace geometry shared by host and kernels: [constants, padded to 256 B][tiles]
-// tile = (n_slots + 1) slots (the last one is the trash slot) of 32*T bytes: [slot][half][T][16 B].
-// A constant uses the same geometry (32*T bytes apart, halves 16*T apart, only the first 16 bytes of each half
-// used) so that every operand's high half sits at the same fixed distance from its low half.
-CWC_HD uint64_t ws_const_bytes(uint32_t n_const, uint32_t T) { return (((uint64_t)n_const * 32u * T) + 255u) & ~255ull; }
-CWC_HD uint64_t ws_tile_bytes(uint32_t n_slots, uint32_t T) { return ((uint64_t)n_slots + 1u) * 32u * T; }
+// Tile geometry shared by host and kernels.  A tile holds the values of T input sets:
+//   [n_const constant slots | n_slots value slots | trash slot], slot = 32*T bytes = [half][T][16 B].
+// Each tile has its own buffer descriptor (base = the tile, 32-bit tile-relative offsets), and its own copy of the
+// constants (written once per workspace by fill_consts_kernel), so that every operand is addressed the same way.
+CWC_HD uint64_t ws_tile_bytes(uint32_t n_const, uint32_t n_slots, uint32_t T) { return ((uint64_t)n_const + n_slots + 1u) * 32u * T; }
 
 }  // namespace cwc

@@ -21,6 +21,7 @@ namespace cwc {
 hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
                          uint32_t batch, hipStream_t stream, unsigned long long* prof);
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream);
+hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
 }  // namespace cwc
 
 using namespace cwc;
@@ -83,7 +84,7 @@ std::string upload_program(DeviceProgram& dp) {
 
 uint64_t workspace_budget() {
     const char* e = getenv("CWC_WORKSPACE_GB");
-    double gb = e ? atof(e) : 3.9;
+    double gb = e ? atof(e) : 8.0;
     if (gb < 1e-4) gb = 1e-4;  // tiny budgets are allowed (tests use them to force chunking); one tile is the floor
     return (uint64_t)(gb * (double)(1ull << 30));
 }
@@ -100,11 +101,15 @@ struct gwb_graph {
     ProgramStats stats;
     std::map<uint32_t, std::unique_ptr<DeviceProgram>> progs;
     uint32_t forced_T = 0;
-    // value workspaces ("chunks"): a wave addresses its chunk through a 32-bit buffer window, so a large batch is
-    // spread over several < 4 GiB chunks, all covered by ONE launch (the kernel picks the chunk per tile)
+    // value workspaces ("chunks"): separately allocated groups of tiles (CWC_WORKSPACE_GB each), all covered by ONE
+    // launch (the kernel picks the chunk per tile; every tile has its own 32-bit buffer window)
     static const int kMaxLanes = (int)WS_MAX_CHUNKS;
     void* d_vals[kMaxLanes] = {nullptr};
     size_t vals_bytes[kMaxLanes] = {0};
+    // which constants the tiles of the workspaces currently hold (fill_consts_kernel runs when this changes)
+    const DeviceProgram* filled_prog = nullptr;
+    uint64_t filled_tiles_per_chunk = 0;
+    size_t filled_chunks = 0;
     bool timing_pending = false;
     gwb_timing_t timing{};
     unsigned long long* d_prof = nullptr;  // diagnostic per-class stamps (gwb_profile_classes), else null
@@ -190,36 +195,47 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     std::string err = get_program(g, T, &dp);
     if (!err.empty()) return err;
     const Program& p = dp->host;
-    // Workspace of one launch: [constant table | tiles]; addressed with 32-bit byte offsets through one buffer
-    // descriptor, so it must stay below 4 GiB; larger batches are evaluated in chunks.
-    const uint64_t const_bytes = ws_const_bytes(p.n_const, T);
-    const uint64_t bytes_per_tile = ws_tile_bytes(p.n_slots, T);
-    uint64_t budget = workspace_budget();
-    const uint64_t cap = 0xffffffffull - 4096;
-    if (budget > cap) budget = cap;
-    if (const_bytes + bytes_per_tile > cap) return "graph too large for the 4 GiB workspace window";
-    uint64_t max_tiles = budget > const_bytes ? (budget - const_bytes) / bytes_per_tile : 0;
+    // Workspace: tiles of (constants | value slots | trash slot), grouped into separately allocated chunks of at most
+    // CWC_WORKSPACE_GB; larger batches than WS_MAX_CHUNKS chunks hold are evaluated in several launches.
+    const uint64_t bytes_per_tile = ws_tile_bytes(p.n_const, p.n_slots, T);
+    const uint64_t budget = workspace_budget();
+    if (bytes_per_tile > 0xffffffffull) return "graph too large for the 4 GiB tile window";
+    uint64_t max_tiles = budget / bytes_per_tile;
     if (max_tiles == 0) max_tiles = 1;
     const uint64_t tiles_total = (batch + T - 1) / T;
     const uint64_t chunk_tiles = tiles_total < max_tiles ? tiles_total : max_tiles;
-    const size_t need = (size_t)(const_bytes + chunk_tiles * bytes_per_tile);
+    const size_t need = (size_t)(chunk_tiles * bytes_per_tile);
     const size_t chunk_sets = (size_t)chunk_tiles * T;
     const size_t n_chunks = (batch + chunk_sets - 1) / chunk_sets;
-    // chunks per launch: all of them when they fit the table and the memory cap (CWC_STREAMS keeps its old meaning of
-    // "chunks in flight"); otherwise several launches, one after the other
+    // chunks per launch: all of them when they fit the table (CWC_STREAMS caps the number); otherwise several
+    // launches, one after the other
     size_t per_launch = n_chunks < WS_MAX_CHUNKS ? n_chunks : WS_MAX_CHUNKS;
     if (const char* e = getenv("CWC_STREAMS")) {
         const long v = atol(e);
         if (v >= 1 && (size_t)v < per_launch) per_launch = (size_t)v;
     }
+    bool refill = g->filled_prog != dp || g->filled_tiles_per_chunk != chunk_tiles || g->filled_chunks < per_launch;
     for (size_t l = 0; l < per_launch; ++l) {
         if (need > g->vals_bytes[l]) {
             if (g->d_vals[l]) HIP_TRY(hipFree(g->d_vals[l]));
             g->d_vals[l] = nullptr;
             g->vals_bytes[l] = 0;
+            g->filled_prog = nullptr;
+            refill = true;
             HIP_TRY(hipMalloc(&g->d_vals[l], need));
             g->vals_bytes[l] = need;
         }
+    }
+    if (refill) {  // every tile's copy of the constants (the interpreter never writes there)
+        WsTable all;
+        memset(&all, 0, sizeof all);
+        all.tiles_per_chunk = (uint32_t)chunk_tiles;
+        all.n_chunks = (uint32_t)per_launch;
+        for (size_t l = 0; l < per_launch; ++l) all.base[l] = g->d_vals[l];
+        HIP_TRY(launch_fill_consts(T, dp->dev, all, (uint32_t)(per_launch * chunk_tiles), stream));
+        g->filled_prog = dp;
+        g->filled_tiles_per_chunk = chunk_tiles;
+        g->filled_chunks = per_launch;
     }
     g->drop_events();
     g->timing = gwb_timing_t{};
@@ -234,11 +250,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         memset(&wst, 0, sizeof wst);
         wst.tiles_per_chunk = (uint32_t)chunk_tiles;
         wst.n_chunks = (uint32_t)((nb + chunk_sets - 1) / chunk_sets);
-        for (uint32_t l = 0; l < wst.n_chunks; ++l) {
-            wst.base[l] = g->d_vals[l];
-            // constants into slot geometry at the head of each chunk: 16-byte halves, 16*T bytes apart
-            HIP_TRY(hipMemcpy2DAsync(g->d_vals[l], (size_t)16 * T, dp->dev.consts, 16, 16, (size_t)p.n_const * 2, hipMemcpyDeviceToDevice, stream));
-        }
+        for (uint32_t l = 0; l < wst.n_chunks; ++l) wst.base[l] = g->d_vals[l];
         hipEvent_t e0, e1, e2;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
@@ -492,12 +504,12 @@ int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void
     std::string err = check_device();
     if (!err.empty()) return fail(status, err);
     unsigned long long* d = nullptr;
-    if (hipMalloc(&d, 40 * 8) != hipSuccess || hipMemset(d, 0, 40 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
+    if (hipMalloc(&d, 64 * 8) != hipSuccess || hipMemset(d, 0, 64 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
     g->d_prof = d;
     err = run_device(g, d_inputs, batch, d_witness, d_set_status, nullptr);
     g->d_prof = nullptr;
     if (err.empty() && hipDeviceSynchronize() != hipSuccess) err = "hipDeviceSynchronize failed";
-    if (err.empty() && hipMemcpy(out36, d, 40 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
+    if (err.empty() && hipMemcpy(out36, d, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
     (void)hipFree(d);
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");

@@ -80,11 +80,12 @@ int gwb_calc_witness_batch_host(gwb_graph_t *g, const void *inputs, size_t batch
 /* Kernel times of the last batch call on this handle (synchronizes on its events). */
 int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 
-/* Diagnostic build of the interpreter with one in-kernel cycle stamp per bundle: out36[class*4 + {cycles, cycles
- * of bundles with a forwarded operand, such bundles, bundles}], shader cycles summed over the sampled waves;
- * out36 must hold 40 words: [36..39] = load-latency probes (constant line, just-stored slot, far record; count). */
+/* Diagnostic build of the interpreter with in-kernel cycle stamps, shader cycles summed over the sampled waves:
+ * out64[class*4 + 0] = cycles of the class's bundles, out64[class*4 + 3] = bundles; for MUL (k = 0) and LIN (k = 1)
+ * bundles out64[40 + 8*k + {0: loop top + wait for staged operands, 1: LDS operand reads, 2: issuing the staging
+ * loads, 3: dispatch + arithmetic, 4: stores + ring write, 5: bundles}].  out64 must hold 64 words. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
-                        uint32_t *d_set_status, uint64_t *out36, gw_status_t *status);
+                        uint32_t *d_set_status, uint64_t *out64, gw_status_t *status);
 
 /* `.wtns` framing of one witness row (wtns_from_witness, src/lib.rs:114-123): out holds gwb_wtns_size bytes. */
 size_t gwb_wtns_size(size_t n_witness);

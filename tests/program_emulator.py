@@ -8,12 +8,14 @@ import struct
 from oracle import model
 
 REF_CONST = 0x80000000
-CREF_TILE = 0x80000000
-CTRL_A_TILE, CTRL_B_TILE, CTRL_ACTIVE = 1, 2, 1 << 24
-SRC_MEM, SRC_PREV, SRC_LDS = 0, 1, 2
-HDR_A_PREV, HDR_A_LDS, HDR_B_PREV, HDR_B_LDS = 1 << 11, 1 << 12, 1 << 13, 1 << 14
-RING_BUNDLES, RING_SLOT_BYTES = 8, 2048
-SUB_TERN, SUB_INPUT = 33, 34
+CTRL_SUB_MASK, CTRL_ACTIVE, CTRL_MASK = 7, 8, 15
+RING_BUNDLES, OPND_AHEAD, REC_AHEAD = 4, 2, 4
+RING_SLOT_BYTES, LDS_HALF_BYTES, STAGE_BYTES = 2048, 1024, 4096
+LDS_RING_OFF = 0
+LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES
+LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES
+SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS": ["Lt", "Gt", "Leq", "Geq"],
+             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Mul"], "DIV": ["Div"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
 HDR_FMT = "<10I25Q"
@@ -47,91 +49,82 @@ class Blob:
 
 
 def run(blob: Blob, inputs_row):
-    """Evaluate one input set (list of ints) through the format-v3 program; returns (witness ints, status bits).
-    Raises on any read of a slot / ring entry that was never written or already overwritten (scheduling bug) and
-    checks the wave-uniform header bits against the per-record control bits."""
+    """Evaluate one input set (list of ints) through the format-v4 program the way the interpreter kernel does, for
+    t = 0; returns (witness ints, status bits).  Models the timing rules of the pipeline: the staging load of bundle b
+    sees the tile as it is after the stores of bundle b - OPND_AHEAD - 1 (it is issued before bundle b - OPND_AHEAD
+    stores), a ring cell holds the result of the last bundle that wrote it.  Raises on any read of a slot or ring cell
+    that does not hold the value the compiler meant (scheduling / liveness / encoding bug)."""
     T, G = blob.T, blob.G
     slot_bytes = 32 * T
-    trash = blob.n_slots * slot_bytes
-    slots = {}
+    NC = blob.n_const
+    trash = (NC + blob.n_slots) * slot_bytes
+    zero_off = (NC - 1) * slot_bytes
+    history = {}  # value slot -> list of (bundle that stored, value)
     status = 0
-    prev = []   # register results of the previous bundle, by node slot
-    ring = {}   # (ring slot, node slot) -> (bundle that wrote it, value)
+    ring = {}     # (ring cell, node slot) -> (bundle that wrote it, value)
 
-    def mem(off, tile_rel):
-        if not tile_rel:
-            assert off % slot_bytes == 0 and off // slot_bytes < blob.n_const
-            return blob.consts[off // slot_bytes]
-        assert off % slot_bytes == 0 and off // slot_bytes < blob.n_slots
-        return slots[off // slot_bytes]
+    def mem_at(off, as_of_bundle):
+        """content of the tile at byte offset off, after the stores of bundles <= as_of_bundle"""
+        assert off % slot_bytes == 0
+        s_ = off // slot_bytes
+        if s_ < NC:
+            return blob.consts[s_]
+        assert s_ < NC + blob.n_slots, "operand read from the trash slot"
+        for wb, val in reversed(history[s_ - NC]):
+            if wb <= as_of_bundle:
+                return val
+        raise AssertionError("slot read before it was written")
 
     for b in range(blob.n_bundles):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
-        assert 1 <= cnt <= G
+        assert h >> 11 == 0 and 1 <= cnt <= G
         name = CLASS_NAMES[cls]
+        stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
-        seen = {HDR_A_PREV: False, HDR_A_LDS: False, HDR_B_PREV: False, HDR_B_LDS: False}
-        for j in range(cnt):
-            ctrl, dst, a, bb = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
-            assert ctrl & CTRL_ACTIVE
-            sub = (ctrl >> 16) & 0xFF
-            if name == "INPUT":
-                assert sub == SUB_INPUT
-                v = inputs_row[a] % model.M
-            else:
-                ops = []
-                for q, (off, tbit, sh, hp, hl) in enumerate(((a, CTRL_A_TILE, 2, HDR_A_PREV, HDR_A_LDS), (bb, CTRL_B_TILE, 4, HDR_B_PREV, HDR_B_LDS))):
-                    src = (ctrl >> sh) & 3
-                    if src == SRC_PREV:
-                        seen[hp] = True
-                        ops.append(prev[j])  # IndexError = the previous bundle had no node in this slot
-                    elif src == SRC_LDS:
-                        seen[hl] = True
-                        rs, rem = divmod(off, RING_SLOT_BYTES)
-                        assert rs < RING_BUNDLES and rem % (16 * T) == 0 and rem // (16 * T) < G
-                        wb, val = ring[(rs, rem // (16 * T))]
-                        assert 1 <= b - wb <= RING_BUNDLES - 1, "ring entry too old or from the future"
-                        ops.append(val)
-                    else:
-                        assert src == SRC_MEM
-                        ops.append(mem(off, bool(ctrl & tbit)))
-                if name == "TERN":
-                    assert sub == SUB_TERN
-                    cr = blob.crefs[b * G + j]
-                    v = model.eval_tres("TernCond", ops[0], ops[1], mem(cr & 0x7FFFFFFF, bool(cr & CREF_TILE)))
+        for j in range(G):
+            a_off, b_off, dctl, lds = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
+            ctrl, dst = dctl & CTRL_MASK, dctl & ~CTRL_MASK
+            assert bool(ctrl & CTRL_ACTIVE) == (j < cnt)
+            ops = []
+            for q, (off, la) in enumerate(((a_off, lds & 0xFFFF), (b_off, lds >> 16))):
+                own_cell = stage + 2 * q * LDS_HALF_BYTES + j * T * 16
+                if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
+                    ops.append(mem_at(off, b - OPND_AHEAD - 1))
                 else:
-                    op = model.DUO[sub]
-                    expect = {"Mul": "MUL", "Div": "DIV", "Add": "LIN", "Sub": "LIN", "Idiv": "IDIVMOD", "Mod": "IDIVMOD",
-                              "Eq": "CMPZ", "Neq": "CMPZ", "Land": "CMPZ", "Lor": "CMPZ", "Lt": "CMPS", "Gt": "CMPS",
-                              "Leq": "CMPS", "Geq": "CMPS", "Shl": "BIT", "Shr": "BIT", "Bor": "BIT", "Band": "BIT",
-                              "Bxor": "BIT"}[op]
-                    assert expect == name, (op, name)
-                    try:
-                        v = model.eval_duo(op, ops[0], ops[1])
-                    except model.ReferencePanic:
-                        status |= 1 if op == "Shl" else 2
-                        v = 0
+                    assert off == zero_off, "ring operand must stage the zero constant"
+                    rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
+                    assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
+                    wb, val = ring[(rs, rem // (16 * T))]
+                    assert 1 <= b - wb <= RING_BUNDLES, "ring cell too old"
+                    ops.append(val)
+            if j >= cnt:  # padding: harmless operands, store to the trash slot
+                assert dst == trash and a_off == zero_off and b_off == zero_off
+                continue
+            sub = ctrl & CTRL_SUB_MASK
+            if name == "INPUT":
+                v = inputs_row[blob.crefs[b * G + j]] % model.M
+            elif name == "TERN":
+                v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
+            else:
+                op = SUB_NAMES[name][sub]
+                try:
+                    v = model.eval_duo(op, ops[0], ops[1])
+                except model.ReferencePanic:
+                    status |= 1 if op == "Shl" else 2
+                    v = 0
             results.append((dst, v))
-        if name != "INPUT":  # header bits must describe the records
-            for bit, s_ in seen.items():
-                assert bool(h & bit) == s_, (b, bit)
-        for j in range(cnt, G):  # padding: record 0 without ACTIVE, stored to the trash slot
-            r0 = blob.recs[b * G * 4:b * G * 4 + 4]
-            rj = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
-            assert rj[0] == r0[0] & ~CTRL_ACTIVE and rj[1] == trash and rj[2:] == r0[2:]
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
-        for d, v in results:  # all loads of a bundle happen before its stores
-            assert d % slot_bytes == 0 and d // slot_bytes <= blob.n_slots
+        for d, v in results:
+            assert d % slot_bytes == 0 and NC * slot_bytes <= d <= trash
             if d != trash:
-                slots[d // slot_bytes] = v
-        prev = [v for _, v in results]
+                history.setdefault(d // slot_bytes - NC, []).append((b, v))
         for j, (_, v) in enumerate(results):
             ring[(b % RING_BUNDLES, j)] = (b, v)
         for j in range(cnt, G):
-            ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the entry with garbage
+            ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
 
     def wit(r):
-        return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else slots[r]
+        return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else history[r][-1][1]
     return [wit(r) for r in blob.witness_refs], status

@@ -26,12 +26,13 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     t = g.last_timing()
     prof = g.profile_classes(d_in, d_out, d_st)
     nw = max(1, (B + tw - 1) // tw // 64 + (1 if ((B + tw - 1) // tw) % 64 else 0))
-    probe = prof.pop("_probe")
-    if probe[3]:
-        print("   load-latency probes (cycles): constant line %.0f, just-stored slot %.0f, record 40 bundles ahead %.0f" % tuple(x / probe[3] for x in probe[:3]))
+    sections = prof.pop("_sections")
     tot = sum(v[0] for v in prof.values())
     print("T=%d B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw, B, t["interp_ms"], nw, tot / nw))
-    for k, (cyc, cyc_f, n_f, n) in prof.items():
+    for k, (cyc, _a, _b, n) in prof.items():
         if n:
-            print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  (forwarded: %6d bundles/wave at %8.0f; others at %8.0f)  share %.1f%%" % (
-                k, n // nw, cyc / n, n_f // nw, cyc_f / max(n_f, 1), (cyc - cyc_f) / max(n - n_f, 1), 100.0 * cyc / tot))
+            print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  share %.1f%%" % (k, n // nw, cyc / n, 100.0 * cyc / tot))
+    for k, v in sections.items():
+        if v[5]:
+            print("   %s sections (cycles/bundle, each includes one ~40-cycle stamp): top+vmcnt wait %.0f | LDS reads %.0f | staging issue %.0f | arithmetic %.0f | stores+ring %.0f" % (
+                (k,) + tuple(x / v[5] for x in v[:5])))
