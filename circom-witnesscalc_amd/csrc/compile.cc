@@ -1,5 +1,6 @@
 // Host graph compiler: validation, level scheduling into same-class bundles, liveness-based slot
 // allocation, program encoding.  See program.hpp.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -69,6 +70,144 @@ static void rewrite_pow2_divisions(Graph& g) {
     }
 }
 
+// Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
+// of the scheduler's critical-path heights and of the tree-height reduction below.
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 120, 110, 800, 38};
+
+// Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
+// chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
+// chain's leaves in any order.  A wave's time is the sum of its bundles and the bundle count follows the longest
+// dependency chain, so every node whose own chain is its critical input is rebuilt as a tree over the leaves, cheapest
+// and earliest-ready first: sum chains of n terms drop from n-1 to ceil(log2 n) levels, and a constant factor is folded
+// into the early part of a product (M_ji * x^5 becomes (M_ji * x) * x^4, one multiplication level less per Poseidon
+// round).  The intermediate nodes of the chain are still computed wherever something else (a witness element, another
+// node) needs them; common subexpressions are shared; nodes that end up unused are dropped.
+// Only Add/Mul nodes are touched, so every operation that can fail (graph.rs:634, :686-716) survives unchanged.
+static void reduce_tree_height(Graph& g) {
+    const size_t N = g.nodes.size();
+    const size_t kMaxLeaves = 8;
+    Graph h;
+    h.const_values = g.const_values;
+    std::vector<uint32_t> m(N, 0xffffffffu);  // old index -> new index
+    std::vector<uint64_t> rt;                 // earliest finish time of each new node (unbounded width)
+    rt.reserve(N + N / 4);
+    h.nodes.reserve(N + N / 4);
+    struct KeyHash {
+        size_t operator()(const uint64_t& k) const { return (size_t)(k * 0x9E3779B97F4A7C15ull >> 16); }
+    };
+    std::unordered_map<uint64_t, uint32_t, KeyHash> vn[2];  // value numbering of Add (0) / Mul (1) nodes by operand pair
+    auto emit = [&](const Node& n, uint64_t t) -> uint32_t {
+        h.nodes.push_back(n);
+        rt.push_back(t);
+        return (uint32_t)(h.nodes.size() - 1);
+    };
+    for (size_t i = 0; i < N; ++i)  // constants first (rewrite_pow2_divisions appends some behind their users)
+        if (g.nodes[i].kind == N_CONST) m[i] = emit(g.nodes[i], 0);
+    auto is_ac = [&](uint32_t idx, uint8_t op) { return h.nodes[idx].kind == N_DUO && h.nodes[idx].op == op; };
+    auto combine = [&](uint8_t op, uint32_t x, uint32_t y) -> uint32_t {  // shared (op, x, y) node
+        if (x > y) std::swap(x, y);
+        const uint64_t key = ((uint64_t)x << 32) | y;
+        auto& table = vn[op == OP_MUL];
+        auto it = table.find(key);
+        if (it != table.end()) return it->second;
+        const uint64_t cost = kClassCost[op == OP_MUL ? C_MUL : C_LIN];
+        const uint32_t idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
+        table.emplace(key, idx);
+        return idx;
+    };
+    std::vector<uint32_t> leaves;
+    std::vector<std::pair<uint64_t, uint32_t>> work;
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        Node c = n;
+        const int ar = arity_of(n);
+        if (ar >= 1) c.a = m[n.a];
+        if (ar >= 2) c.b = m[n.b];
+        if (ar >= 3) c.c = m[n.c];
+        if (!(n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_MUL))) {
+            uint64_t t = 0;
+            if (ar >= 1) t = rt[c.a];
+            if (ar >= 2) t = std::max(t, rt[c.b]);
+            if (ar >= 3) t = std::max(t, rt[c.c]);
+            m[i] = emit(c, t + kClassCost[class_of(n)]);
+            continue;
+        }
+        const uint64_t cost = kClassCost[n.op == OP_MUL ? C_MUL : C_LIN];
+        const uint64_t direct = std::max(rt[c.a], rt[c.b]) + cost;
+        // flatten: keep opening the latest-ready leaf while it is a node of the same operation
+        leaves.clear();
+        leaves.push_back(c.a);
+        leaves.push_back(c.b);
+        bool opened = false;
+        while (leaves.size() < kMaxLeaves) {
+            size_t worst = 0;
+            for (size_t q = 1; q < leaves.size(); ++q)
+                if (rt[leaves[q]] > rt[leaves[worst]]) worst = q;
+            const uint32_t L = leaves[worst];
+            if (!is_ac(L, n.op)) break;
+            leaves[worst] = h.nodes[L].a;
+            leaves.push_back(h.nodes[L].b);
+            opened = true;
+        }
+        uint32_t result = 0xffffffffu;
+        if (opened) {
+            // would the rebuilt tree finish earlier?  (computed on times only, nothing is emitted yet)
+            work.clear();
+            for (uint32_t L : leaves) work.emplace_back(rt[L], L);
+            std::sort(work.begin(), work.end());
+            std::vector<uint64_t> times;
+            for (auto& w : work) times.push_back(w.first);
+            while (times.size() > 1) {  // combine the two earliest
+                const uint64_t t = std::max(times[0], times[1]) + cost;
+                times.erase(times.begin(), times.begin() + 2);
+                times.insert(std::lower_bound(times.begin(), times.end(), t), t);
+            }
+            if (times[0] < direct) {
+                while (work.size() > 1) {
+                    const uint32_t idx = combine(n.op, work[0].second, work[1].second);
+                    work.erase(work.begin(), work.begin() + 2);
+                    const std::pair<uint64_t, uint32_t> e(rt[idx], idx);
+                    work.insert(std::lower_bound(work.begin(), work.end(), e), e);
+                }
+                result = work[0].second;
+            }
+        }
+        m[i] = result != 0xffffffffu ? result : combine(n.op, c.a, c.b);
+    }
+    // drop what nothing needs any more: roots are the witness elements and every node that is not a plain Add/Mul
+    const size_t M = h.nodes.size();
+    std::vector<uint8_t> live(M, 0);
+    for (uint32_t w : g.witness_signals) live[m[w]] = 1;
+    for (size_t i = 0; i < M; ++i) {
+        const Node& n = h.nodes[i];
+        if (n.kind != N_CONST && !(n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_MUL))) live[i] = 1;
+    }
+    for (size_t i = M; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& n = h.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) live[n.a] = 1;
+        if (ar >= 2) live[n.b] = 1;
+        if (ar >= 3) live[n.c] = 1;
+    }
+    std::vector<uint32_t> pos(M, 0xffffffffu);
+    std::vector<Node> kept;
+    kept.reserve(M);
+    for (size_t i = 0; i < M; ++i) {
+        if (!live[i]) continue;
+        Node n = h.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[m[w]];
+    g.nodes.swap(kept);
+}
+
 bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& err) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
@@ -89,7 +228,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     }
     Graph g = g_in;
     rewrite_pow2_divisions(g);
-    const size_t N = g.nodes.size();
+    size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
     out = Program();
     out.T = T;
@@ -119,24 +258,12 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
             st.n_input_nodes++;
         }
     }
-    for (uint32_t w : g.witness_signals)
+    for (uint32_t w : g_in.witness_signals)
         if (w >= g_in.nodes.size()) {
             err = "witness signal references node " + std::to_string(w) + " beyond the graph";
             return false;
         }
     st.algorithmic_bytes_per_set = 32ull * (arity_sum + 2 * st.n_input_nodes + 2 * st.n_witness);
-
-    // ---- constants -> table (Montgomery form), node -> ref ----
-    std::vector<uint32_t> ref(N, 0);  // for consts: REF_CONST|idx ; for others: slot (filled later)
-    for (size_t i = 0; i < N; ++i)
-        if (g.nodes[i].kind == N_CONST) {
-            Fr m = fr_to_mont(g.const_values[g.nodes[i].a]);
-            ref[i] = REF_CONST | (uint32_t)(out.consts.size() / 8);
-            out.consts.insert(out.consts.end(), m.v, m.v + 8);
-        }
-    st.n_const = out.consts.size() / 8;
-    out.consts.insert(out.consts.end(), 8, 0u);  // trailing dummy entry: the table is never empty (prefetch target)
-    out.n_const = (uint32_t)(out.consts.size() / 8);
 
     // ---- levels ----
     std::vector<uint32_t> level(N, 0);
@@ -152,6 +279,25 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
         depth = std::max(depth, l + 1);
     }
     st.depth = depth;
+
+    // ---- exact depth-reducing rewrite (the statistics above describe the graph as loaded) ----
+    if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
+        reduce_tree_height(g);
+        N = g.nodes.size();
+    }
+    for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
+
+    // ---- constants -> table (Montgomery form), node -> ref ----
+    std::vector<uint32_t> ref(N, 0);  // for consts: REF_CONST|idx ; for others: slot (filled later)
+    for (size_t i = 0; i < N; ++i)
+        if (g.nodes[i].kind == N_CONST) {
+            Fr m = fr_to_mont(g.const_values[g.nodes[i].a]);
+            ref[i] = REF_CONST | (uint32_t)(out.consts.size() / 8);
+            out.consts.insert(out.consts.end(), m.v, m.v + 8);
+        }
+    st.n_const = out.consts.size() / 8;
+    out.consts.insert(out.consts.end(), 8, 0u);  // trailing dummy entry: the table is never empty (prefetch target)
+    out.n_const = (uint32_t)(out.consts.size() / 8);
 
     // ---- schedule: order of evaluated nodes (inputs + ops) and bundle boundaries ----
     // G == 1: file order (the reference's own loop order; best locality, every bundle is one node anyway).
@@ -172,8 +318,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 order.push_back((uint32_t)i);
             }
     } else {
-        // approximate lane-instruction cost of one bundle of each class (measured on gfx950, relative)
-        static const uint32_t class_cost[C_COUNT] = {8, 9, 3, 270, 4, 8, 14, 60, 4};
+        const uint32_t* class_cost = kClassCost;
         std::vector<uint64_t> height(N, 0);
         std::vector<uint32_t> n_users_left;  // unused placeholder to keep vectors grouped
         std::vector<uint32_t> indeg(N, 0);
@@ -201,6 +346,21 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
             for (uint32_t u : users[i]) h = std::max(h, height[u]);
             height[i] = h + class_cost[class_of(g.nodes[i])];
         }
+        // operations between a node and the nearest division that depends on it (saturating)
+        static const uint32_t kFar = 0xffffu;
+        uint32_t div_wait_ops = 6;
+        if (const char* e = getenv("CWC_SCHED_DIV_WAIT")) div_wait_ops = (uint32_t)atoi(e);
+        std::vector<uint16_t> dist_to_div(N, (uint16_t)kFar);
+        for (size_t i = N; i-- > 0;) {
+            if (g.nodes[i].kind == N_CONST) continue;
+            if (class_of(g.nodes[i]) == C_DIV) {
+                dist_to_div[i] = 0;
+                continue;
+            }
+            uint32_t d = kFar;
+            for (uint32_t u : users[i]) d = std::min<uint32_t>(d, dist_to_div[u] + 1u);
+            dist_to_div[i] = (uint16_t)std::min<uint32_t>(d, kFar);
+        }
         // ready heaps per class, keyed by (height, -index)
         typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
         std::vector<std::vector<Key>> heap(C_COUNT);
@@ -221,6 +381,21 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
             if (best < 0) {
                 err = "internal error: scheduler found no ready node";
                 return false;
+            }
+            // An inversion bundle costs about thirty multiplication bundles however few of its lanes are used, and a
+            // wave's time is the sum of its bundles: a ready division waits while another chain is within a few
+            // operations of its own division (its ready node goes first), so that sibling chains divide together.
+            if (best == C_DIV) {
+                int other = -1;
+                for (int c = 0; c < (int)C_COUNT; ++c) {
+                    if (c == C_DIV || heap[c].empty()) continue;
+                    // the heap top is the class's most urgent node; scan the ready nodes of the class for one that
+                    // is about to reach a division
+                    bool near = false;
+                    for (const Key& k : heap[c]) near |= dist_to_div[~k.second] <= div_wait_ops;
+                    if (near && (other < 0 || heap[c].front() > heap[other].front())) other = c;
+                }
+                if (other >= 0) best = other;
             }
             // INPUT nodes first whenever any is ready (they have no producers and feed everything)
             if (!heap[C_INPUT].empty()) best = C_INPUT;
@@ -377,7 +552,11 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 if (needs_slot[o] == 1 && last_mem_use[o] == b) dying.push_back(o);
             }
         }
-        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT);
+        uint32_t lin_bits = 0;
+        if (cl == C_LIN)
+            for (uint32_t k = k0; k < k1; ++k)
+                lin_bits |= (ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK) == SUB_SUB ? HDR_LIN_SUB : HDR_LIN_ADD;
+        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits;
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);

@@ -116,6 +116,26 @@ FRD Fr fr_sub(const Fr& a, const Fr& b) {
     u256_add(t, d, fr_p());
     return u256_select(br != 0, t, d);
 }
+#if defined(__HIPCC__)
+// Interpreter versions of fr_add / fr_sub: the two carry chains (sum and correction) interleaved limb by limb in
+// inline assembly, so that a lone wavefront never waits on a carry; pv = the modulus held in VGPRs by the caller.
+__device__ __forceinline__ Fr fr_add_wave(const Fr& a, const Fr& b, const Fr& pv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_add_gfx950.inc"
+#else
+    (void)pv;
+    return fr_add(a, b);
+#endif
+}
+__device__ __forceinline__ Fr fr_sub_wave(const Fr& a, const Fr& b, const Fr& pv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_sub_gfx950.inc"
+#else
+    (void)pv;
+    return fr_sub(a, b);
+#endif
+}
+#endif
 // reference src/graph.rs:188-194: 0 -> 0, else r - a   (identical in Montgomery form)
 FRD Fr fr_neg(const Fr& a) {
     Fr t;

@@ -107,6 +107,9 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         dma16(s + 3 * LDS_HALF_BYTES, bo, rsrc_w, HI);
     };
     uint32_t err_bits = 0;
+    Fr pv = fr_p();  // the modulus in VGPRs for fr_add_wave / fr_sub_wave
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pv.v[i]));
     unsigned long long pf[C_COUNT][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
     if (PROF) {
 #pragma unroll
@@ -155,11 +158,15 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
         if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul(a_op, b_op);
         } else if (__builtin_expect(cls == C_LIN, 1)) {
-            // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a.  Branch-free: a + (+-b) with -b = r - b
-            // (b = 0 gives a + r, folded by the conditional subtraction of fr_add).
-            Fr nb;
-            u256_sub(nb, fr_p(), b_op);
-            r = fr_add(a_op, u256_select(sub == SUB_ADD, b_op, nb));
+            // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
+            // uniform (header bits); a mixed one computes both and selects per lane.
+            if (!(h & HDR_LIN_SUB)) {
+                r = fr_add_wave(a_op, b_op, pv);
+            } else if (!(h & HDR_LIN_ADD)) {
+                r = fr_sub_wave(a_op, b_op, pv);
+            } else {
+                r = u256_select(sub == SUB_ADD, fr_add_wave(a_op, b_op, pv), fr_sub_wave(a_op, b_op, pv));
+            }
         } else
         switch (cls) {
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])

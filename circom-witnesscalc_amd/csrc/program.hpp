@@ -21,6 +21,7 @@ struct ProgramStats {
     uint64_t depth = 0;                 // dependency levels
     uint64_t class_nodes[C_COUNT] = {0};
     uint64_t class_bundles[C_COUNT] = {0};
+    uint64_t n_op_compiled = 0;         // operation nodes after the depth-reducing rewrite (>= n_op is possible)
     uint64_t algorithmic_bytes_per_set = 0;  // 32*[sum_ops(arity+1) + 2*n_input_nodes + 2*W]  
 };
 

@@ -16,7 +16,7 @@ namespace cwc {
 enum BundleClass : uint32_t {
     C_INPUT = 0,    // dst = to_mont(inputs[set][a])                       graph.rs:376
     C_MUL = 1,      // graph.rs:105
-    C_LIN = 2,      // Add / Sub / Neg                                     graph.rs:110-111, 188-194
+    C_LIN = 2,      // Add / Sub / Neg (as 0 - a)                          graph.rs:110-111, 188-194
     C_DIV = 3,      // graph.rs:109
     C_CMPZ = 4,     // Eq / Neq / Land / Lor (no representation change)    graph.rs:122-129, 134-135
     C_CMPS = 5,     // Lt / Gt / Leq / Geq (signed compare on canonical)   graph.rs:130-133, 720-769
@@ -29,7 +29,8 @@ enum BundleClass : uint32_t {
 // Program format v4 -- every operand of a bundle is read from the wave's LDS at a host-computed address, and the
 // interpreter spends no vector instruction on decoding or address arithmetic beyond adding the lane's 16*t.
 //
-// hdr[bundle] (wave-uniform, fetched with scalar loads): bits 0-3 class | bits 4-10 node count
+// hdr[bundle] (wave-uniform, fetched with scalar loads): bits 0-3 class | bits 4-10 node count |
+//   C_LIN only: bit 11 some lane subtracts, bit 12 some lane adds (uniform bundles take a shorter path)
 //
 // LDS of a wave (one wave per workgroup), byte addresses:
 //   RING   [LDS_RING_OFF  + (bundle mod RING_BUNDLES) * 2 KiB]  results of the last RING_BUNDLES bundles,
@@ -50,6 +51,7 @@ enum BundleClass : uint32_t {
 //                           INPUT bundles: index into the set's input row.
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
+static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
 static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
 static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;

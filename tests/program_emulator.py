@@ -18,7 +18,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Mul"], "DIV": ["Div"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<10I25Q"
+HDR_FMT = "<10I26Q"
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN"]
 
@@ -30,7 +30,7 @@ class Blob:
          self.n_witness, _res) = h[:10]
         st = h[10:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:15], class_bundles=st[15:24], algorithmic_bytes_per_set=st[24])
+                          class_nodes=st[6:15], class_bundles=st[15:24], n_op_compiled=st[24], algorithmic_bytes_per_set=st[25])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -78,10 +78,11 @@ def run(blob: Blob, inputs_row):
     for b in range(blob.n_bundles):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
-        assert h >> 11 == 0 and 1 <= cnt <= G
+        assert h >> 13 == 0 and 1 <= cnt <= G
         name = CLASS_NAMES[cls]
         stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
+        lin_seen = 0
         for j in range(G):
             a_off, b_off, dctl, lds = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
             ctrl, dst = dctl & CTRL_MASK, dctl & ~CTRL_MASK
@@ -108,12 +109,15 @@ def run(blob: Blob, inputs_row):
                 v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
             else:
                 op = SUB_NAMES[name][sub]
+                if name == "LIN":
+                    lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
                 try:
                     v = model.eval_duo(op, ops[0], ops[1])
                 except model.ReferencePanic:
                     status |= 1 if op == "Shl" else 2
                     v = 0
             results.append((dst, v))
+        assert (h >> 11) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
         for d, v in results:
