@@ -30,7 +30,8 @@ class GraphInfo(ctypes.Structure):
 
 class Timing(ctypes.Structure):
     _fields_ = [("tile_width", ctypes.c_uint32), ("n_launches", ctypes.c_uint32), ("n_bundles", ctypes.c_uint64),
-                ("n_slots", ctypes.c_uint64), ("interp_ms", ctypes.c_float), ("pack_ms", ctypes.c_float)]
+                ("n_slots", ctypes.c_uint64), ("interp_ms", ctypes.c_float), ("pack_ms", ctypes.c_float),
+                ("divider", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class WitnessCalcError(RuntimeError):
@@ -274,9 +275,9 @@ class Graph:
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),
                                        d_status.data_ptr(), out.ctypes.data, ctypes.byref(st))
         _check(rc, st)
-        names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN"]
+        names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET"]
         res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
-        res["_sections"] = {"MUL": tuple(int(x) for x in out[40:46]), "LIN": tuple(int(x) for x in out[48:54])}
+        res["_sections"] = {"MUL": tuple(int(x) for x in out[48:54]), "LIN": tuple(int(x) for x in out[56:62])}
         return res
 
     def last_timing(self):

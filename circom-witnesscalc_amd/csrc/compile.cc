@@ -72,7 +72,7 @@ static void rewrite_pow2_divisions(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 120, 110, 800, 38};
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 120, 110, 800, 38, 22, 22};
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -208,7 +208,7 @@ static void reduce_tree_height(Graph& g) {
     g.nodes.swap(kept);
 }
 
-bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& err) {
+bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, std::string& err) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
@@ -230,9 +230,11 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     rewrite_pow2_divisions(g);
     size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
+    if (G == 1) divider = false;  // T = 64 keeps the reference's node order, one node per bundle
     out = Program();
     out.T = T;
     out.G = G;
+    out.divider = divider ? 1u : 0u;
     ProgramStats& st = out.stats;
     st.n_nodes = g_in.nodes.size();
     st.n_witness = g.witness_signals.size();
@@ -308,12 +310,15 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     // of costing one bundle per (level, class).
     std::vector<uint32_t> order;
     order.reserve(N);
-    std::vector<uint32_t> bundle_of(N, 0xffffffffu);
+    std::vector<uint32_t> bundle_of(N, 0xffffffffu);      // bundle that produces the node's value
+    std::vector<uint32_t> use_bundle_of(N, 0xffffffffu);  // bundle that reads the node's operands (differs for a
+                                                          // division handed to the divider wave: request vs. collect)
     std::vector<uint32_t> bundle_start;  // index into order
+    static const uint32_t REQ_FLAG = 0x80000000u;         // order[] entry: the request half of a division
     if (G == 1) {
         for (size_t i = 0; i < N; ++i)
             if (g.nodes[i].kind != N_CONST) {
-                bundle_of[i] = (uint32_t)bundle_start.size();
+                bundle_of[i] = use_bundle_of[i] = (uint32_t)bundle_start.size();
                 bundle_start.push_back((uint32_t)order.size());
                 order.push_back((uint32_t)i);
             }
@@ -374,10 +379,52 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
         std::vector<uint32_t> picked;
         size_t remaining = 0;
         for (size_t i = 0; i < N; ++i) remaining += g.nodes[i].kind != N_CONST;
+        // Asynchronous divider: a division bundle is split into a request (operands to the divider wave) and, about
+        // one inversion later on the scheduler's clock, a collect bundle with the same nodes in the same node slots;
+        // the interpreter runs other ready work in between.  One request is in flight at a time.
+        uint64_t clock = 0;
+        std::vector<uint32_t> in_flight;  // nodes of the pending request
+        uint64_t in_flight_ready = 0;
+        auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect) {
+            const uint32_t b = (uint32_t)bundle_start.size();
+            bundle_start.push_back((uint32_t)order.size());
+            for (uint32_t i : nodes) {
+                if (request) {
+                    use_bundle_of[i] = b;
+                    order.push_back(i | REQ_FLAG);
+                } else {
+                    bundle_of[i] = b;
+                    if (!collect) use_bundle_of[i] = b;
+                    order.push_back(i);
+                }
+            }
+            if (request) return;
+            remaining -= nodes.size();
+            for (uint32_t i : nodes)  // release users only now: a bundle never reads its own results
+                for (uint32_t u : users[i])
+                    if (--indeg[u] == 0) push(u);
+        };
         while (remaining) {
             int best = -1;
             for (int c = 0; c < (int)C_COUNT; ++c)
                 if (!heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
+            if (!in_flight.empty()) {
+                // collect when the quotients are due, or when nothing else can run (the interpreter then waits)
+                bool other_ready = false;
+                for (int c = 0; c < (int)C_COUNT; ++c) other_ready |= c != C_DIV && !heap[c].empty();
+                if (clock >= in_flight_ready || !other_ready) {
+                    emit_bundle(in_flight, false, true);
+                    in_flight.clear();
+                    out.n_div_requests++;
+                    clock += class_cost[C_LIN];
+                    continue;
+                }
+                if (best == C_DIV) {  // a second request has to wait for the first one: run the best other class
+                    best = -1;
+                    for (int c = 0; c < (int)C_COUNT; ++c)
+                        if (c != C_DIV && !heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
+                }
+            }
             if (best < 0) {
                 err = "internal error: scheduler found no ready node";
                 return false;
@@ -407,16 +454,15 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 h.pop_back();
             }
             std::sort(picked.begin(), picked.end());
-            const uint32_t b = (uint32_t)bundle_start.size();
-            bundle_start.push_back((uint32_t)order.size());
-            for (uint32_t i : picked) {
-                bundle_of[i] = b;
-                order.push_back(i);
+            if (best == C_DIV && divider) {
+                emit_bundle(picked, true, false);
+                in_flight = picked;
+                clock += class_cost[C_LIN];
+                in_flight_ready = clock + class_cost[C_DIV];
+            } else {
+                emit_bundle(picked, false, false);
+                clock += class_cost[best];
             }
-            remaining -= picked.size();
-            for (uint32_t i : picked)  // release users only now: a bundle never reads its own results
-                for (uint32_t u : users[i])
-                    if (--indeg[u] == 0) push(u);
         }
     }
     const uint32_t NB = (uint32_t)bundle_start.size();
@@ -433,18 +479,23 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     static_assert(RING_BUNDLES >= OPND_AHEAD, "values younger than the staging distance must come from the ring");
     std::vector<uint32_t> pos_in_bundle(N, 0);
     for (uint32_t b = 0; b < NB; ++b)
-        for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k]] = k - bundle_start[b];
+        for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k] & ~REQ_FLAG] = k - bundle_start[b];
     enum { SRC_MEM = 0, SRC_RING = 1 };
     auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
         if (q >= 2 || g.nodes[producer].kind == N_CONST) return SRC_MEM;
-        const uint32_t d = bundle_of[consumer] - bundle_of[producer];
+        const uint32_t d = use_bundle_of[consumer] - bundle_of[producer];
         return (d >= 1 && d <= RING_BUNDLES) ? SRC_RING : SRC_MEM;
     };
     std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
     std::vector<uint8_t> needs_slot(N, 0);
     for (uint32_t w : g.witness_signals)
         if (g.nodes[w].kind != N_CONST) needs_slot[w] = 2;  // pinned
-    for (uint32_t i : order) {
+    auto is_collect = [&](uint32_t entry) {  // the collect half of a division served by the divider wave: no operands
+        return divider && !(entry & REQ_FLAG) && class_of(g.nodes[entry]) == C_DIV;
+    };
+    for (uint32_t e : order) {
+        if (is_collect(e)) continue;
+        const uint32_t i = e & ~REQ_FLAG;
         const Node& n = g.nodes[i];
         // Neg is encoded as 0 - a: its operand travels in the b position
         const uint32_t ops[3] = {n.a, n.b, n.c};
@@ -452,7 +503,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
             const uint32_t o = ops[q];
             if (g.nodes[o].kind == N_CONST || route(o, i, q) != SRC_MEM) continue;
             if (!needs_slot[o]) needs_slot[o] = 1;
-            last_mem_use[o] = std::max(last_mem_use[o], bundle_of[i]);
+            last_mem_use[o] = std::max(last_mem_use[o], use_bundle_of[i]);
         }
     }
 
@@ -486,17 +537,18 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
     std::vector<uint8_t> ctrl_of((size_t)NB * G, 0);
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
-        const int cl = class_of(g.nodes[order[k0]]);
+        const bool request = (order[k0] & REQ_FLAG) != 0, collect = is_collect(order[k0]);
+        const int cl = request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : class_of(g.nodes[order[k0]]);
         st.class_bundles[cl]++;
         st.class_nodes[cl] += cnt;
         dying.clear();
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         for (uint32_t k = k0; k < k1; ++k) {
-            const uint32_t i = order[k];
+            const uint32_t i = order[k] & ~REQ_FLAG;
             const Node& n = g.nodes[i];
             const uint32_t js = k - k0;  // node slot
             uint32_t slot = 0xffffffffu;
-            if (needs_slot[i]) {
+            if (needs_slot[i] && !request) {
                 if (!free_slots.empty()) {
                     slot = free_slots.back();
                     free_slots.pop_back();
@@ -504,7 +556,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                     slot = n_slots++;
                 }
             }
-            ref[i] = slot;  // 0xffffffff: no slot (every use comes from the ring)
+            if (!request) ref[i] = slot;  // 0xffffffff: no slot (every use comes from the ring)
             uint32_t* r = &out.recs[((size_t)b * G + js) * 4];
             r[2] = slot;
             // default: both operands unused -> staging loads of the zero constant, LDS reads of the own stage cells
@@ -519,6 +571,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
                 }
             };
             uint32_t ctrl = CTRL_ACTIVE;
+            if (!collect)
             switch (n.kind) {
                 case N_INPUT:
                     if (n.a >= n_in_buf) {
@@ -547,7 +600,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
             r[3] = lds[0] | (lds[1] << 16);
             ctrl_of[(size_t)b * G + js] = (uint8_t)ctrl;
             const uint32_t ops[3] = {n.a, n.b, n.c};
-            for (int q = 0; q < arity_of(n); ++q) {
+            for (int q = 0; q < (collect ? 0 : arity_of(n)); ++q) {
                 uint32_t o = ops[q];
                 if (needs_slot[o] == 1 && last_mem_use[o] == b) dying.push_back(o);
             }
@@ -595,7 +648,7 @@ bool compile_program(const Graph& g_in, uint32_t T, Program& out, std::string& e
 // ---- blob ----------------------------------------------------------------------------------------
 static const uint32_t kBlobMagic = 0x47505743u;  // "CWPG"
 struct BlobHeader {
-    uint32_t magic, version, T, G, n_bundles, n_slots, n_const, n_inputs, n_witness, reserved;
+    uint32_t magic, version, T, G, n_bundles, n_slots, n_const, n_inputs, n_witness, divider, n_div_requests, reserved;
     ProgramStats stats;
 };
 
@@ -603,9 +656,10 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 4;
+    h.version = 5;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
+    h.divider = p.divider; h.n_div_requests = p.n_div_requests;
     h.stats = p.stats;
     std::vector<uint8_t> out((uint8_t*)&h, (uint8_t*)&h + sizeof h);
     auto put = [&](const std::vector<uint32_t>& v) { out.insert(out.end(), (const uint8_t*)v.data(), (const uint8_t*)(v.data() + v.size())); };
@@ -617,10 +671,11 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 4 || h.T == 0 || h.T > 64 || h.G != 64 / h.T) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 5 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || h.divider > 1) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;
+    p.divider = h.divider; p.n_div_requests = h.n_div_requests;
     const size_t n_hdr = p.n_bundles, n_recs = (size_t)p.n_bundles * p.G * 4, n_c = (size_t)p.n_bundles * p.G,
                  n_k = (size_t)p.n_const * 8, n_w = p.n_witness;
     if (len != sizeof h + 4 * (n_hdr + n_recs + n_c + n_k + n_w)) { err = "program blob size mismatch"; return false; }

@@ -30,13 +30,24 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // PROF = true is a diagnostic build (gwb_profile_classes): one s_memtime per bundle, summed per bundle class by
 // lane 0 of every 64th tile (prof[class*4 + {0: cycles, 3: bundles}]), and for MUL and LIN bundles five sections of
-// the iteration (prof[40 + 8*{MUL, LIN} + section]).  No stamp executes in the product kernel.
+// the iteration (prof[48 + 8*{MUL, LIN} + section]).  No stamp executes in the product kernel.
 //
 // The program arrays are separate `const __restrict__` kernel arguments (not a by-value struct) so that hipcc can
 // prove them read-only: the wave-uniform header stream then becomes scalar loads (s_load).
 struct InterpDims {
-    uint32_t n_bundles, n_slots, n_inputs, batch, n_const;
+    uint32_t n_bundles, n_slots, n_inputs, batch, n_const, n_div_requests;
 };
+static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox wait gave up (never expected)
+
+// Mailbox wait of the asynchronous divider protocol: sleeps until the sequence word reaches `need`.  Bounded, so that
+// a protocol bug ends the kernel with an error status instead of hanging the device.
+__device__ __forceinline__ bool mbox_wait(const volatile uint32_t* seq, uint32_t need) {
+    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+        if (*seq >= need) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
@@ -53,15 +64,15 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t byte
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
-template <int T, bool PROF>
-__global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
+template <int T, bool PROF, bool DIVIDER>
+__global__ __launch_bounds__(DIVIDER ? 128 : 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
                                                     const uint32_t* __restrict__ crefs, InterpDims p, WsTable wst,
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
     constexpr uint32_t HI = 16u * T;  // byte distance between the two 16-byte halves of a value in a slot
     const uint32_t batch = p.batch;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t = lane % T;
     const uint32_t j = (G == 1) ? 0u : lane / T;
     const uint32_t tile = blockIdx.x;
@@ -74,10 +85,41 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
     const i32x4 rsrc_w = make_rsrc_words(tile_base, (uint32_t)tile_bytes);
     const i32x4 rsrc_rec = make_rsrc_words(recs, p.n_bundles * (uint32_t)G * 16u);
-    __shared__ uint4 lds[LDS_BYTES / 16];  // the only LDS object of the kernel: host-computed addresses are offsets into it
+    __shared__ uint4 lds[(LDS_BYTES + (DIVIDER ? MBOX_BYTES : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into it
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)(char*)lds;
     const uint32_t t16 = 16u * t, lane16 = 16u * lane, j16 = 16u * j;
     char* const ldsb = reinterpret_cast<char*>(lds);
+    char* const mbox = ldsb + LDS_BYTES;
+    if (DIVIDER) {
+        if (threadIdx.x == 0) {  // sequence words start at zero
+            reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF)[0] = 0;
+            reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF)[1] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64u) {
+            // ---- divider wave: serves the interpreter's division requests in order (graph.rs:109: b == 0 -> 0) ----
+            volatile uint32_t* seq = reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF);
+            for (uint32_t k = 0; k < p.n_div_requests; ++k) {
+                if (!mbox_wait(seq + 0, k + 1)) {
+                    if (set < batch) atomicOr(&status[set], ST_DIVIDER_TIMEOUT);
+                    break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint4* qa = reinterpret_cast<const uint4*>(mbox + MBOX_A_OFF + 16u * lane);
+                const uint4* qb = reinterpret_cast<const uint4*>(mbox + MBOX_B_OFF + 16u * lane);
+                const Fr a = fr_from_u4(qa[0], qa[LDS_HALF_BYTES / 16]), b = fr_from_u4(qb[0], qb[LDS_HALF_BYTES / 16]);
+                const Fr inv = fr_inv(b);  // safegcd divsteps; inv(0) = 0
+                const Fr r = u256_select(u256_is_zero(b), fr_zero(), fr_mul(a, inv));
+                uint4* qr = reinterpret_cast<uint4*>(mbox + MBOX_R_OFF + 16u * lane);
+                qr[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                qr[LDS_HALF_BYTES / 16] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) seq[1] = k + 1;
+            }
+            return;
+        }
+    }
+    uint32_t div_seq = 0;  // requests posted / collected so far (interpreter wave)
 
     auto ld = [&](uint32_t off) -> Fr {  // synchronous load of a slot (third operands only)
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
@@ -173,6 +215,31 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
                 const uint32_t idx = crefs[(size_t)b * G + j];
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + idx) * 2;
                 r = fr_to_mont(fr_from_u4(q[0], q[1]));
+                break;
+            }
+            case C_DIVREQ: {  // hand the operands to the divider wave; this bundle has no result of its own
+                if (DIVIDER) {
+                    uint4* qa = reinterpret_cast<uint4*>(mbox + MBOX_A_OFF + lane16);
+                    uint4* qb = reinterpret_cast<uint4*>(mbox + MBOX_B_OFF + lane16);
+                    qa[0] = make_uint4(a_op.v[0], a_op.v[1], a_op.v[2], a_op.v[3]);
+                    qa[LDS_HALF_BYTES / 16] = make_uint4(a_op.v[4], a_op.v[5], a_op.v[6], a_op.v[7]);
+                    qb[0] = make_uint4(b_op.v[0], b_op.v[1], b_op.v[2], b_op.v[3]);
+                    qb[LDS_HALF_BYTES / 16] = make_uint4(b_op.v[4], b_op.v[5], b_op.v[6], b_op.v[7]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF)[0] = div_seq + 1;
+                }
+                r = fr_zero();
+                break;
+            }
+            case C_DIVGET: {  // the quotients of the last request (same node slots)
+                r = fr_zero();
+                if (DIVIDER) {
+                    ++div_seq;
+                    if (!mbox_wait(reinterpret_cast<const volatile uint32_t*>(mbox + MBOX_SEQ_OFF) + 1, div_seq)) err_bits |= ST_DIVIDER_TIMEOUT;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint4* qr = reinterpret_cast<const uint4*>(mbox + MBOX_R_OFF + lane16);
+                    r = fr_from_u4(qr[0], qr[LDS_HALF_BYTES / 16]);
+                }
                 break;
             }
             case C_DIV: {  // graph.rs:109  b == 0 -> 0 else a / b
@@ -305,7 +372,7 @@ __global__ __launch_bounds__(64) void interp_kernel(const uint32_t* __restrict__
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) atomicAdd(&prof[40 + 8 * k + q], psec[k][q]);
+            for (int q = 0; q < 6; ++q) atomicAdd(&prof[48 + 8 * k + q], psec[k][q]);
     }
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }
@@ -349,23 +416,25 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
 }
 
 // ---- launchers (called from runtime.cc) -----------------------------------------------------------
-hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
-                         uint32_t batch, hipStream_t stream, unsigned long long* prof) {
+hipError_t launch_interp(uint32_t T, bool divider, uint32_t n_div_requests, const ProgramDev& p, const WsTable& wst, const void* inputs,
+                         uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
     const uint32_t tiles = (batch + T - 1) / T;
-    dim3 grid(tiles), block(64);
+    dim3 grid(tiles), block(divider ? 128 : 64);
     const uint4* in = (const uint4*)inputs;
-    const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const};
+    const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests};
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-#define CWC_LAUNCH(TT)                                                                                              \
-    case TT:                                                                                                        \
-        if (prof) interp_kernel<TT, true><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);    \
-        else interp_kernel<TT, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, nullptr);   \
+#define CWC_LAUNCH2(TT, PP, DD) interp_kernel<TT, PP, DD><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
+#define CWC_LAUNCH(TT)                                                  \
+    case TT:                                                            \
+        if (prof) { if (divider) CWC_LAUNCH2(TT, true, true); else CWC_LAUNCH2(TT, true, false); }       \
+        else { if (divider) CWC_LAUNCH2(TT, false, true); else CWC_LAUNCH2(TT, false, false); }          \
         break;
     switch (T) {
         CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32) CWC_LAUNCH(64)
         default: return hipErrorInvalidValue;
     }
 #undef CWC_LAUNCH
+#undef CWC_LAUNCH2
     return hipGetLastError();
 }
 

@@ -23,7 +23,10 @@ enum BundleClass : uint32_t {
     C_BIT = 6,      // Shl / Shr / Bor / Band / Bxor                       graph.rs:621-717
     C_IDIVMOD = 7,  // Idiv / Mod                                          graph.rs:112-121
     C_TERN = 8,     // TernCond                                            graph.rs:221-225
-    C_COUNT = 9
+    // programs compiled for the asynchronous divider (one extra wavefront per tile): a division is split into
+    C_DIVREQ = 9,   // ... handing the operands to the divider wave (no result), and
+    C_DIVGET = 10,  // ... collecting the quotients a while later (same node slots as the request)
+    C_COUNT = 11
 };
 
 // Program format v4 -- every operand of a bundle is read from the wave's LDS at a host-computed address, and the
@@ -55,6 +58,11 @@ static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
 static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
 static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;
+// Asynchronous divider (programs with Program::divider = 1): the workgroup is two wavefronts, the interpreter and a
+// divider.  Mailbox in LDS behind the interpreter's own area: operands a and b and the quotients as
+// [half][64 lanes][16 B] each, then two sequence words: requests posted (written by the interpreter), requests
+// served (written by the divider).  One request is in flight at a time (the compiler emits REQ k, GET k, REQ k+1, ...).
+static const uint32_t MBOX_A_OFF = 0, MBOX_B_OFF = 2048, MBOX_R_OFF = 4096, MBOX_SEQ_OFF = 6144, MBOX_BYTES = 6400;
 static const uint32_t LDS_RING_OFF = 0, LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES,
                       LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES, LDS_BYTES = LDS_REC_OFF + REC_AHEAD * REC_BYTES;
 // sub-ops inside a class (3 bits)

@@ -18,7 +18,7 @@
 #include "program.hpp"
 
 namespace cwc {
-hipError_t launch_interp(uint32_t T, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
+hipError_t launch_interp(uint32_t T, bool divider, uint32_t n_div_requests, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
                          uint32_t batch, hipStream_t stream, unsigned long long* prof);
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream);
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
@@ -142,10 +142,17 @@ extern "C" uint32_t gwb_pick_tile_width(size_t batch) {
         long v = atol(e);
         if (v > 0) target = (size_t)v;
     }
-    if (batch <= 512) return 1;
-    uint32_t t = 2;
-    while (t < 64 && batch / (t * 2) >= target) t *= 2;
-    return t;
+    uint32_t t = 1;
+    if (batch > 512) {
+        t = 2;
+        while (t < 64 && batch / (t * 2) >= target) t *= 2;
+    }
+    // Asynchronous divider wave (one extra wavefront per tile that serves the divisions while the interpreter goes
+    // on): pays while the extra waves find free SIMDs, i.e. up to about one interpreter wave per two SIMDs.
+    size_t divider_tiles = 640;
+    if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
+    const size_t tiles = (batch + t - 1) / t;
+    return t | (tiles <= divider_tiles ? KEY_DIVIDER : 0u);
 }
 
 namespace {
@@ -162,15 +169,17 @@ std::string check_device() {
 uint32_t pick_tile_width(const gwb_graph* g, size_t batch) {
     if (!g->has_graph && !g->progs.empty()) return g->progs.begin()->first;  // imported: the one program it has
     if (g->forced_T) return g->forced_T;
-    if (const char* e = getenv("CWC_TILE_WIDTH")) {
-        uint32_t t = (uint32_t)atoi(e);
-        if (t >= 1 && t <= 64 && !(t & (t - 1))) return t;
+    if (const char* e = getenv("CWC_TILE_WIDTH")) {  // width, or width + 256 for the asynchronous divider
+        const uint32_t key = (uint32_t)atoi(e), t = key & ~KEY_DIVIDER;
+        if (t >= 1 && t <= 64 && !(t & (t - 1))) return key;
     }
     return gwb_pick_tile_width(batch);
 }
 
-std::string get_program(gwb_graph* g, uint32_t T, DeviceProgram** out) {
-    auto it = g->progs.find(T);
+std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
+    const uint32_t T = key & ~KEY_DIVIDER;
+    if (T == 64) key = T;  // no divider programs at T = 64
+    auto it = g->progs.find(key);
     if (it != g->progs.end()) {
         *out = it->second.get();
         return "";
@@ -178,11 +187,11 @@ std::string get_program(gwb_graph* g, uint32_t T, DeviceProgram** out) {
     if (!g->has_graph) return "imported graph handle has no program for tile width " + std::to_string(T);
     std::unique_ptr<DeviceProgram> dp(new DeviceProgram());
     std::string err;
-    if (!compile_program(g->graph, T, dp->host, err)) return err;
+    if (!compile_program(g->graph, T, (key & KEY_DIVIDER) != 0, dp->host, err)) return err;
     err = upload_program(*dp);
     if (!err.empty()) return err;
     *out = dp.get();
-    g->progs[T] = std::move(dp);
+    g->progs[key] = std::move(dp);
     return "";
 }
 
@@ -190,11 +199,12 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
                        hipStream_t stream) {
     if (batch == 0) return "";
     if (batch > 0x7fffffffull) return "batch too large";
-    const uint32_t T = pick_tile_width(g, batch);
+    const uint32_t key = pick_tile_width(g, batch);
     DeviceProgram* dp = nullptr;
-    std::string err = get_program(g, T, &dp);
+    std::string err = get_program(g, key, &dp);
     if (!err.empty()) return err;
     const Program& p = dp->host;
+    const uint32_t T = p.T;
     // Workspace: tiles of (constants | value slots | trash slot), grouped into separately allocated chunks of at most
     // CWC_WORKSPACE_GB; larger batches than WS_MAX_CHUNKS chunks hold are evaluated in several launches.
     const uint64_t bytes_per_tile = ws_tile_bytes(p.n_const, p.n_slots, T);
@@ -240,6 +250,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     g->drop_events();
     g->timing = gwb_timing_t{};
     g->timing.tile_width = T;
+    g->timing.divider = p.divider;
     g->timing.n_bundles = p.n_bundles;
     g->timing.n_slots = p.n_slots;
     HIP_TRY(hipMemsetAsync(d_status, 0, batch * sizeof(uint32_t), stream));
@@ -256,7 +267,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
         HIP_TRY(hipEventRecord(e0, stream));
-        HIP_TRY(launch_interp(T, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
+        HIP_TRY(launch_interp(T, p.divider != 0, p.n_div_requests, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
         HIP_TRY(hipEventRecord(e2, stream));
@@ -294,6 +305,7 @@ std::string run_host(gwb_graph* g, const void* inputs, size_t batch, void* witne
 std::string set_status_text(uint32_t bits) {
     std::string s;
     if (bits & ST_SHL_OVERFLOW) s += "Shl result does not fit the field (reference panics at graph.rs:634)";
+    if (bits & 0x80000000u) s += std::string(s.empty() ? "" : "; ") + "internal error: divider mailbox wait timed out";
     if (bits & ST_BITOP_EQ_R) s += std::string(s.empty() ? "" : "; ") + "bit operation result equals the modulus (reference panics at graph.rs:686/701/716)";
     return s;
 }
@@ -322,7 +334,7 @@ int load_graph(const void* data, size_t len, gwb_graph** out, std::string& err) 
     g->has_graph = true;
     // validate by compiling the widest program's metadata (cheap) -- catches bad indices / Pow / Id early
     Program probe;
-    if (!compile_program(g->graph, 64, probe, err)) return 1;
+    if (!compile_program(g->graph, 64, false, probe, err)) return 1;
     g->stats = probe.stats;
     g->n_inputs = probe.n_inputs;
     g->n_witness = probe.n_witness;
@@ -446,9 +458,10 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
     return 0;
 }
 
-int gwb_set_tile_width(gwb_graph_t* g, uint32_t T) {
-    if (!g || T > 64 || (T & (T - 1))) return 1;
-    g->forced_T = T;
+int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
+    const uint32_t T = key & ~KEY_DIVIDER;
+    if (!g || T > 64 || (T & (T - 1)) || (key & KEY_DIVIDER && T == 0)) return 1;
+    g->forced_T = key;
     return 0;
 }
 
@@ -529,13 +542,14 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
     std::lock_guard<std::mutex> lk(g->mu);
     Program tmp;
     const Program* p = nullptr;
+    if ((T & ~KEY_DIVIDER) == 64) T = 64;
     auto it = g->progs.find(T);
     std::string err;
     if (it != g->progs.end()) {
         p = &it->second->host;
     } else {
         if (!g->has_graph) return fail(status, "imported handle has no program for that tile width");
-        if (!compile_program(g->graph, T, tmp, err)) return fail(status, err);
+        if (!compile_program(g->graph, T & ~KEY_DIVIDER, (T & KEY_DIVIDER) != 0, tmp, err)) return fail(status, err);
         p = &tmp;
     }
     std::vector<uint8_t> b = program_to_blob(*p);
@@ -597,7 +611,7 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     err = check_device();
     if (err.empty()) err = upload_program(*dp);
     if (!err.empty()) return fail(status, err);
-    const uint32_t T = dp->host.T;
+    const uint32_t T = dp->host.T | (dp->host.divider ? KEY_DIVIDER : 0u);
     g->progs[T] = std::move(dp);
     *out = g.release();
     set_status(status, OK, "");

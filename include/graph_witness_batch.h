@@ -41,6 +41,8 @@ typedef struct {
   uint64_t n_slots;          /* value slots per set */
   float interp_ms;           /* HIP-event time of the interpreter kernel(s), on the launch stream */
   float pack_ms;             /* HIP-event time of the witness pack kernel(s) */
+  uint32_t divider;          /* 1: the last call ran programs with the asynchronous divider wave */
+  uint32_t reserved;
 } gwb_timing_t;
 
 /* Parse + validate a `wtns.graph.001` image (deserialize_witnesscalc_graph, src/storage.rs:214-249). */
@@ -62,9 +64,13 @@ int gwb_inputs_from_json_batch(const gwb_graph_t *g, const char *text, size_t te
  * through one %lu conversion, e.g. "out/witness_%05lu.wtns". */
 int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, const char *path_pattern, gw_status_t *status);
 
-/* 0 = choose from the batch size (default); else a power of two in 1..64 */
+/* Wherever this API takes or returns a tile width it is a "program key": the width (input sets per wavefront, a power
+ * of two in 1..64), optionally OR'ed with GWB_TILE_ASYNC_DIVIDER = programs for the asynchronous divider wave (one
+ * extra wavefront per tile serves the field divisions while the interpreter wave goes on; widths below 64). */
+#define GWB_TILE_ASYNC_DIVIDER 0x100u
+/* 0 = choose from the batch size (default); else a program key */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
-/* the tile width (input sets per wavefront) the library chooses for a batch of this size */
+/* the program key the library chooses for a batch of this size */
 uint32_t gwb_pick_tile_width(size_t batch);
 
 /* Evaluate `batch` input sets resident in device memory (graph::evaluate per set, src/graph.rs:367-391).
@@ -82,7 +88,7 @@ int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 
 /* Diagnostic build of the interpreter with in-kernel cycle stamps, shader cycles summed over the sampled waves:
  * out64[class*4 + 0] = cycles of the class's bundles, out64[class*4 + 3] = bundles; for MUL (k = 0) and LIN (k = 1)
- * bundles out64[40 + 8*k + {0: loop top + wait for staged operands, 1: LDS operand reads, 2: issuing the staging
+ * bundles out64[48 + 8*k + {0: loop top + wait for staged operands, 1: LDS operand reads, 2: issuing the staging
  * loads, 3: dispatch + arithmetic, 4: stores + ring write, 5: bundles}].  out64 must hold 64 words. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out64, gw_status_t *status);

@@ -18,19 +18,19 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Mul"], "DIV": ["Div"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<10I26Q"
+HDR_FMT = "<12I30Q"
 HDR_SIZE = struct.calcsize(HDR_FMT)
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET"]
 
 
 class Blob:
     def __init__(self, data):
         h = struct.unpack_from(HDR_FMT, data, 0)
         (self.magic, self.version, self.T, self.G, self.n_bundles, self.n_slots, self.n_const, self.n_inputs,
-         self.n_witness, _res) = h[:10]
-        st = h[10:]
+         self.n_witness, self.divider, self.n_div_requests, _res) = h[:12]
+        st = h[12:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:15], class_bundles=st[15:24], n_op_compiled=st[24], algorithmic_bytes_per_set=st[25])
+                          class_nodes=st[6:17], class_bundles=st[17:28], n_op_compiled=st[28], algorithmic_bytes_per_set=st[29])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -62,6 +62,8 @@ def run(blob: Blob, inputs_row):
     history = {}  # value slot -> list of (bundle that stored, value)
     status = 0
     ring = {}     # (ring cell, node slot) -> (bundle that wrote it, value)
+    mailbox = None  # operands of the division request in flight (asynchronous divider programs)
+    n_requests = 0
 
     def mem_at(off, as_of_bundle):
         """content of the tile at byte offset off, after the stores of bundles <= as_of_bundle"""
@@ -83,6 +85,11 @@ def run(blob: Blob, inputs_row):
         stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
         lin_seen = 0
+        if name == "DIVREQ":
+            assert blob.divider and mailbox is None, "one division request in flight at a time"
+            request = {}
+        if name == "DIVGET":
+            assert blob.divider and mailbox is not None and len(mailbox) == cnt, "collect must mirror the request"
         for j in range(G):
             a_off, b_off, dctl, lds = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
             ctrl, dst = dctl & CTRL_MASK, dctl & ~CTRL_MASK
@@ -103,7 +110,13 @@ def run(blob: Blob, inputs_row):
                 assert dst == trash and a_off == zero_off and b_off == zero_off
                 continue
             sub = ctrl & CTRL_SUB_MASK
-            if name == "INPUT":
+            if name == "DIVREQ":
+                request[j] = (ops[0], ops[1])
+                assert dst == trash
+                v = 0
+            elif name == "DIVGET":
+                v = model.eval_duo("Div", *mailbox[j])
+            elif name == "INPUT":
                 v = inputs_row[blob.crefs[b * G + j]] % model.M
             elif name == "TERN":
                 v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
@@ -117,6 +130,13 @@ def run(blob: Blob, inputs_row):
                     status |= 1 if op == "Shl" else 2
                     v = 0
             results.append((dst, v))
+        if name == "DIVREQ":
+            mailbox = request
+            n_requests += 1
+        elif name == "DIVGET":
+            mailbox = None
+        else:
+            assert name != "DIV" or not blob.divider
         assert (h >> 11) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
@@ -126,8 +146,10 @@ def run(blob: Blob, inputs_row):
                 history.setdefault(d // slot_bytes - NC, []).append((b, v))
         for j, (_, v) in enumerate(results):
             ring[(b % RING_BUNDLES, j)] = (b, v)
-        for j in range(cnt, G):
+        for j in range(cnt if name != "DIVREQ" else 0, G):
             ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
+
+    assert mailbox is None and n_requests == blob.n_div_requests
 
     def wit(r):
         return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else history[r][-1][1]

@@ -26,7 +26,10 @@ def _rand_row(rnd, n, small=0.3):
     return [1] + [rnd.randrange(M) if rnd.random() > small else rnd.choice([rnd.randrange(1 << 16), rnd.choice(EDGE)]) for _ in range(n - 1)]
 
 
-def _check(pkg, data, rows, tiles=(1, 4, 64)):
+DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER
+
+
+def _check(pkg, data, rows, tiles=(1, 4, 64, 1 | DIVIDER, 4 | DIVIDER)):
     g = pkg.Graph(data)
     og = cbind.Graph(data)
     inp = cbind.ints_to_array(rows)
@@ -56,7 +59,7 @@ def test_every_op_on_edge_operands(pkg):
     inp = cbind.ints_to_array(rows)
     # a panicking op poisons the whole set in the oracle (evaluate stops), so compare op by op instead
     nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
-    for tw in (1, 16, 64):
+    for tw in (1, 16, 64, 2 | DIVIDER):
         g.set_tile_width(tw)
         got, st = g.calc_witness_batch(inp)
         for r, (row, o, s) in enumerate(zip(rows, got, st)):
@@ -135,14 +138,14 @@ def test_cli_twin(pkg, tmp_path):
 def test_random_dag_fuzz(pkg, seed):
     rnd = random.Random(100 + seed)
     b = C.build_random_dag(seed, n_ops=400, panic_free=(seed % 3 != 0))
-    _check(pkg, b.to_bin(), [_rand_row(rnd, 7) for _ in range(40)], tiles=(1, 8, 64))
+    _check(pkg, b.to_bin(), [_rand_row(rnd, 7) for _ in range(40)], tiles=(1, 8, 64, 8 | DIVIDER))
 
 
 def test_gadgets_and_ragged_batches(pkg):
     rnd = random.Random(5)
     data = C.build_gadgets().to_bin()
     for n in (1, 2, 63, 64, 65, 130):  # tails of every tile width
-        _check(pkg, data, [_rand_row(rnd, 7) for _ in range(n)], tiles=(1, 2, 4, 8, 16, 32, 64))
+        _check(pkg, data, [_rand_row(rnd, 7) for _ in range(n)], tiles=(1, 2, 4, 8, 16, 32, 64, 2 | DIVIDER, 32 | DIVIDER))
     g = pkg.Graph(data)
     w, s = g.calc_witness_batch(np.zeros((0, g.n_inputs, 32), dtype=np.uint8))  # empty batch
     assert w.shape == (0, g.n_witness, 32) and s.shape == (0,)
@@ -211,7 +214,7 @@ def test_authv2_class_full_size_batch_1024(pkg):
     d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device="cuda")
     d_st = torch.zeros(B, dtype=torch.int32, device="cuda")
     digests = []
-    for tw in (0, 1, 64):
+    for tw in (0, 1, 64, 2, 2 | DIVIDER):  # 0 = the library's choice (asynchronous divider at this batch size)
         g.set_tile_width(tw)
         d_out.zero_()
         g.calc_witness_batch_device(d_in, d_out, d_st)

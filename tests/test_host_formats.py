@@ -148,18 +148,28 @@ def test_wtns_framing(pkg):
     assert pkg.wtns_from_witness([1, 31817, 105, 303]) == open(os.path.join(GOLD, "circuit1.wtns"), "rb").read()
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64])
+DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER: programs for the asynchronous divider wave
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64, 1 | DIVIDER, 2 | DIVIDER, 8 | DIVIDER, 32 | DIVIDER])
 def test_graph_compiler_emulated(pkg, tile):
-    """Level scheduling, bundling, slot reuse and operand encoding for every tile width (host logic only)."""
+    """Level scheduling, bundling, slot reuse and operand encoding for every tile width and both division
+    strategies (host logic only)."""
     rnd = random.Random(tile)
+    key, tile = tile, tile & ~DIVIDER
     cases = [(C.build_gadgets(), 7), (C.build_poseidon(2), 3), (C.build_bigint_class(k=3, rounds=2), 8)] + \
             [(C.build_random_dag(s, n_ops=250, panic_free=(s % 2 == 0)), 7) for s in range(6)]
     for b, n_in in cases:
         data = b.to_bin()
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
         g = pkg.Graph(data)
-        blob = pe.Blob(g.export_blob(tile))
-        assert blob.T == tile and blob.n_witness == len(wit)
+        blob = pe.Blob(g.export_blob(key))
+        assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 0)
+        n_div = sum(1 for n in nodes if n[0] == "Duo" and n[1] == "Div")
+        if key & DIVIDER:
+            assert blob.stats["class_nodes"][9] == blob.stats["class_nodes"][10] == n_div and blob.stats["class_nodes"][3] == 0
+        else:
+            assert blob.stats["class_nodes"][3] == n_div and blob.n_div_requests == 0
         assert blob.stats["algorithmic_bytes_per_set"] == g.algorithmic_bytes_per_set
         arity = {"Uno": 1, "Duo": 2, "Tres": 3}
         want_bytes = 32 * (sum(arity[n[0]] + 1 for n in nodes if n[0] in arity) + 2 * sum(1 for n in nodes if n[0] == "Input") + 2 * len(wit))
