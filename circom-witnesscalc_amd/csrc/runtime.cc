@@ -100,6 +100,8 @@ struct gwb_graph {
     uint32_t n_inputs = 0, n_witness = 0;
     ProgramStats stats;
     std::map<uint32_t, std::unique_ptr<DeviceProgram>> progs;
+    std::map<uint32_t, std::unique_ptr<Program>> compiled;  // compiled for the cost model, not uploaded (yet)
+    std::map<size_t, uint32_t> chosen;                       // batch size -> program key picked by the cost model
     uint32_t forced_T = 0;
     // value workspaces ("chunks"): separately allocated groups of tiles (CWC_WORKSPACE_GB each), all covered by ONE
     // launch (the kernel picks the chunk per tile; every tile has its own 32-bit buffer window)
@@ -131,28 +133,24 @@ struct gwb_graph {
     }
 };
 
-// Tile width heuristic (measured on MI355X, profiles/r01_sweep_batch_tile.txt).  The kernel needs 178 VGPRs, so a
-// SIMD holds two waves and the chip 2048; a wave's time is set by its instruction stream (bundles), and wider tiles
-// mean better lane use but more bundles.  Best measured: T = 1 up to 512 sets, T = 2 up to 4095, then the widest
-// tile that still leaves about 2048 waves in flight (8192 sets -> 4, 16384 -> 8, 32768 -> 16, ...).
-// CWC_TARGET_WAVES (default 2048) moves the large-batch rule; gwb_set_tile_width / CWC_TILE_WIDTH override it.
+// Program choice (measured on MI355X, profiles/r01_sweep_batch_tile.txt).  A wave's time is the sum of its bundles;
+// wider tiles use the lanes better but need more bundles, and the chip holds 2048 of these waves (LDS: 8 per CU).
+// Best measured: T = 1 up to 256 sets, 2 up to 1024, 4 up to 8192, then the narrowest tile whose waves are all
+// resident at once (16384 sets -> 8, 32768 -> 16, ...).  The asynchronous divider wave (one extra wavefront per tile
+// that serves the divisions while the interpreter goes on) pays while the extra waves find free SIMDs: up to 1024 tiles.
+// CWC_TARGET_WAVES (default 2048) and CWC_DIVIDER_TILES (default 1024) move the rules; gwb_set_tile_width /
+// CWC_TILE_WIDTH override them.
 extern "C" uint32_t gwb_pick_tile_width(size_t batch) {
-    size_t target = 2048;
+    size_t target = 2048, divider_tiles = 1024;
     if (const char* e = getenv("CWC_TARGET_WAVES")) {
         long v = atol(e);
         if (v > 0) target = (size_t)v;
     }
-    uint32_t t = 1;
-    if (batch > 512) {
-        t = 2;
-        while (t < 64 && batch / (t * 2) >= target) t *= 2;
-    }
-    // Asynchronous divider wave (one extra wavefront per tile that serves the divisions while the interpreter goes
-    // on): pays while the extra waves find free SIMDs, i.e. up to about one interpreter wave per two SIMDs.
-    size_t divider_tiles = 640;
     if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
+    uint32_t t = batch <= 256 ? 1 : batch <= 1024 ? 2 : 4;
+    while (t < 64 && (batch + t - 1) / t > target) t *= 2;
     const size_t tiles = (batch + t - 1) / t;
-    return t | (tiles <= divider_tiles ? KEY_DIVIDER : 0u);
+    return t | (tiles <= divider_tiles && t < 64 ? KEY_DIVIDER : 0u);
 }
 
 namespace {
@@ -166,14 +164,67 @@ std::string check_device() {
     return "";
 }
 
-uint32_t pick_tile_width(const gwb_graph* g, size_t batch) {
+// Cost model behind the automatic program choice.  A wave's time is the sum of its bundles (lone-wave shader cycles
+// per bundle class, profiles/r01_class_profile.txt); waves slow each other down as the CUs fill (measured on the
+// authV2-class graph: x1.0 at 512 waves, x1.4 at 1024, x1.6 at 2048), and beyond 2048 waves they run in rounds.
+double estimate_cycles(const Program& p, size_t batch) {
+    static const double kCycles[C_COUNT] = {5000, 2350, 1150, 73500, 1250, 6000, 5600, 40000, 1900, 1450, 1450};
+    double per_wave = 0;
+    for (int c = 0; c < (int)C_COUNT; ++c) per_wave += kCycles[c] * (double)p.stats.class_bundles[c];
+    const double waves = (double)((batch + p.T - 1) / p.T);
+    const double resident = waves < 2048 ? waves : 2048;
+    const double crowd = resident <= 512 ? 1.0 : resident <= 1024 ? 1.0 + 0.4 * (resident - 512) / 512 : 1.4 + 0.2 * (resident - 1024) / 1024;
+    const double rounds = waves <= 2048 ? 1.0 : waves / 2048;
+    return per_wave * crowd * rounds;
+}
+
+// The program key for a batch: forced / environment override, else the static rule's width and its neighbours
+// compiled (host only) and priced with the cost model; the choice is remembered per batch size.
+uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     if (!g->has_graph && !g->progs.empty()) return g->progs.begin()->first;  // imported: the one program it has
     if (g->forced_T) return g->forced_T;
     if (const char* e = getenv("CWC_TILE_WIDTH")) {  // width, or width + 256 for the asynchronous divider
         const uint32_t key = (uint32_t)atoi(e), t = key & ~KEY_DIVIDER;
         if (t >= 1 && t <= 64 && !(t & (t - 1))) return key;
     }
-    return gwb_pick_tile_width(batch);
+    const uint32_t rule = gwb_pick_tile_width(batch);
+    if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph) return rule;
+    auto hit = g->chosen.find(batch);
+    if (hit != g->chosen.end()) return hit->second;
+    size_t divider_tiles = 1024;
+    if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
+    const uint32_t t0 = rule & ~KEY_DIVIDER;
+    uint32_t best = rule;
+    double best_cost = -1;
+    for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2) {
+        const size_t tiles = (batch + t - 1) / t;
+        if (tiles > 4 * 2048) continue;
+        const bool divider = tiles <= divider_tiles && g->stats.class_nodes[C_DIV] > 0;
+        const uint32_t key = t | (divider ? KEY_DIVIDER : 0u);
+        const Program* p = nullptr;
+        auto up = g->progs.find(key);
+        if (up != g->progs.end()) {
+            p = &up->second->host;
+        } else {
+            auto& slot = g->compiled[key];
+            if (!slot) {
+                slot.reset(new Program());
+                std::string err;
+                if (!compile_program(g->graph, t, divider, *slot, err)) {
+                    g->compiled.erase(key);
+                    continue;
+                }
+            }
+            p = slot.get();
+        }
+        const double cost = estimate_cycles(*p, batch);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = key;
+        }
+    }
+    g->chosen[batch] = best;
+    return best;
 }
 
 std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
@@ -187,7 +238,13 @@ std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
     if (!g->has_graph) return "imported graph handle has no program for tile width " + std::to_string(T);
     std::unique_ptr<DeviceProgram> dp(new DeviceProgram());
     std::string err;
-    if (!compile_program(g->graph, T, (key & KEY_DIVIDER) != 0, dp->host, err)) return err;
+    auto pre = g->compiled.find(key);
+    if (pre != g->compiled.end()) {  // already compiled for the cost model
+        dp->host = std::move(*pre->second);
+        g->compiled.erase(pre);
+    } else if (!compile_program(g->graph, T, (key & KEY_DIVIDER) != 0, dp->host, err)) {
+        return err;
+    }
     err = upload_program(*dp);
     if (!err.empty()) return err;
     *out = dp.get();
