@@ -25,10 +25,11 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     g.calc_witness_batch_device(d_in, d_out, d_st); torch.cuda.synchronize()
     t = g.last_timing()
     prof = g.profile_classes(d_in, d_out, d_st)
-    nw = max(1, (B + tw - 1) // tw // 64 + (1 if ((B + tw - 1) // tw) % 64 else 0))
+    tiles = (B + (tw & 0xff) - 1) // (tw & 0xff)
+    nw = max(1, tiles // 64 + (1 if tiles % 64 else 0))
     sections = prof.pop("_sections")
     tot = sum(v[0] for v in prof.values())
-    print("T=%d B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw, B, t["interp_ms"], nw, tot / nw))
+    print("T=%d%s B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw & 0xff, " + divider wave" if tw & 0x100 else "", B, t["interp_ms"], nw, tot / nw))
     for k, (cyc, _a, _b, n) in prof.items():
         if n:
             print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  share %.1f%%" % (k, n // nw, cyc / n, 100.0 * cyc / tot))
