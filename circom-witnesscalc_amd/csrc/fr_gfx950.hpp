@@ -182,6 +182,18 @@ FRD Fr fr_mul(const Fr& a, const Fr& b) {
     return u256_select(br != 0, r, s);
 #endif
 }
+#if defined(__HIPCC__)
+// Montgomery product as ONE asm block (accumulators in fixed VGPRs v160-v167): no compiler-inserted hazard padding, the
+// column shift is one v_pk_mov_b32, the conditional subtraction rides in the tails of the last columns.
+__device__ __forceinline__ Fr fr_mul_wave(const Fr& a, const Fr& b, const Fr& pv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_mul_block_gfx950.inc"
+#else
+    (void)pv;
+    return fr_mul(a, b);
+#endif
+}
+#endif
 FRD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 
 // canonical -> Montgomery (Fr::new): reduces any x < 2^256

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(DIVIDER ? 128 : 64) void interp_kernel(const uint32
         const uint32_t sub = ctrl & CTRL_SUB_MASK;
         Fr r;
         if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
-            r = fr_mul(a_op, b_op);
+            r = fr_mul_wave(a_op, b_op, pv);
         } else if (__builtin_expect(cls == C_LIN, 1)) {
             // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
             // uniform (header bits); a mixed one computes both and selects per lane.
