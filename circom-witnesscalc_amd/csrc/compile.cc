@@ -1,5 +1,6 @@
 // Host graph compiler: validation, level scheduling into same-class bundles, liveness-based slot
 // allocation, program encoding.  See program.hpp.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -351,6 +352,27 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
             for (uint32_t u : users[i]) h = std::max(h, height[u]);
             height[i] = h + class_cost[class_of(g.nodes[i])];
         }
+        if (getenv("CWC_DEBUG_CRITICAL_PATH")) {  // diagnostic: class composition of the cost-weighted critical path
+            uint32_t cur = 0xffffffffu;
+            for (size_t i = 0; i < N; ++i)
+                if (g.nodes[i].kind != N_CONST && (cur == 0xffffffffu || height[i] > height[cur])) cur = (uint32_t)i;
+            uint64_t cnt[C_COUNT] = {0}, total = height[cur];
+            std::string seq;
+            while (true) {
+                const int c = class_of(g.nodes[cur]);
+                cnt[c]++;
+                if (seq.size() < 400) seq += "IMLD?????T"[c < 10 ? c : 4];
+                uint32_t nxt = 0xffffffffu;
+                for (uint32_t u : users[cur])
+                    if (nxt == 0xffffffffu || height[u] > height[nxt]) nxt = u;
+                if (nxt == 0xffffffffu) break;
+                cur = nxt;
+            }
+            fprintf(stderr, "critical path: cost %llu; nodes by class:", (unsigned long long)total);
+            for (int c = 0; c < (int)C_COUNT; ++c)
+                if (cnt[c]) fprintf(stderr, " %d:%llu", c, (unsigned long long)cnt[c]);
+            fprintf(stderr, "\n  start: %s\n", seq.c_str());
+        }
         // operations between a node and the nearest division that depends on it (saturating)
         static const uint32_t kFar = 0xffffu;
         uint32_t div_wait_ops = 6;
@@ -382,6 +404,7 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
         // Asynchronous divider: a division bundle is split into a request (operands to the divider wave) and, about
         // one inversion later on the scheduler's clock, a collect bundle with the same nodes in the same node slots;
         // the interpreter runs other ready work in between.  One request is in flight at a time.
+        const bool ride_along = !getenv("CWC_NO_RIDE_ALONG");
         uint64_t clock = 0;
         std::vector<uint32_t> in_flight;  // nodes of the pending request
         uint64_t in_flight_ready = 0;
@@ -454,6 +477,20 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
                 h.pop_back();
             }
             std::sort(picked.begin(), picked.end());
+            // A wave's time is the sum of its bundles and a multiplication bundle costs the same however few of its
+            // node slots are used: ready Add/Sub nodes ride in its free slots (the kernel then also runs the ~40-slot
+            // linear body, header bits) instead of asking for a bundle of their own later.
+            if (best == C_MUL && picked.size() < G && !heap[C_LIN].empty() && ride_along) {
+                auto& hl = heap[C_LIN];
+                std::vector<uint32_t> riders;
+                while (!hl.empty() && picked.size() + riders.size() < G) {
+                    std::pop_heap(hl.begin(), hl.end());
+                    riders.push_back(~hl.back().second);
+                    hl.pop_back();
+                }
+                std::sort(riders.begin(), riders.end());
+                picked.insert(picked.end(), riders.begin(), riders.end());  // multiplications first: they name the class
+            }
             if (best == C_DIV && divider) {
                 emit_bundle(picked, true, false);
                 in_flight = picked;
@@ -525,12 +562,12 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
     };
     auto sub_of = [&](uint8_t op) -> uint32_t {
         switch (op) {
-            case OP_ADD: return SUB_ADD;   case OP_SUB: return SUB_SUB;
+            case OP_ADD: return SUB_ADD;   case OP_SUB: return SUB_SUB;   case OP_MUL: return SUB_MULT;
             case OP_EQ: return SUB_EQ;     case OP_NEQ: return SUB_NEQ;   case OP_LAND: return SUB_LAND; case OP_LOR: return SUB_LOR;
             case OP_LT: return SUB_LT;     case OP_GT: return SUB_GT;     case OP_LEQ: return SUB_LEQ;   case OP_GEQ: return SUB_GEQ;
             case OP_SHL: return SUB_SHL;   case OP_SHR: return SUB_SHR;   case OP_BOR: return SUB_BOR;   case OP_BAND: return SUB_BAND;
             case OP_BXOR: return SUB_BXOR; case OP_IDIV: return SUB_IDIV; case OP_MOD: return SUB_MOD;
-            default: return 0;  // Mul, Div: the class says it all
+            default: return 0;  // Div: the class says it all
         }
     };
     // first pass: slots bundle by bundle; r = {a_off, b_off, slot id (patched below) , a_lds | b_lds << 16}, ctrl kept aside
@@ -606,9 +643,11 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
             }
         }
         uint32_t lin_bits = 0;
-        if (cl == C_LIN)
-            for (uint32_t k = k0; k < k1; ++k)
-                lin_bits |= (ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK) == SUB_SUB ? HDR_LIN_SUB : HDR_LIN_ADD;
+        if (cl == C_LIN || cl == C_MUL)
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK;
+                lin_bits |= sub == SUB_SUB ? HDR_LIN_SUB : sub == SUB_ADD ? HDR_LIN_ADD : 0u;
+            }
         out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits;
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());

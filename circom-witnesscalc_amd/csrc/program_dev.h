@@ -15,7 +15,7 @@ namespace cwc {
 // bundle classes (wave-uniform: one scalar branch per bundle, no divergence on op type)
 enum BundleClass : uint32_t {
     C_INPUT = 0,    // dst = to_mont(inputs[set][a])                       graph.rs:376
-    C_MUL = 1,      // graph.rs:105
+    C_MUL = 1,      // graph.rs:105; free node slots may carry Add/Sub nodes (header bits say so), see compile.cc
     C_LIN = 2,      // Add / Sub / Neg (as 0 - a)                          graph.rs:110-111, 188-194
     C_DIV = 3,      // graph.rs:109
     C_CMPZ = 4,     // Eq / Neq / Land / Lor (no representation change)    graph.rs:122-129, 134-135
@@ -33,7 +33,8 @@ enum BundleClass : uint32_t {
 // interpreter spends no vector instruction on decoding or address arithmetic beyond adding the lane's 16*t.
 //
 // hdr[bundle] (wave-uniform, fetched with scalar loads): bits 0-3 class | bits 4-10 node count |
-//   C_LIN only: bit 11 some lane subtracts, bit 12 some lane adds (uniform bundles take a shorter path)
+//   C_LIN and C_MUL: bit 11 some lane subtracts, bit 12 some lane adds (C_LIN: uniform bundles take a shorter path;
+//   C_MUL: the bundle also carries linear nodes in otherwise idle node slots)
 //
 // LDS of a wave (one wave per workgroup), byte addresses:
 //   RING   [LDS_RING_OFF  + (bundle mod RING_BUNDLES) * 2 KiB]  results of the last RING_BUNDLES bundles,
@@ -67,7 +68,7 @@ static const uint32_t LDS_RING_OFF = 0, LDS_STAGE_OFF = LDS_RING_OFF + RING_BUND
                       LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES, LDS_BYTES = LDS_REC_OFF + REC_AHEAD * REC_BYTES;
 // sub-ops inside a class (3 bits)
 enum SubOp : uint32_t {
-    SUB_ADD = 0, SUB_SUB = 1,                                      // C_LIN (Neg is 0 - a)
+    SUB_ADD = 0, SUB_SUB = 1, SUB_MULT = 2,                        // C_LIN (Neg is 0 - a); C_MUL lanes: SUB_MULT or a linear rider
     SUB_EQ = 0, SUB_NEQ = 1, SUB_LAND = 2, SUB_LOR = 3,            // C_CMPZ
     SUB_LT = 0, SUB_GT = 1, SUB_LEQ = 2, SUB_GEQ = 3,              // C_CMPS
     SUB_SHL = 0, SUB_SHR = 1, SUB_BOR = 2, SUB_BAND = 3, SUB_BXOR = 4,  // C_BIT

@@ -15,7 +15,7 @@ LDS_RING_OFF = 0
 LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES
 LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES
 SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS": ["Lt", "Gt", "Leq", "Geq"],
-             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Mul"], "DIV": ["Div"]}
+             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Add", "Sub", "Mul"], "DIV": ["Div"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
 HDR_FMT = "<12I30Q"
@@ -122,7 +122,7 @@ def run(blob: Blob, inputs_row):
                 v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
             else:
                 op = SUB_NAMES[name][sub]
-                if name == "LIN":
+                if name in ("LIN", "MUL") and op != "Mul":
                     lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
                 try:
                     v = model.eval_duo(op, ops[0], ops[1])
