@@ -141,6 +141,15 @@ def test_random_dag_fuzz(pkg, seed):
     _check(pkg, b.to_bin(), [_rand_row(rnd, 7) for _ in range(40)], tiles=(1, 8, 64, 8 | DIVIDER))
 
 
+def test_compiler_rewrites_on_chain_heavy_graphs(pkg):
+    """Exact rewrites of the host compiler (tree-height reduction, riders, request/collect divisions) on the GPU."""
+    rnd = random.Random(77)
+    for seed in range(4):
+        b = C.build_chain_heavy(seed)
+        rows = [[1] + [rnd.choice([0, 1, M - 1, rnd.randrange(M)]) for _ in range(5)] for _ in range(37)]
+        _check(pkg, b.to_bin(), rows, tiles=(1, 2, 16, 64, 2 | DIVIDER, 8 | DIVIDER))
+
+
 def test_gadgets_and_ragged_batches(pkg):
     rnd = random.Random(5)
     data = C.build_gadgets().to_bin()

@@ -240,3 +240,21 @@ def test_power_of_two_division_rewrite_is_exact(pkg):
     M = model.M
     for xv in (0, 1, 5, (1 << 64) - 1, 1 << 200, M - 1, M // 2, (1 << 253) + 12345):
         assert pe.run(blob, [1, xv])[0] == model.evaluate(nodes, [1, xv], wit)
+
+
+@pytest.mark.parametrize("key", [2, 2 | DIVIDER, 16])
+def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
+    """Tree-height reduction, shared subexpressions, dead-node elimination, linear riders in multiplication bundles and
+    request/collect divisions: long Add / Mul chains with constants, repeated operands, witness elements in the middle of
+    chains and unused tails, against the big-int oracle."""
+    rnd = random.Random(1000 + key)
+    for case in range(4):
+        b = C.build_chain_heavy(1000 * key + case)
+        data = b.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        g = pkg.Graph(data)
+        blob = pe.Blob(g.export_blob(key))
+        for _ in range(3):
+            row = [1] + [rnd.choice([0, 1, model.M - 1, rnd.randrange(model.M)]) for _ in range(5)]
+            got, st = pe.run(blob, row)
+            assert st == 0 and got == model.evaluate(nodes, row, wit)

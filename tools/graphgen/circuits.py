@@ -703,3 +703,29 @@ def build_bigint_class(k=8, n_bits=64, rounds=4, seed="bigint"):
         x, y = nx, ny
         d = b.signal(b.add(b.op("Band", b.add(d, rem), mask), one))
     return b
+
+
+def build_chain_heavy(seed, n_chains=12, n_inputs=5):
+    """Long Add / Mul / mixed chains with constants (`lc += c * x`), repeated operands, witness elements in the middle of
+    chains and unused tails: the shapes the compiler's exact rewrites (tree-height reduction, shared subexpressions,
+    dead-node elimination, linear riders, request/collect divisions) act on."""
+    rnd = random.Random(seed)
+    b = Builder()
+    ins = b.input("in", n_inputs)
+    pool = list(ins)
+    for _chain in range(n_chains):
+        op = rnd.choice(["add", "mul", "mixed"])
+        acc = rnd.choice(pool)
+        for _step in range(rnd.randrange(3, 14)):
+            x = rnd.choice(pool) if rnd.random() < 0.7 else b.const(rnd.choice([0, 1, 2, R - 1, rnd.randrange(R)]))
+            if rnd.random() < 0.3:
+                x = b.mul(b.const(rnd.randrange(1, R)), x)
+            kind = op if op != "mixed" else rnd.choice(["add", "mul", "sub", "div"])
+            acc = {"add": b.add, "mul": b.mul, "sub": b.sub, "div": b.div}[kind](acc, x)
+            if rnd.random() < 0.25:
+                b.signal(acc)
+            if rnd.random() < 0.3:
+                pool.append(acc)
+        if rnd.random() < 0.7:
+            b.signal(acc)
+    return b
