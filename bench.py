@@ -148,7 +148,7 @@ def main():
                        "graph": "generated (tools/graphgen): real circom graphs cannot be built offline",
                        "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth,
                        "op_histogram": stats["hist"], "batch_per_gpu": B, "tile_width": tm["tile_width"],
-                       "async_divider_wave": bool(tm["divider"]),
+                       "interpreter_waves_per_divider_wave": tm["divider"],
                        "bundles": tm["n_bundles"], "slots": tm["n_slots"], "sets_with_error_status": bad_sets,
                        "parallelism": "batch shards x%d, program broadcast over RCCL" % world if distributed
                        else "single process, 1 GPU"},
@@ -190,7 +190,7 @@ def large_batch_point(pkg, g, graph_kind, batch, dev):
     tm = g.last_timing()
     achieved = g.algorithmic_bytes_per_set * batch / (tm["interp_ms"] * 1e-3) / 1e9
     return {"batch_per_gpu": batch, "value": batch / dt, "unit": "witnesses/s", "ms_per_step": dt * 1e3,
-            "tile_width": tm["tile_width"], "async_divider_wave": bool(tm["divider"]), "launches": tm["n_launches"],
+            "tile_width": tm["tile_width"], "interpreter_waves_per_divider_wave": tm["divider"], "launches": tm["n_launches"],
             "roofline_frac": achieved / HBM_PEAK_GBS, "sets_with_error_status": int((d_st != 0).sum().item())}
 
 

@@ -209,7 +209,7 @@ static void reduce_tree_height(Graph& g) {
     g.nodes.swap(kept);
 }
 
-bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, std::string& err) {
+bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& out, std::string& err) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
@@ -231,11 +231,15 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
     rewrite_pow2_divisions(g);
     size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
-    if (G == 1) divider = false;  // T = 64 keeps the reference's node order, one node per bundle
+    if (divider != 0 && divider != 1 && divider != 4) {
+        err = "divider waves serve 1 or 4 interpreter waves";
+        return false;
+    }
+    if (G == 1) divider = 0;  // T = 64 keeps the reference's node order, one node per bundle
     out = Program();
     out.T = T;
     out.G = G;
-    out.divider = divider ? 1u : 0u;
+    out.divider = divider;
     ProgramStats& st = out.stats;
     st.n_nodes = g_in.nodes.size();
     st.n_witness = g.witness_signals.size();
@@ -437,6 +441,7 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
                 for (int c = 0; c < (int)C_COUNT; ++c) other_ready |= c != C_DIV && !heap[c].empty();
                 if (clock >= in_flight_ready || !other_ready) {
                     emit_bundle(in_flight, false, true);
+                    out.div_lanes.push_back((uint32_t)in_flight.size() * T);
                     in_flight.clear();
                     out.n_div_requests++;
                     clock += class_cost[C_LIN];
@@ -471,7 +476,9 @@ bool compile_program(const Graph& g_in, uint32_t T, bool divider, Program& out, 
             if (!heap[C_INPUT].empty()) best = C_INPUT;
             picked.clear();
             auto& h = heap[best];
-            while (!h.empty() && picked.size() < G) {
+            // a request must fit the interpreter's mailbox (mbox_lanes active lanes = node slots x T)
+            const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : G;
+            while (!h.empty() && picked.size() < cap) {
                 std::pop_heap(h.begin(), h.end());
                 picked.push_back(~h.back().second);
                 h.pop_back();
@@ -695,14 +702,14 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 5;
+    h.version = 6;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
     h.stats = p.stats;
     std::vector<uint8_t> out((uint8_t*)&h, (uint8_t*)&h + sizeof h);
     auto put = [&](const std::vector<uint32_t>& v) { out.insert(out.end(), (const uint8_t*)v.data(), (const uint8_t*)(v.data() + v.size())); };
-    put(p.hdr); put(p.recs); put(p.crefs); put(p.consts); put(p.witness_refs);
+    put(p.hdr); put(p.recs); put(p.crefs); put(p.consts); put(p.witness_refs); put(p.div_lanes);
     return out;
 }
 
@@ -710,20 +717,21 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 5 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || h.divider > 1) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 6 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;
     p.divider = h.divider; p.n_div_requests = h.n_div_requests;
     const size_t n_hdr = p.n_bundles, n_recs = (size_t)p.n_bundles * p.G * 4, n_c = (size_t)p.n_bundles * p.G,
-                 n_k = (size_t)p.n_const * 8, n_w = p.n_witness;
-    if (len != sizeof h + 4 * (n_hdr + n_recs + n_c + n_k + n_w)) { err = "program blob size mismatch"; return false; }
+                 n_k = (size_t)p.n_const * 8, n_w = p.n_witness, n_d = p.n_div_requests;
+    if (len != sizeof h + 4 * (n_hdr + n_recs + n_c + n_k + n_w + n_d)) { err = "program blob size mismatch"; return false; }
     const uint32_t* q = (const uint32_t*)(data + sizeof h);
     p.hdr.assign(q, q + n_hdr); q += n_hdr;
     p.recs.assign(q, q + n_recs); q += n_recs;
     p.crefs.assign(q, q + n_c); q += n_c;
     p.consts.assign(q, q + n_k); q += n_k;
-    p.witness_refs.assign(q, q + n_w);
+    p.witness_refs.assign(q, q + n_w); q += n_w;
+    p.div_lanes.assign(q, q + n_d);
     return true;
 }
 

@@ -36,6 +36,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // prove them read-only: the wave-uniform header stream then becomes scalar loads (s_load).
 struct InterpDims {
     uint32_t n_bundles, n_slots, n_inputs, batch, n_const, n_div_requests;
+    const uint32_t* div_lanes;  // active lanes of each division request (divider programs)
 };
 static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox wait gave up (never expected)
 
@@ -64,18 +65,26 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t byte
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
-template <int T, bool PROF, bool DIVIDER>
-__global__ __launch_bounds__(DIVIDER ? 128 : 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
+// W = interpreter waves per workgroup that share one divider wave (0: no divider wave, workgroup = one wave).
+template <int T, bool PROF, int W>
+__global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
                                                     const uint32_t* __restrict__ crefs, InterpDims p, WsTable wst,
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
     constexpr uint32_t HI = 16u * T;  // byte distance between the two 16-byte halves of a value in a slot
+    constexpr bool DIVIDER = W > 0;
+    constexpr uint32_t NW = W > 0 ? (uint32_t)W : 1u;               // interpreter waves per workgroup
+    constexpr uint32_t AREA = lds_area_bytes((uint32_t)W, LDS_BYTES);  // LDS of one interpreter wave
+    constexpr uint32_t ML = mbox_lanes((uint32_t)W), MB = mbox_bytes((uint32_t)W);
     const uint32_t batch = p.batch;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_tiles = (batch + T - 1) / T;
     const uint32_t t = lane % T;
     const uint32_t j = (G == 1) ? 0u : lane / T;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile_raw = blockIdx.x * NW + wave;
+    const uint32_t tile = tile_raw < n_tiles ? tile_raw : n_tiles - 1;  // (divider wave / absent interpreters: any valid tile)
     const uint32_t set = tile * T + t;
     const uint32_t set_c = set < batch ? set : batch - 1;  // padded lanes of the last tile re-evaluate a real set
     // One buffer descriptor per tile: every operand / destination is a 32-bit tile-relative byte offset.
@@ -85,39 +94,55 @@ __global__ __launch_bounds__(DIVIDER ? 128 : 64) void interp_kernel(const uint32
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
     const i32x4 rsrc_w = make_rsrc_words(tile_base, (uint32_t)tile_bytes);
     const i32x4 rsrc_rec = make_rsrc_words(recs, p.n_bundles * (uint32_t)G * 16u);
-    __shared__ uint4 lds[(LDS_BYTES + (DIVIDER ? MBOX_BYTES : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into it
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)(char*)lds;
+    __shared__ uint4 lds[(NW * AREA + (DIVIDER ? NW * MB + 64u : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into a wave's area
+    const uint32_t area = wave * AREA;  // this interpreter wave's LDS area (0 for single-wave workgroups)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)(char*)lds + area;
     const uint32_t t16 = 16u * t, lane16 = 16u * lane, j16 = 16u * j;
-    char* const ldsb = reinterpret_cast<char*>(lds);
-    char* const mbox = ldsb + LDS_BYTES;
+    char* const ldsb = reinterpret_cast<char*>(lds) + area;
+    char* const mbox_all = reinterpret_cast<char*>(lds) + NW * AREA;        // mailboxes, then the sequence words
+    char* const mbox = mbox_all + (wave < NW ? wave : 0u) * MB;             // this interpreter's mailbox
+    volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(mbox_all + NW * MB);  // [NW] posted, [NW] = served
     if (DIVIDER) {
-        if (threadIdx.x == 0) {  // sequence words start at zero
-            reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF)[0] = 0;
-            reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF)[1] = 0;
-        }
+        if (threadIdx.x <= NW) seq[threadIdx.x] = 0;  // sequence words start at zero
         __syncthreads();
-        if (threadIdx.x >= 64u) {
-            // ---- divider wave: serves the interpreter's division requests in order (graph.rs:109: b == 0 -> 0) ----
-            volatile uint32_t* seq = reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF);
+        const uint32_t first_tile = blockIdx.x * NW;
+        const uint32_t n_active = n_tiles - first_tile < NW ? n_tiles - first_tile : NW;  // interpreters with a tile
+        if (wave == NW) {
+            // ---- divider wave: serves the division requests in order (graph.rs:109: b == 0 -> 0).  Request k of
+            // every interpreter has the same div_lanes[k] active lanes; they are packed into passes of 64 lanes.
             for (uint32_t k = 0; k < p.n_div_requests; ++k) {
-                if (!mbox_wait(seq + 0, k + 1)) {
+                bool ok = true;
+                for (uint32_t w = 0; w < n_active; ++w) ok = ok && mbox_wait(seq + w, k + 1);
+                if (!ok) {
                     if (set < batch) atomicOr(&status[set], ST_DIVIDER_TIMEOUT);
                     break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint4* qa = reinterpret_cast<const uint4*>(mbox + MBOX_A_OFF + 16u * lane);
-                const uint4* qb = reinterpret_cast<const uint4*>(mbox + MBOX_B_OFF + 16u * lane);
-                const Fr a = fr_from_u4(qa[0], qa[LDS_HALF_BYTES / 16]), b = fr_from_u4(qb[0], qb[LDS_HALF_BYTES / 16]);
-                const Fr inv = fr_inv(b);  // safegcd divsteps; inv(0) = 0
-                const Fr r = u256_select(u256_is_zero(b), fr_zero(), fr_mul(a, inv));
-                uint4* qr = reinterpret_cast<uint4*>(mbox + MBOX_R_OFF + 16u * lane);
-                qr[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-                qr[LDS_HALF_BYTES / 16] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+                const uint32_t lanes_k = NW == 1 ? 64u : p.div_lanes[k];
+                const uint32_t total = n_active * lanes_k;
+                for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
+                    const uint32_t g = g0 + lane;
+                    const bool valid = g < total;
+                    const uint32_t w = valid ? g / lanes_k : 0u, i = valid ? g % lanes_k : 0u;
+                    char* mb = mbox_all + w * MB + 16u * i;
+                    const uint4* qa = reinterpret_cast<const uint4*>(mb);
+                    const uint4* qb = reinterpret_cast<const uint4*>(mb + 32u * ML);
+                    Fr a = fr_from_u4(qa[0], qa[ML]), b = fr_from_u4(qb[0], qb[ML]);
+                    if (!valid) b = fr_zero();
+                    const Fr inv = fr_inv(b);  // safegcd divsteps; inv(0) = 0
+                    const Fr r = u256_select(u256_is_zero(b), fr_zero(), fr_mul(a, inv));
+                    if (valid) {  // the quotient overwrites operand a
+                        uint4* qr = reinterpret_cast<uint4*>(mb);
+                        qr[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                        qr[ML] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) seq[1] = k + 1;
+                if (lane == 0) seq[NW] = k + 1;
             }
             return;
         }
+        if (tile_raw >= n_tiles) return;  // an interpreter wave without a tile (last workgroup)
     }
     uint32_t div_seq = 0;  // requests posted / collected so far (interpreter wave)
 
@@ -222,14 +247,16 @@ __global__ __launch_bounds__(DIVIDER ? 128 : 64) void interp_kernel(const uint32
             }
             case C_DIVREQ: {  // hand the operands to the divider wave; this bundle has no result of its own
                 if (DIVIDER) {
-                    uint4* qa = reinterpret_cast<uint4*>(mbox + MBOX_A_OFF + lane16);
-                    uint4* qb = reinterpret_cast<uint4*>(mbox + MBOX_B_OFF + lane16);
-                    qa[0] = make_uint4(a_op.v[0], a_op.v[1], a_op.v[2], a_op.v[3]);
-                    qa[LDS_HALF_BYTES / 16] = make_uint4(a_op.v[4], a_op.v[5], a_op.v[6], a_op.v[7]);
-                    qb[0] = make_uint4(b_op.v[0], b_op.v[1], b_op.v[2], b_op.v[3]);
-                    qb[LDS_HALF_BYTES / 16] = make_uint4(b_op.v[4], b_op.v[5], b_op.v[6], b_op.v[7]);
+                    if (lane < ML) {  // (a request has at most ML active lanes: the compiler caps its node count)
+                        uint4* qa = reinterpret_cast<uint4*>(mbox + lane16);
+                        uint4* qb = reinterpret_cast<uint4*>(mbox + 32u * ML + lane16);
+                        qa[0] = make_uint4(a_op.v[0], a_op.v[1], a_op.v[2], a_op.v[3]);
+                        qa[ML] = make_uint4(a_op.v[4], a_op.v[5], a_op.v[6], a_op.v[7]);
+                        qb[0] = make_uint4(b_op.v[0], b_op.v[1], b_op.v[2], b_op.v[3]);
+                        qb[ML] = make_uint4(b_op.v[4], b_op.v[5], b_op.v[6], b_op.v[7]);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) reinterpret_cast<volatile uint32_t*>(mbox + MBOX_SEQ_OFF)[0] = div_seq + 1;
+                    if (lane == 0) seq[wave] = div_seq + 1;
                 }
                 r = fr_zero();
                 break;
@@ -238,10 +265,12 @@ __global__ __launch_bounds__(DIVIDER ? 128 : 64) void interp_kernel(const uint32
                 r = fr_zero();
                 if (DIVIDER) {
                     ++div_seq;
-                    if (!mbox_wait(reinterpret_cast<const volatile uint32_t*>(mbox + MBOX_SEQ_OFF) + 1, div_seq)) err_bits |= ST_DIVIDER_TIMEOUT;
+                    if (!mbox_wait(seq + NW, div_seq)) err_bits |= ST_DIVIDER_TIMEOUT;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const uint4* qr = reinterpret_cast<const uint4*>(mbox + MBOX_R_OFF + lane16);
-                    r = fr_from_u4(qr[0], qr[LDS_HALF_BYTES / 16]);
+                    if (lane < ML) {
+                        const uint4* qr = reinterpret_cast<const uint4*>(mbox + lane16);
+                        r = fr_from_u4(qr[0], qr[ML]);
+                    }
                 }
                 break;
             }
@@ -419,25 +448,34 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
 }
 
 // ---- launchers (called from runtime.cc) -----------------------------------------------------------
-hipError_t launch_interp(uint32_t T, bool divider, uint32_t n_div_requests, const ProgramDev& p, const WsTable& wst, const void* inputs,
-                         uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
-    const uint32_t tiles = (batch + T - 1) / T;
-    dim3 grid(tiles), block(divider ? 128 : 64);
+hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p, const WsTable& wst,
+                         const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
+    const uint32_t tiles = (batch + T - 1) / T, nw = W ? W : 1u;
+    dim3 grid((tiles + nw - 1) / nw), block((W + 1) * 64);
     const uint4* in = (const uint4*)inputs;
-    const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests};
+    const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes};
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-#define CWC_LAUNCH2(TT, PP, DD) interp_kernel<TT, PP, DD><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
-#define CWC_LAUNCH(TT)                                                  \
-    case TT:                                                            \
-        if (prof) { if (divider) CWC_LAUNCH2(TT, true, true); else CWC_LAUNCH2(TT, true, false); }       \
-        else { if (divider) CWC_LAUNCH2(TT, false, true); else CWC_LAUNCH2(TT, false, false); }          \
+#define CWC_LAUNCH3(TT, PP, WW) interp_kernel<TT, PP, WW><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
+#define CWC_LAUNCH2(TT, PP)                               \
+    if (W == 0) CWC_LAUNCH3(TT, PP, 0);                   \
+    else if (W == 1) CWC_LAUNCH3(TT, PP, 1);              \
+    else if (W == 4) CWC_LAUNCH3(TT, PP, 4);              \
+    else return hipErrorInvalidValue;
+#define CWC_LAUNCH(TT)                                    \
+    case TT:                                              \
+        if (prof) { CWC_LAUNCH2(TT, true) } else { CWC_LAUNCH2(TT, false) } \
         break;
     switch (T) {
-        CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32) CWC_LAUNCH(64)
+        CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32)
+        case 64:
+            if (W != 0) return hipErrorInvalidValue;
+            if (prof) CWC_LAUNCH3(64, true, 0); else CWC_LAUNCH3(64, false, 0);
+            break;
         default: return hipErrorInvalidValue;
     }
 #undef CWC_LAUNCH
 #undef CWC_LAUNCH2
+#undef CWC_LAUNCH3
     return hipGetLastError();
 }
 

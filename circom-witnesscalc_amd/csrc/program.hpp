@@ -27,7 +27,7 @@ struct ProgramStats {
 
 struct Program {
     uint32_t T = 0, G = 0;
-    uint32_t divider = 0;                // 1: compiled for the asynchronous divider wave (C_DIVREQ / C_DIVGET bundles)
+    uint32_t divider = 0;                // W > 0: compiled for a divider wave shared by W interpreter waves (1 or 4)
     uint32_t n_div_requests = 0;         // C_DIVREQ bundles (what the divider wave serves, in order)
     uint32_t n_bundles = 0, n_slots = 0, n_const = 0, n_inputs = 0, n_witness = 0;
     std::vector<uint32_t> hdr;           // [n_bundles]      see program_dev.h (format v4)
@@ -35,14 +35,19 @@ struct Program {
     std::vector<uint32_t> crefs;         // [n_bundles*G]    third operand byte offset (C_TERN) / input index (C_INPUT)
     std::vector<uint32_t> consts;        // [n_const*8]      Montgomery form
     std::vector<uint32_t> witness_refs;  // [n_witness]      slot or REF_CONST|idx
+    std::vector<uint32_t> div_lanes;     // [n_div_requests] active lanes of each division request
     ProgramStats stats;
 };
 
 // Validates the graph (backward references, evaluable ops, index ranges) and compiles it for tile width T
-// (power of two, 1..64); divider = true compiles divisions for the asynchronous divider wave (T < 64 only).
-bool compile_program(const Graph& g, uint32_t T, bool divider, Program& out, std::string& err);
-// "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER
-static const uint32_t KEY_DIVIDER = 0x100u;
+// (power of two, 1..64); divider = W > 0 compiles divisions for a divider wave shared by W interpreter waves (W = 1 or
+// 4, T < 64 only).
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err);
+// "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER | KEY_GROUP
+static const uint32_t KEY_DIVIDER = 0x100u;  // one divider wave per interpreter wave
+static const uint32_t KEY_GROUP = 0x200u;    // one divider wave per four interpreter waves
+static const uint32_t KEY_MODE_MASK = KEY_DIVIDER | KEY_GROUP;
+static inline uint32_t key_divider_waves(uint32_t key) { return key & KEY_GROUP ? 4u : key & KEY_DIVIDER ? 1u : 0u; }
 
 // pointer-free serialisation (what is broadcast between GPUs)
 std::vector<uint8_t> program_to_blob(const Program& p);

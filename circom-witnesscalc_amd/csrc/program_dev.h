@@ -6,8 +6,10 @@
 
 #if defined(__HIPCC__)
 #define CWC_HD __host__ __device__ static inline
+#define CWC_HDC __host__ __device__ static constexpr
 #else
 #define CWC_HD static inline
+#define CWC_HDC static constexpr
 #endif
 
 namespace cwc {
@@ -59,11 +61,15 @@ static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
 static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
 static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;
-// Asynchronous divider (programs with Program::divider = 1): the workgroup is two wavefronts, the interpreter and a
-// divider.  Mailbox in LDS behind the interpreter's own area: operands a and b and the quotients as
-// [half][64 lanes][16 B] each, then two sequence words: requests posted (written by the interpreter), requests
-// served (written by the divider).  One request is in flight at a time (the compiler emits REQ k, GET k, REQ k+1, ...).
-static const uint32_t MBOX_A_OFF = 0, MBOX_B_OFF = 2048, MBOX_R_OFF = 4096, MBOX_SEQ_OFF = 6144, MBOX_BYTES = 6400;
+// Asynchronous divider (Program::divider = W > 0): a workgroup is W interpreter wavefronts (one tile each) plus one
+// divider wavefront; W = 1 serves the latency regime, W = 4 the throughput regime (the divider packs the requests of
+// its four interpreters into the lanes of ONE inversion).  LDS of the workgroup: W interpreter areas, then W mailboxes
+// of mbox_lanes(W) lanes -- operand a, operand b as [half][lane][16 B]; the quotient overwrites a -- then the sequence
+// words: requests posted by interpreter w (W words), requests served (one word, written by the divider).  One request
+// per interpreter is in flight at a time (the compiler emits REQ k, GET k, REQ k+1, ...).
+CWC_HDC uint32_t mbox_lanes(uint32_t W) { return W <= 1u ? 64u : 32u; }          // most active lanes of a request
+CWC_HDC uint32_t mbox_bytes(uint32_t W) { return mbox_lanes(W) * 64u; }           // per interpreter
+CWC_HDC uint32_t lds_area_bytes(uint32_t W, uint32_t lds_bytes) { return (void)W, lds_bytes; }  // per interpreter
 static const uint32_t LDS_RING_OFF = 0, LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES,
                       LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES, LDS_BYTES = LDS_REC_OFF + REC_AHEAD * REC_BYTES;
 // sub-ops inside a class (3 bits)
@@ -91,6 +97,7 @@ struct ProgramDev {
     const uint32_t* crefs;         // [n_bundles*G]
     const uint32_t* consts;        // [n_const*8] Montgomery form (the last entry is a dummy zero)
     const uint32_t* witness_refs;  // [n_witness]
+    const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
 };
 

@@ -18,8 +18,8 @@
 #include "program.hpp"
 
 namespace cwc {
-hipError_t launch_interp(uint32_t T, bool divider, uint32_t n_div_requests, const ProgramDev& p, const WsTable& wst, const void* inputs, uint32_t* status,
-                         uint32_t batch, hipStream_t stream, unsigned long long* prof);
+hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p, const WsTable& wst,
+                         const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof);
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream);
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
 }  // namespace cwc
@@ -60,7 +60,7 @@ std::string upload_program(DeviceProgram& dp) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_hdr = 0, o_recs = o_hdr + al(p.hdr.size() * 4), o_crefs = o_recs + al(p.recs.size() * 4),
                  o_consts = o_crefs + al(p.crefs.size() * 4), o_wit = o_consts + al(p.consts.size() * 4 + 32),
-                 total = o_wit + al(p.witness_refs.size() * 4 + 4);
+                 o_div = o_wit + al(p.witness_refs.size() * 4 + 4), total = o_div + al(p.div_lanes.size() * 4 + 4);
     HIP_TRY(hipMalloc(&dp.d_blob, total));
     char* d = (char*)dp.d_blob;
     HIP_TRY(hipMemset(d, 0, total));
@@ -73,7 +73,9 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.recs = (const uint32_t*)(d + o_recs);
     dp.dev.crefs = (const uint32_t*)(d + o_crefs);
     dp.dev.consts = (const uint32_t*)(d + o_consts);
+    if (!p.div_lanes.empty()) HIP_TRY(hipMemcpy(d + o_div, p.div_lanes.data(), p.div_lanes.size() * 4, hipMemcpyHostToDevice));
     dp.dev.witness_refs = (const uint32_t*)(d + o_wit);
+    dp.dev.div_lanes = (const uint32_t*)(d + o_div);
     dp.dev.n_bundles = p.n_bundles;
     dp.dev.n_slots = p.n_slots;
     dp.dev.n_inputs = p.n_inputs;
@@ -172,7 +174,9 @@ double estimate_cycles(const Program& p, size_t batch) {
     double per_wave = 0;
     for (int c = 0; c < (int)C_COUNT; ++c) per_wave += kCycles[c] * (double)p.stats.class_bundles[c];
     const double waves = (double)((batch + p.T - 1) / p.T);
-    const double resident = waves < 2048 ? waves : 2048;
+    // divider waves are busy about half of the time (W = 1) and take a wave slot of their CU
+    const double with_dividers = waves * (p.divider == 1 ? 1.3 : p.divider == 4 ? 1.1 : 1.0);
+    const double resident = with_dividers < 2048 ? with_dividers : 2048;
     const double crowd = resident <= 512 ? 1.0 : resident <= 1024 ? 1.0 + 0.4 * (resident - 512) / 512 : 1.4 + 0.2 * (resident - 1024) / 1024;
     const double rounds = waves <= 2048 ? 1.0 : waves / 2048;
     return per_wave * crowd * rounds;
@@ -184,23 +188,27 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     if (!g->has_graph && !g->progs.empty()) return g->progs.begin()->first;  // imported: the one program it has
     if (g->forced_T) return g->forced_T;
     if (const char* e = getenv("CWC_TILE_WIDTH")) {  // width, or width + 256 for the asynchronous divider
-        const uint32_t key = (uint32_t)atoi(e), t = key & ~KEY_DIVIDER;
+        const uint32_t key = (uint32_t)atoi(e), t = key & ~KEY_MODE_MASK;
         if (t >= 1 && t <= 64 && !(t & (t - 1))) return key;
     }
     const uint32_t rule = gwb_pick_tile_width(batch);
     if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph) return rule;
     auto hit = g->chosen.find(batch);
     if (hit != g->chosen.end()) return hit->second;
-    size_t divider_tiles = 1024;
+    size_t divider_tiles = 768;
     if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
-    const uint32_t t0 = rule & ~KEY_DIVIDER;
+    const uint32_t t0 = rule & ~KEY_MODE_MASK;
     uint32_t best = rule;
     double best_cost = -1;
     for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2) {
         const size_t tiles = (batch + t - 1) / t;
         if (tiles > 4 * 2048) continue;
-        const bool divider = tiles <= divider_tiles && g->stats.class_nodes[C_DIV] > 0;
-        const uint32_t key = t | (divider ? KEY_DIVIDER : 0u);
+        const bool has_div = g->stats.class_nodes[C_DIV] > 0;
+        const bool divider = tiles <= divider_tiles && has_div;
+        // one divider wave per four interpreter waves: measured to pay only while one such workgroup per CU covers the
+        // batch (a CU holds a single five-wave workgroup of this kernel)
+        const bool group = !divider && has_div && tiles > 768 && tiles <= 1024 && t <= 32 && !getenv("CWC_NO_GROUP_DIVIDER");
+        const uint32_t key = t | (divider ? KEY_DIVIDER : group ? KEY_GROUP : 0u);
         const Program* p = nullptr;
         auto up = g->progs.find(key);
         if (up != g->progs.end()) {
@@ -210,7 +218,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
             if (!slot) {
                 slot.reset(new Program());
                 std::string err;
-                if (!compile_program(g->graph, t, divider, *slot, err)) {
+                if (!compile_program(g->graph, t, key_divider_waves(key), *slot, err)) {
                     g->compiled.erase(key);
                     continue;
                 }
@@ -228,7 +236,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
 }
 
 std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
-    const uint32_t T = key & ~KEY_DIVIDER;
+    const uint32_t T = key & ~KEY_MODE_MASK;
     if (T == 64) key = T;  // no divider programs at T = 64
     auto it = g->progs.find(key);
     if (it != g->progs.end()) {
@@ -242,7 +250,7 @@ std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
     if (pre != g->compiled.end()) {  // already compiled for the cost model
         dp->host = std::move(*pre->second);
         g->compiled.erase(pre);
-    } else if (!compile_program(g->graph, T, (key & KEY_DIVIDER) != 0, dp->host, err)) {
+    } else if (!compile_program(g->graph, T, key_divider_waves(key), dp->host, err)) {
         return err;
     }
     err = upload_program(*dp);
@@ -324,7 +332,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
         HIP_TRY(hipEventRecord(e0, stream));
-        HIP_TRY(launch_interp(T, p.divider != 0, p.n_div_requests, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
+        HIP_TRY(launch_interp(T, p.divider, p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
         HIP_TRY(hipEventRecord(e2, stream));
@@ -391,7 +399,7 @@ int load_graph(const void* data, size_t len, gwb_graph** out, std::string& err) 
     g->has_graph = true;
     // validate by compiling the widest program's metadata (cheap) -- catches bad indices / Pow / Id early
     Program probe;
-    if (!compile_program(g->graph, 64, false, probe, err)) return 1;
+    if (!compile_program(g->graph, 64, 0, probe, err)) return 1;
     g->stats = probe.stats;
     g->n_inputs = probe.n_inputs;
     g->n_witness = probe.n_witness;
@@ -516,8 +524,8 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
 }
 
 int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
-    const uint32_t T = key & ~KEY_DIVIDER;
-    if (!g || T > 64 || (T & (T - 1)) || (key & KEY_DIVIDER && T == 0)) return 1;
+    const uint32_t T = key & ~KEY_MODE_MASK;
+    if (!g || T > 64 || (T & (T - 1)) || (key & KEY_MODE_MASK && T == 0) || (key & KEY_MODE_MASK) == KEY_MODE_MASK) return 1;
     g->forced_T = key;
     return 0;
 }
@@ -599,14 +607,14 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
     std::lock_guard<std::mutex> lk(g->mu);
     Program tmp;
     const Program* p = nullptr;
-    if ((T & ~KEY_DIVIDER) == 64) T = 64;
+    if ((T & ~KEY_MODE_MASK) == 64) T = 64;
     auto it = g->progs.find(T);
     std::string err;
     if (it != g->progs.end()) {
         p = &it->second->host;
     } else {
         if (!g->has_graph) return fail(status, "imported handle has no program for that tile width");
-        if (!compile_program(g->graph, T & ~KEY_DIVIDER, (T & KEY_DIVIDER) != 0, tmp, err)) return fail(status, err);
+        if (!compile_program(g->graph, T & ~KEY_MODE_MASK, key_divider_waves(T), tmp, err)) return fail(status, err);
         p = &tmp;
     }
     std::vector<uint8_t> b = program_to_blob(*p);
@@ -668,7 +676,7 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     err = check_device();
     if (err.empty()) err = upload_program(*dp);
     if (!err.empty()) return fail(status, err);
-    const uint32_t T = dp->host.T | (dp->host.divider ? KEY_DIVIDER : 0u);
+    const uint32_t T = dp->host.T | (dp->host.divider == 4 ? KEY_GROUP : dp->host.divider ? KEY_DIVIDER : 0u);
     g->progs[T] = std::move(dp);
     *out = g.release();
     set_status(status, OK, "");

@@ -41,7 +41,7 @@ typedef struct {
   uint64_t n_slots;          /* value slots per set */
   float interp_ms;           /* HIP-event time of the interpreter kernel(s), on the launch stream */
   float pack_ms;             /* HIP-event time of the witness pack kernel(s) */
-  uint32_t divider;          /* 1: the last call ran programs with the asynchronous divider wave */
+  uint32_t divider;          /* interpreter waves per divider wave in the last call's programs: 0 (none), 1 or 4 */
   uint32_t reserved;
 } gwb_timing_t;
 
@@ -68,6 +68,9 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
  * of two in 1..64), optionally OR'ed with GWB_TILE_ASYNC_DIVIDER = programs for the asynchronous divider wave (one
  * extra wavefront per tile serves the field divisions while the interpreter wave goes on; widths below 64). */
 #define GWB_TILE_ASYNC_DIVIDER 0x100u
+/* ... or with GWB_TILE_GROUP_DIVIDER = one divider wave per FOUR interpreter waves, which packs their division requests
+ * into the lanes of one inversion (throughput regime, widths up to 32). */
+#define GWB_TILE_GROUP_DIVIDER 0x200u
 /* 0 = choose from the batch size (default); else a program key */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
 /* the program key the library chooses for a batch of this size */

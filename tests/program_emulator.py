@@ -46,6 +46,8 @@ class Blob:
         self.consts = [sum(k[8 * i + j] << (32 * j) for j in range(8)) * R_INV % model.M for i in range(self.n_const)]
         assert self.n_const >= 1 and self.consts[-1] == 0  # trailing dummy entry (prefetch target)
         self.witness_refs = take(self.n_witness)
+        self.div_lanes = take(self.n_div_requests)
+        assert self.divider in (0, 1, 4) and pos <= len(data)  # (an exported blob carries the input map behind the program)
 
 
 def run(blob: Blob, inputs_row):
@@ -132,6 +134,7 @@ def run(blob: Blob, inputs_row):
             results.append((dst, v))
         if name == "DIVREQ":
             mailbox = request
+            assert blob.div_lanes[n_requests] == cnt * T <= (64 if blob.divider == 1 else 32), "request must fit the mailbox"
             n_requests += 1
         elif name == "DIVGET":
             mailbox = None

@@ -27,9 +27,10 @@ def _rand_row(rnd, n, small=0.3):
 
 
 DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER
+GROUP = 0x200    # GWB_TILE_GROUP_DIVIDER
 
 
-def _check(pkg, data, rows, tiles=(1, 4, 64, 1 | DIVIDER, 4 | DIVIDER)):
+def _check(pkg, data, rows, tiles=(1, 4, 64, 1 | DIVIDER, 4 | DIVIDER, 4 | GROUP)):
     g = pkg.Graph(data)
     og = cbind.Graph(data)
     inp = cbind.ints_to_array(rows)
@@ -147,14 +148,14 @@ def test_compiler_rewrites_on_chain_heavy_graphs(pkg):
     for seed in range(4):
         b = C.build_chain_heavy(seed)
         rows = [[1] + [rnd.choice([0, 1, M - 1, rnd.randrange(M)]) for _ in range(5)] for _ in range(37)]
-        _check(pkg, b.to_bin(), rows, tiles=(1, 2, 16, 64, 2 | DIVIDER, 8 | DIVIDER))
+        _check(pkg, b.to_bin(), rows, tiles=(1, 2, 16, 64, 2 | DIVIDER, 8 | DIVIDER, 1 | GROUP, 8 | GROUP))
 
 
 def test_gadgets_and_ragged_batches(pkg):
     rnd = random.Random(5)
     data = C.build_gadgets().to_bin()
     for n in (1, 2, 63, 64, 65, 130):  # tails of every tile width
-        _check(pkg, data, [_rand_row(rnd, 7) for _ in range(n)], tiles=(1, 2, 4, 8, 16, 32, 64, 2 | DIVIDER, 32 | DIVIDER))
+        _check(pkg, data, [_rand_row(rnd, 7) for _ in range(n)], tiles=(1, 2, 4, 8, 16, 32, 64, 2 | DIVIDER, 32 | DIVIDER, 2 | GROUP, 32 | GROUP))
     g = pkg.Graph(data)
     w, s = g.calc_witness_batch(np.zeros((0, g.n_inputs, 32), dtype=np.uint8))  # empty batch
     assert w.shape == (0, g.n_witness, 32) and s.shape == (0,)
@@ -223,7 +224,7 @@ def test_authv2_class_full_size_batch_1024(pkg):
     d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device="cuda")
     d_st = torch.zeros(B, dtype=torch.int32, device="cuda")
     digests = []
-    for tw in (0, 1, 64, 2, 2 | DIVIDER):  # 0 = the library's choice (asynchronous divider at this batch size)
+    for tw in (0, 1, 64, 2, 2 | DIVIDER, 4 | GROUP):  # 0 = the library's choice (asynchronous divider at this batch size)
         g.set_tile_width(tw)
         d_out.zero_()
         g.calc_witness_batch_device(d_in, d_out, d_st)

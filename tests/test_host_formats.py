@@ -149,14 +149,16 @@ def test_wtns_framing(pkg):
 
 
 DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER: programs for the asynchronous divider wave
+GROUP = 0x200    # GWB_TILE_GROUP_DIVIDER: one divider wave per four interpreter waves
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64, 1 | DIVIDER, 2 | DIVIDER, 8 | DIVIDER, 32 | DIVIDER])
+@pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64, 1 | DIVIDER, 2 | DIVIDER, 8 | DIVIDER, 32 | DIVIDER,
+                                  1 | GROUP, 4 | GROUP, 32 | GROUP])
 def test_graph_compiler_emulated(pkg, tile):
     """Level scheduling, bundling, slot reuse and operand encoding for every tile width and both division
     strategies (host logic only)."""
     rnd = random.Random(tile)
-    key, tile = tile, tile & ~DIVIDER
+    key, tile = tile, tile & 0xff
     cases = [(C.build_gadgets(), 7), (C.build_poseidon(2), 3), (C.build_bigint_class(k=3, rounds=2), 8)] + \
             [(C.build_random_dag(s, n_ops=250, panic_free=(s % 2 == 0)), 7) for s in range(6)]
     for b, n_in in cases:
@@ -164,9 +166,9 @@ def test_graph_compiler_emulated(pkg, tile):
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
         g = pkg.Graph(data)
         blob = pe.Blob(g.export_blob(key))
-        assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 0)
+        assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 4 if key & GROUP else 0)
         n_div = sum(1 for n in nodes if n[0] == "Duo" and n[1] == "Div")
-        if key & DIVIDER:
+        if key & (DIVIDER | GROUP):
             assert blob.stats["class_nodes"][9] == blob.stats["class_nodes"][10] == n_div and blob.stats["class_nodes"][3] == 0
         else:
             assert blob.stats["class_nodes"][3] == n_div and blob.n_div_requests == 0
@@ -242,7 +244,7 @@ def test_power_of_two_division_rewrite_is_exact(pkg):
         assert pe.run(blob, [1, xv])[0] == model.evaluate(nodes, [1, xv], wit)
 
 
-@pytest.mark.parametrize("key", [2, 2 | DIVIDER, 16])
+@pytest.mark.parametrize("key", [2, 2 | DIVIDER, 16, 4 | GROUP])
 def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
     """Tree-height reduction, shared subexpressions, dead-node elimination, linear riders in multiplication bundles and
     request/collect divisions: long Add / Mul chains with constants, repeated operands, witness elements in the middle of

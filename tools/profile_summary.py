@@ -49,8 +49,8 @@ def main():
     interp = [d for d in disp if "interp_kernel" in d[0]]
     pack = [d for d in disp if "pack_kernel" in d[0]]
     tile = int(interp[0][0].split("interp_kernel<")[1].split(",")[0])
-    divider = interp[0][0].split("interp_kernel<")[1].split(">")[0].split(",")[2].strip() == "true"
-    summary = {"config": {"graph": a.graph, "batch_per_gpu": a.batch, "tile_width": tile, "async_divider_wave": divider},
+    divider = int(interp[0][0].split("interp_kernel<")[1].split(">")[0].split(",")[2].strip())
+    summary = {"config": {"graph": a.graph, "batch_per_gpu": a.batch, "tile_width": tile, "interpreter_waves_per_divider_wave": divider},
                "source": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* passes of "
                          "`python3 bench.py --steps N --warmup 1 --cpu-sample 0 --extra-batch 0`, one pass per command",
                "kernels": {"interp": {"name": interp[0][0].split("(")[0], "launches": len(interp),
