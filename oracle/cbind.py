@@ -37,6 +37,9 @@ def lib():
         L.orc_evaluate_batch.restype = ctypes.c_int
         L.orc_evaluate_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_evaluate_batch_threads.restype = ctypes.c_int
+        L.orc_evaluate_batch_threads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         L.orc_eval_op.restype = ctypes.c_int
         L.orc_eval_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
                                   ctypes.c_char_p]
@@ -107,6 +110,18 @@ class Graph:
         t0 = time.perf_counter()
         lib().orc_evaluate_batch(self._h, inputs.ctypes.data, n_in, b, out.ctypes.data, status.ctypes.data)
         return time.perf_counter() - t0, out, status
+
+
+def time_batch_threads(graph, inputs, n_threads):
+    """The batch over `n_threads` host threads (contiguous shares): seconds, witness, status."""
+    import time
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
+    b, n_in = inputs.shape[0], inputs.shape[1]
+    out = np.zeros((b, graph.n_witness, 32), dtype=np.uint8)
+    status = np.zeros(b, dtype=np.int32)
+    t0 = time.perf_counter()
+    lib().orc_evaluate_batch_threads(graph._h, inputs.ctypes.data, n_in, b, out.ctypes.data, status.ctypes.data, n_threads)
+    return time.perf_counter() - t0, out, status
 
 
 def eval_op(kind, op, a, b=None, c=None):

@@ -18,6 +18,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 typedef unsigned __int128 u128;
@@ -420,6 +421,41 @@ int orc_evaluate_batch(const graph_t *g, const uint8_t *inputs, uint64_t n_input
         any |= rc;
     }
     free(values);
+    return any;
+}
+
+/* The same loop spread over `n_threads` host threads, contiguous shares of the batch (bench.py cpu_baseline, the
+ * all-cores courtesy figure of SURVEY 8(d)(ii); the reference itself is single-threaded). */
+typedef struct { const graph_t *g; const uint8_t *inputs; uint64_t n_inputs, lo, hi; uint8_t *out; int32_t *status; int any; } orc_share_t;
+static void *orc_share_run(void *arg) {
+    orc_share_t *s = (orc_share_t *)arg;
+    if (s->hi > s->lo)
+        s->any = orc_evaluate_batch(s->g, s->inputs + s->lo * s->n_inputs * 32, s->n_inputs, s->hi - s->lo,
+                                    s->out ? s->out + s->lo * s->g->n_witness * 32 : NULL, s->status ? s->status + s->lo : NULL);
+    return NULL;
+}
+int orc_evaluate_batch_threads(const graph_t *g, const uint8_t *inputs, uint64_t n_inputs, uint64_t count, uint8_t *out,
+                               int32_t *status, uint32_t n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    pthread_t *th = malloc(n_threads * sizeof(pthread_t));
+    orc_share_t *sh = calloc(n_threads, sizeof(orc_share_t));
+    int any = 0;
+    for (uint32_t i = 0; i < n_threads; ++i) {
+        sh[i] = (orc_share_t){g, inputs, n_inputs, count * i / n_threads, count * (i + 1) / n_threads, out, status, 0};
+        if (pthread_create(&th[i], NULL, orc_share_run, &sh[i]) != 0) {  /* run the share here instead */
+            orc_share_run(&sh[i]);
+            th[i] = 0;
+            sh[i].lo = sh[i].hi = 0;
+            sh[i].any |= 0x100;
+        }
+    }
+    for (uint32_t i = 0; i < n_threads; ++i) {
+        if (!(sh[i].any & 0x100)) pthread_join(th[i], NULL);
+        any |= sh[i].any & 0xff;
+    }
+    free(th);
+    free(sh);
     return any;
 }
 
