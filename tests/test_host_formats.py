@@ -260,3 +260,33 @@ def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
             row = [1] + [rnd.choice([0, 1, model.M - 1, rnd.randrange(model.M)]) for _ in range(5)]
             got, st = pe.run(blob, row)
             assert st == 0 and got == model.evaluate(nodes, row, wit)
+
+
+def test_loader_and_compiler_under_sanitizers(tmp_path):
+    """graph.cc + compile.cc (loader, exact rewrites, scheduler, encoder, blob) under ASan + UBSan on generated graphs,
+    a fuzzed DAG, the chain-heavy graphs and a few corrupted files (no GPU involved)."""
+    import subprocess
+    src = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc")
+    exe = str(tmp_path / "compile_sanitize")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-Wno-unknown-pragmas", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "compile_sanitize.cc"),
+                           os.path.join(src, "graph.cc"), os.path.join(src, "compile.cc")])
+    files = []
+    cases = {"gadgets": C.build_gadgets(), "poseidon3": C.build_poseidon(3), "dag": C.build_random_dag(5, n_ops=300),
+             "chains": C.build_chain_heavy(3), "bigint": C.build_bigint_class(k=3, rounds=2)}
+    rnd = random.Random(9)
+    for name, b in cases.items():
+        data = b.to_bin()
+        f = tmp_path / (name + ".bin")
+        f.write_bytes(data)
+        files.append(str(f))
+        for k in range(3):  # corrupted variants: flipped byte, truncation
+            bad = bytearray(data)
+            bad[rnd.randrange(14, len(bad))] ^= 1 << rnd.randrange(8)
+            g = tmp_path / ("%s_bad%d.bin" % (name, k))
+            g.write_bytes(bytes(bad[:len(bad) - (k * 7)]))
+            files.append(str(g))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe] + files, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "done rc=0" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
