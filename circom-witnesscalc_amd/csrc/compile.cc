@@ -23,7 +23,7 @@ static int class_of(const Node& n) {
                 case OP_ADD: case OP_SUB: return C_LIN;
                 case OP_EQ: case OP_NEQ: case OP_LAND: case OP_LOR: return C_CMPZ;
                 case OP_LT: case OP_GT: case OP_LEQ: case OP_GEQ: return C_CMPS;
-                case OP_SHL: case OP_SHR: case OP_BOR: case OP_BAND: case OP_BXOR: return C_BIT;
+                case OP_SHL: case OP_SHR: case OP_BOR: case OP_BAND: case OP_BXOR: case OP_BITX: return C_BIT;
                 case OP_IDIV: case OP_MOD: return C_IDIVMOD;
             }
     }
@@ -69,6 +69,68 @@ static void rewrite_pow2_divisions(Graph& g) {
         n2.op = n2.op == OP_IDIV ? OP_SHR : OP_BAND;
         n2.b = it->second;
     }
+}
+
+// Exact fusion of the bit-decomposition idiom (circomlib Num2Bits: out[i] <-- (in >> i) & 1): Band(Shr(a, k), 1) with a
+// constant k < 254 whose Shr has no other user becomes one BITX node.  The pair costs two BIT bundles with four
+// conversions out of and one into Montgomery form (graph.rs:637-672 then :674-687); the fused node converts once and
+// its result is a boolean.  Shr cannot fail, so dropping the intermediate node loses no error.
+static void fuse_bit_extract(Graph& g) {
+    const size_t N = g.nodes.size();
+    std::vector<uint32_t> uses(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) uses[n.a]++;
+        if (ar >= 2) uses[n.b]++;
+        if (ar >= 3) uses[n.c]++;
+    }
+    for (uint32_t w : g.witness_signals) uses[w]++;
+    auto small_const = [&](uint32_t idx, uint32_t& value) {
+        const Node& c = g.nodes[idx];
+        if (c.kind != N_CONST) return false;
+        const Fr& v = g.const_values[c.a];
+        for (int q = 1; q < 8; ++q)
+            if (v.v[q]) return false;
+        value = v.v[0];
+        return true;
+    };
+    std::vector<uint8_t> dead(N, 0);
+    bool any = false;
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind != N_DUO || n.op != OP_BAND) continue;
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t s = side ? n.b : n.a, c = side ? n.a : n.b;
+            uint32_t one = 0, k = 0;
+            if (!small_const(c, one) || one != 1u) continue;
+            const Node& sh = g.nodes[s];
+            if (sh.kind != N_DUO || sh.op != OP_SHR || uses[s] != 1 || !small_const(sh.b, k) || k >= 254u) continue;
+            n = Node{N_DUO, OP_BITX, sh.a, sh.b, 0};
+            dead[s] = 1;
+            any = true;
+            break;
+        }
+    }
+    if (!any) return;
+    std::vector<uint32_t> pos(N, 0xffffffffu);
+    std::vector<Node> kept;
+    kept.reserve(N);
+    // (constants appended by rewrite_pow2_divisions sit behind their users: number the survivors first)
+    uint32_t next = 0;
+    for (size_t i = 0; i < N; ++i)
+        if (!dead[i]) pos[i] = next++;
+    for (size_t i = 0; i < N; ++i) {
+        if (dead[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        kept.push_back(n);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
 }
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
@@ -209,7 +271,27 @@ static void reduce_tree_height(Graph& g) {
     g.nodes.swap(kept);
 }
 
-bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& out, std::string& err) {
+double program_wave_cycles(const Program& p) {
+    static const double kCycles[C_COUNT] = {5000, 2350, 1150, 73500, 1250, 6000, 5600, 40000, 1900, 1450, 1450};
+    double c = 0;
+    for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)p.stats.class_bundles[k];
+    return c - (kCycles[C_BIT] - 1500.0) * (double)p.stats.n_bitx_bundles;
+}
+
+static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, Program& out, std::string& err);
+
+// The list scheduler is a heuristic and exact rewrites shift how the chains of a graph line up in bundles: the program
+// is compiled with and without the bit-extract fusion and the cheaper schedule (program_wave_cycles) is kept.
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err) {
+    if (!compile_variant(g, T, divider, true, out, err)) return false;
+    if (out.stats.n_bitx_nodes == 0 || getenv("CWC_NO_BIT_FUSION") || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
+    Program alt;
+    std::string err2;
+    if (compile_variant(g, T, divider, false, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+    return true;
+}
+
+static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, Program& out, std::string& err) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
@@ -288,6 +370,11 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
     st.depth = depth;
 
     // ---- exact depth-reducing rewrite (the statistics above describe the graph as loaded) ----
+    if (bit_fusion && !getenv("CWC_NO_BIT_FUSION")) {
+        fuse_bit_extract(g);
+        N = g.nodes.size();
+        for (const Node& n : g.nodes) st.n_bitx_nodes += n.kind == N_DUO && n.op == OP_BITX;
+    }
     if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
         reduce_tree_height(g);
         N = g.nodes.size();
@@ -392,12 +479,13 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
             for (uint32_t u : users[i]) d = std::min<uint32_t>(d, dist_to_div[u] + 1u);
             dist_to_div[i] = (uint16_t)std::min<uint32_t>(d, kFar);
         }
+        const bool tie_reverse = getenv("CWC_SCHED_TIE_REVERSE") != nullptr;
         // ready heaps per class, keyed by (height, -index)
         typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
         std::vector<std::vector<Key>> heap(C_COUNT);
         auto push = [&](uint32_t i) {
             auto& h = heap[class_of(g.nodes[i])];
-            h.push_back(Key(height[i], ~i));
+            h.push_back(Key(height[i], tie_reverse ? i : ~i));
             std::push_heap(h.begin(), h.end());
         };
         for (size_t i = 0; i < N; ++i)
@@ -467,7 +555,7 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
                     // the heap top is the class's most urgent node; scan the ready nodes of the class for one that
                     // is about to reach a division
                     bool near = false;
-                    for (const Key& k : heap[c]) near |= dist_to_div[~k.second] <= div_wait_ops;
+                    for (const Key& k : heap[c]) near |= dist_to_div[tie_reverse ? k.second : ~k.second] <= div_wait_ops;
                     if (near && (other < 0 || heap[c].front() > heap[other].front())) other = c;
                 }
                 if (other >= 0) best = other;
@@ -480,7 +568,7 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
             const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : G;
             while (!h.empty() && picked.size() < cap) {
                 std::pop_heap(h.begin(), h.end());
-                picked.push_back(~h.back().second);
+                picked.push_back(tie_reverse ? h.back().second : ~h.back().second);
                 h.pop_back();
             }
             std::sort(picked.begin(), picked.end());
@@ -492,7 +580,7 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
                 std::vector<uint32_t> riders;
                 while (!hl.empty() && picked.size() + riders.size() < G) {
                     std::pop_heap(hl.begin(), hl.end());
-                    riders.push_back(~hl.back().second);
+                    riders.push_back(tie_reverse ? hl.back().second : ~hl.back().second);
                     hl.pop_back();
                 }
                 std::sort(riders.begin(), riders.end());
@@ -574,6 +662,7 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
             case OP_LT: return SUB_LT;     case OP_GT: return SUB_GT;     case OP_LEQ: return SUB_LEQ;   case OP_GEQ: return SUB_GEQ;
             case OP_SHL: return SUB_SHL;   case OP_SHR: return SUB_SHR;   case OP_BOR: return SUB_BOR;   case OP_BAND: return SUB_BAND;
             case OP_BXOR: return SUB_BXOR; case OP_IDIV: return SUB_IDIV; case OP_MOD: return SUB_MOD;
+            case OP_BITX: return SUB_BITX;
             default: return 0;  // Div: the class says it all
         }
     };
@@ -631,6 +720,10 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
                 case N_DUO:
                     ctrl |= sub_of(n.op);
                     enc_operand(n.a, 0);
+                    if (n.op == OP_BITX) {  // the shift amount travels in the b_lds field, no second operand is read
+                        lds[1] = g.const_values[g.nodes[n.b].a].v[0] * 16u;
+                        break;
+                    }
                     enc_operand(n.b, 1);
                     break;
                 case N_TRES:
@@ -655,6 +748,14 @@ bool compile_program(const Graph& g_in, uint32_t T, uint32_t divider, Program& o
                 const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK;
                 lin_bits |= sub == SUB_SUB ? HDR_LIN_SUB : sub == SUB_ADD ? HDR_LIN_ADD : 0u;
             }
+        if (cl == C_BIT) {
+            bool all = true;
+            for (uint32_t k = k0; k < k1; ++k) all = all && (ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK) == SUB_BITX;
+            if (all) {
+                lin_bits |= HDR_BITX_ALL;
+                st.n_bitx_bundles++;
+            }
+        }
         out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits;
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
@@ -702,7 +803,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 6;
+    h.version = 7;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -717,7 +818,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 6 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 7 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

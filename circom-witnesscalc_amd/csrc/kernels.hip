@@ -296,17 +296,32 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 break;
             }
             case C_BIT: {  // graph.rs:621-717
-                const Fr x = fr_from_mont(a_op), y = fr_from_mont(b_op);
+                const Fr x = fr_from_mont(a_op);
+                // compiler-made bit extract (a >> k) & 1 (Band(Shr(a, k), 1), graph.rs:637-672 + :674-687): k rides in
+                // the b_lds field, the result is a boolean -- no second conversion, no conversion back
+                const uint32_t kx = rec_hi.y >> 20;  // (b_lds = 16 * k)
+                const bool is_x = sub == SUB_BITX;
+                if (h & HDR_BITX_ALL) {
+                    const Fr e = u256_shr(x, kx);
+                    r = u256_select((e.v[0] & 1u) != 0u, fr_one(), fr_zero());
+                    break;
+                }
+                const Fr y = fr_from_mont(b_op);
                 uint32_t hi_or = 0;
 #pragma unroll
                 for (int i = 1; i < 8; ++i) hi_or |= y.v[i];
                 const bool big = hi_or != 0 || y.v[0] >= 254u;  // b >= MODULUS_BIT_SIZE -> 0
-                const uint32_t n = big ? 0u : y.v[0];
+                const uint32_t n = is_x ? kx : big ? 0u : y.v[0];
                 Fr d;
-                if (sub == SUB_SHL || sub == SUB_SHR) {
+                if (sub == SUB_SHL || sub == SUB_SHR || is_x) {
                     const Fr sl = u256_shl(x, n), sr = u256_shr(x, n);
                     d = u256_select(sub == SUB_SHL, sl, sr);
-                    d = u256_select(big, fr_zero(), d);
+                    d = u256_select(big && !is_x, fr_zero(), d);
+                    if (is_x) {
+                        d.v[0] &= 1u;
+#pragma unroll
+                        for (int i = 1; i < 8; ++i) d.v[i] = 0;
+                    }
                     if (sub == SUB_SHL && !u256_lt(d, fr_p())) {  // graph.rs:634 unwrap on None
                         if (active) err_bits |= ST_SHL_OVERFLOW;
                         d = fr_zero();

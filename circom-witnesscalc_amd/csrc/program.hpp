@@ -22,6 +22,8 @@ struct ProgramStats {
     uint64_t class_nodes[C_COUNT] = {0};
     uint64_t class_bundles[C_COUNT] = {0};
     uint64_t n_op_compiled = 0;         // operation nodes after the depth-reducing rewrite (>= n_op is possible)
+    uint64_t n_bitx_bundles = 0;        // BIT bundles made of bit-extract nodes only (cheap path)
+    uint64_t n_bitx_nodes = 0;          // bit-extract nodes made by the compiler
     uint64_t algorithmic_bytes_per_set = 0;  // 32*[sum_ops(arity+1) + 2*n_input_nodes + 2*W]  
 };
 
@@ -48,6 +50,10 @@ static const uint32_t KEY_DIVIDER = 0x100u;  // one divider wave per interpreter
 static const uint32_t KEY_GROUP = 0x200u;    // one divider wave per four interpreter waves
 static const uint32_t KEY_MODE_MASK = KEY_DIVIDER | KEY_GROUP;
 static inline uint32_t key_divider_waves(uint32_t key) { return key & KEY_GROUP ? 4u : key & KEY_DIVIDER ? 1u : 0u; }
+
+// Lone-wave shader cycles of a program's bundles (measured per class on MI355X, profiles/r01_class_profile.txt): what the
+// compiler uses to choose between schedule variants and the runtime to choose a program for a batch.
+double program_wave_cycles(const Program& p);
 
 // pointer-free serialisation (what is broadcast between GPUs)
 std::vector<uint8_t> program_to_blob(const Program& p);

@@ -57,7 +57,7 @@ enum BundleClass : uint32_t {
 //                           INPUT bundles: index into the set's input row.
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
-static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12;
+static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
 static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
 static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;
@@ -78,6 +78,7 @@ enum SubOp : uint32_t {
     SUB_EQ = 0, SUB_NEQ = 1, SUB_LAND = 2, SUB_LOR = 3,            // C_CMPZ
     SUB_LT = 0, SUB_GT = 1, SUB_LEQ = 2, SUB_GEQ = 3,              // C_CMPS
     SUB_SHL = 0, SUB_SHR = 1, SUB_BOR = 2, SUB_BAND = 3, SUB_BXOR = 4,  // C_BIT
+    SUB_BITX = 5,  // C_BIT: (a >> k) & 1, k = b_lds / 16 (no second operand is read); header bit 13: every lane is one
     SUB_IDIV = 0, SUB_MOD = 1,                                     // C_IDIVMOD
 };
 

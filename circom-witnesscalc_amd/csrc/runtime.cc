@@ -170,9 +170,7 @@ std::string check_device() {
 // per bundle class, profiles/r01_class_profile.txt); waves slow each other down as the CUs fill (measured on the
 // authV2-class graph: x1.0 at 512 waves, x1.4 at 1024, x1.6 at 2048), and beyond 2048 waves they run in rounds.
 double estimate_cycles(const Program& p, size_t batch) {
-    static const double kCycles[C_COUNT] = {5000, 2350, 1150, 73500, 1250, 6000, 5600, 40000, 1900, 1450, 1450};
-    double per_wave = 0;
-    for (int c = 0; c < (int)C_COUNT; ++c) per_wave += kCycles[c] * (double)p.stats.class_bundles[c];
+    const double per_wave = program_wave_cycles(p);
     const double waves = (double)((batch + p.T - 1) / p.T);
     // divider waves are busy about half of the time (W = 1) and take a wave slot of their CU
     const double with_dividers = waves * (p.divider == 1 ? 1.3 : p.divider == 4 ? 1.1 : 1.0);

@@ -15,10 +15,10 @@ LDS_RING_OFF = 0
 LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES
 LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES
 SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS": ["Lt", "Gt", "Leq", "Geq"],
-             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Add", "Sub", "Mul"], "DIV": ["Div"]}
+             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor", "BitX"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Add", "Sub", "Mul"], "DIV": ["Div"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I30Q"
+HDR_FMT = "<12I32Q"
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET"]
 
@@ -30,7 +30,7 @@ class Blob:
          self.n_witness, self.divider, self.n_div_requests, _res) = h[:12]
         st = h[12:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:17], class_bundles=st[17:28], n_op_compiled=st[28], algorithmic_bytes_per_set=st[29])
+                          class_nodes=st[6:17], class_bundles=st[17:28], n_op_compiled=st[28], n_bitx_bundles=st[29], n_bitx_nodes=st[30], algorithmic_bytes_per_set=st[31])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -82,7 +82,7 @@ def run(blob: Blob, inputs_row):
     for b in range(blob.n_bundles):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
-        assert h >> 13 == 0 and 1 <= cnt <= G
+        assert h >> 14 == 0 and 1 <= cnt <= G
         name = CLASS_NAMES[cls]
         stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
@@ -97,7 +97,12 @@ def run(blob: Blob, inputs_row):
             ctrl, dst = dctl & CTRL_MASK, dctl & ~CTRL_MASK
             assert bool(ctrl & CTRL_ACTIVE) == (j < cnt)
             ops = []
+            bitx = name == "BIT" and (ctrl & CTRL_SUB_MASK) == 5 and j < cnt  # (a >> k) & 1 with k = b_lds / 16
             for q, (off, la) in enumerate(((a_off, lds & 0xFFFF), (b_off, lds >> 16))):
+                if bitx and q == 1:
+                    assert off == zero_off and la % 16 == 0 and la // 16 < 254
+                    ops.append(la // 16)
+                    continue
                 own_cell = stage + 2 * q * LDS_HALF_BYTES + j * T * 16
                 if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
                     ops.append(mem_at(off, b - OPND_AHEAD - 1))
@@ -124,6 +129,9 @@ def run(blob: Blob, inputs_row):
                 v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
             else:
                 op = SUB_NAMES[name][sub]
+                if op == "BitX":
+                    results.append((dst, (ops[0] >> ops[1]) & 1))
+                    continue
                 if name in ("LIN", "MUL") and op != "Mul":
                     lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
                 try:
@@ -140,7 +148,10 @@ def run(blob: Blob, inputs_row):
             mailbox = None
         else:
             assert name != "DIV" or not blob.divider
-        assert (h >> 11) == (lin_seen >> 11), "LIN header bits must describe the records"
+        if name == "BIT":
+            all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
+            assert ((h >> 13) & 1) == (1 if all_x else 0), "BITX header bit must describe the records"
+        assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
         for d, v in results:
