@@ -146,9 +146,8 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 120, 110, 80
 // round).  The intermediate nodes of the chain are still computed wherever something else (a witness element, another
 // node) needs them; common subexpressions are shared; nodes that end up unused are dropped.
 // Only Add/Mul nodes are touched, so every operation that can fail (graph.rs:634, :686-716) survives unchanged.
-static void reduce_tree_height(Graph& g) {
+static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
     const size_t N = g.nodes.size();
-    const size_t kMaxLeaves = 8;
     Graph h;
     h.const_values = g.const_values;
     std::vector<uint32_t> m(N, 0xffffffffu);  // old index -> new index
@@ -376,7 +375,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (const Node& n : g.nodes) st.n_bitx_nodes += n.kind == N_DUO && n.op == OP_BITX;
     }
     if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
-        reduce_tree_height(g);
+        // whole chains at T = 1 (small batches: depth is everything); at most 8 leaves per tree otherwise, where the
+        // extra nodes of wide trees cost lanes and memory traffic (measured on sha256_512: 293 k vs 265 k wit/s at 4096 sets)
+        reduce_tree_height(g, G >= 64 ? 64 : 8);
         N = g.nodes.size();
     }
     for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
