@@ -1,5 +1,7 @@
-// Host graph compiler: validation, level scheduling into same-class bundles, liveness-based slot
-// allocation, program encoding.  See program.hpp.
+// Host graph compiler: validation, exact rewrites (power-of-two divisions, bit-extract fusion, tree-height reduction with
+// shared subexpressions and dead-node elimination), critical-path list scheduling into same-class bundles (linear riders,
+// request / collect divisions for the divider waves), operand routing (LDS ring vs. staged memory), liveness-based slot
+// allocation, program encoding (format v4) and the pointer-free program blob.  See program.hpp / program_dev.h.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -418,7 +420,6 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     } else {
         const uint32_t* class_cost = kClassCost;
         std::vector<uint64_t> height(N, 0);
-        std::vector<uint32_t> n_users_left;  // unused placeholder to keep vectors grouped
         std::vector<uint32_t> indeg(N, 0);
         std::vector<std::vector<uint32_t>> users;  // adjacency (only non-const producers)
         users.resize(N);
