@@ -558,4 +558,89 @@ FRD void u256_divrem(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t top) {
     }
 }
 
+// Digit-wise division (schoolbook / Knuth D with 32-bit digits): q = floor(a / b), rem = a mod b for b != 0.
+// Both operands are shifted so that the divisor's top bit sits at bit 255: every quotient digit is then estimated from
+// the same register positions (runtime-indexed register arrays would spill to scratch on the GPU), and the 512-bit
+// shifted dividend is consumed 32 bits per step.  `digits` (1..8) = how many low quotient digits can be non-zero:
+// ceil((bitlen(a) - bitlen(b) + 1) / 32), or the wave-wide maximum of that so that the loop stays uniform (0: a < b
+// everywhere).  A step costs ~80 VALU instructions against ~35 per BIT of the restoring division above.
+FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t digits) {
+    const uint32_t L = u256_bitlen(b);   // 1..256 (callers pass b != 0)
+    const uint32_t sh = 256u - L;        // divisor shifted left by sh has its top bit set
+    const Fr bn = sh ? u256_shl(b, sh) : b;
+    // a << sh as 512 bits: hi:lo (sh = 0: hi = 0)
+    Fr lo = sh ? u256_shl(a, sh) : a;
+    uint32_t R[9];
+    {
+        const Fr hi = sh ? u256_shr(a, L) : fr_zero();  // < 2^(256-L) <= bn
+#pragma unroll
+        for (int i = 0; i < 8; ++i) R[i] = hi.v[i];
+        R[8] = 0;
+    }
+    q = fr_zero();
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        // R = R * 2^32 + next dividend digit   (R < bn before, < bn * 2^32 after)
+#pragma unroll
+        for (int i = 8; i > 0; --i) R[i] = R[i - 1];
+        R[0] = lo.v[j];
+        if ((uint32_t)j >= digits) continue;  // the quotient digit is known to be zero (uniform across the wave)
+        // qhat = floor(top 64 bits of R / top 32 bits of bn), capped at 2^32 - 1: a floating-point estimate (within one
+        // of the floor) corrected with exact 64-bit arithmetic; the true digit is then within [qhat - 2, qhat] (Knuth D)
+        const uint32_t d = bn.v[7];
+        uint32_t qhat;
+        {
+            const uint64_t n64 = ((uint64_t)R[8] << 32) | R[7];
+            const double n = (double)R[8] * 4294967296.0 + (double)R[7];
+            double e = n / (double)d;
+            e = e < 4294967295.0 ? e : 4294967295.0;
+            uint32_t est = (uint32_t)e;
+#if defined(CWC_TEST_PERTURB_QHAT)
+            if ((CWC_TEST_PERTURB_QHAT) > 0 ? est != 0xffffffffu : est != 0u) est += (uint32_t)(CWC_TEST_PERTURB_QHAT);  // (host test: the correction below must absorb an estimate that is off by one)
+#endif
+            const int64_t r = (int64_t)(n64 - (uint64_t)est * d);
+            est = r < 0 ? est - 1u : ((uint64_t)r >= d ? est + 1u : est);
+            qhat = R[8] >= d ? 0xffffffffu : est;
+        }
+        // R -= qhat * bn
+        uint32_t P[9];
+        {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                c += (uint64_t)qhat * bn.v[i];
+                P[i] = (uint32_t)c;
+                c >>= 32;
+            }
+            P[8] = (uint32_t)c;
+        }
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const uint64_t t = (uint64_t)R[i] - P[i] - borrow;
+            R[i] = (uint32_t)t;
+            borrow = (uint32_t)(t >> 63);
+        }
+        // too large (R negative): add the divisor back, at most twice
+#pragma unroll
+        for (int fix = 0; fix < 2; ++fix) {
+            const bool neg = borrow != 0;
+            uint32_t carry = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const uint64_t t = (uint64_t)R[i] + (neg ? (i < 8 ? bn.v[i] : 0u) : 0u) + carry;
+                R[i] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+            borrow = neg && !carry ? 1u : 0u;  // still negative iff the addition did not wrap around
+            qhat -= neg ? 1u : 0u;
+        }
+        q.v[j] = qhat;
+    }
+    Fr r8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r8.v[i] = R[i];
+    rem = sh ? u256_shr(r8, sh) : r8;
+}
+
 }  // namespace cwc

@@ -351,17 +351,17 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 const bool yz = u256_is_zero(y);
                 Fr ys = y;
                 ys.v[0] |= yz ? 1u : 0u;
-                // trip count = length of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 (0 when x < y)
+                // quotient digits (32 bits each) of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 bits
                 const uint32_t lx = u256_bitlen(x), ly = u256_bitlen(ys);
-                uint32_t top = lx >= ly ? lx - ly + 1u : 0u;
+                uint32_t dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;
 #pragma unroll
                 for (int off = 32; off; off >>= 1) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)top, off);
-                    top = top > o ? top : o;
+                    const uint32_t o = (uint32_t)__shfl_xor((int)dig, off);
+                    dig = dig > o ? dig : o;
                 }
-                top = (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
+                dig = (uint32_t)__builtin_amdgcn_readfirstlane((int)dig);
                 Fr q, rem;
-                u256_divrem(q, rem, x, ys, top);
+                u256_divrem_digits(q, rem, x, ys, dig);
                 const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));
                 r = fr_to_mont(d);
                 break;

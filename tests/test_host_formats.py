@@ -290,3 +290,16 @@ def test_loader_and_compiler_under_sanitizers(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     out = subprocess.run([exe] + files, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "done rc=0" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("perturb", [None, 1, -1])
+def test_digitwise_division_on_host(tmp_path, perturb):
+    """u256_divrem_digits (Idiv / Mod bundles) == the bit-serial division, also when the floating-point quotient-digit
+    estimate is off by one in either direction."""
+    import subprocess
+    exe = str(tmp_path / "div_digits_test")
+    flags = [] if perturb is None else ["-DCWC_TEST_PERTURB_QHAT=%d" % perturb]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags +
+                          ["-o", exe, os.path.join(ROOT, "tests", "native", "div_digits_test.cc")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
