@@ -242,7 +242,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
                 const uint32_t idx = crefs[(size_t)b * G + j];
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + idx) * 2;
-                r = fr_to_mont(fr_from_u4(q[0], q[1]));
+                r = fr_mul_wave(fr_from_u4(q[0], q[1]), fr_r2(), pv);  // (any value below 2^256 is reduced: Fr::new)
                 break;
             }
             case C_DIVREQ: {  // hand the operands to the divider wave; this bundle has no result of its own
@@ -340,7 +340,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 // boolean-valued results (Num2Bits-style Band(x,1)) skip the Montgomery multiplication
                 const bool small = (d.v[0] < 2u) && ((d.v[1] | d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) == 0u);
                 if (wave_any(!small)) {
-                    r = fr_to_mont(d);
+                    r = fr_mul_wave(d, fr_r2(), pv);
                 } else {
                     r = u256_select(d.v[0] != 0u, fr_one(), fr_zero());
                 }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 Fr q, rem;
                 u256_divrem_digits(q, rem, x, ys, dig);
                 const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));
-                r = fr_to_mont(d);
+                r = fr_mul_wave(d, fr_r2(), pv);
                 break;
             }
             case C_TERN: {  // graph.rs:221-225  a == 0 ? c : b ; the third operand is always a memory reference
