@@ -56,6 +56,31 @@ FRD bool u256_eq(const Fr& a, const Fr& b) {
 // r = a + b, returns carry out
 // (clang's __builtin_addc / __builtin_subc lower to v_add_co / v_addc_co chains; the uint64 idiom below makes hipcc
 // emit 64-bit adds, sign extensions and moves -- ~110 instructions for one modular addition instead of ~35)
+// one limb of an add / subtract chain (clang: carry builtins, which hipcc turns into v_addc / v_subb; portable otherwise)
+FRD uint32_t adc32(uint32_t a, uint32_t b, uint32_t& carry) {
+#if defined(__clang__)
+    unsigned c = carry;
+    const uint32_t r = __builtin_addc(a, b, c, &c);
+    carry = c;
+    return r;
+#else
+    const uint64_t t = (uint64_t)a + b + carry;
+    carry = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+#endif
+}
+FRD uint32_t sbb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+#if defined(__clang__)
+    unsigned c = borrow;
+    const uint32_t r = __builtin_subc(a, b, c, &c);
+    borrow = c;
+    return r;
+#else
+    const uint64_t t = (uint64_t)a - b - borrow;
+    borrow = (uint32_t)(t >> 63);
+    return (uint32_t)t;
+#endif
+}
 FRD uint32_t u256_add(Fr& r, const Fr& a, const Fr& b) {
 #if defined(__clang__)
     unsigned c = 0;
@@ -616,22 +641,14 @@ FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t d
         }
         uint32_t borrow = 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const uint64_t t = (uint64_t)R[i] - P[i] - borrow;
-            R[i] = (uint32_t)t;
-            borrow = (uint32_t)(t >> 63);
-        }
+        for (int i = 0; i < 9; ++i) R[i] = sbb32(R[i], P[i], borrow);
         // too large (R negative): add the divisor back, at most twice
 #pragma unroll
         for (int fix = 0; fix < 2; ++fix) {
             const bool neg = borrow != 0;
             uint32_t carry = 0;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const uint64_t t = (uint64_t)R[i] + (neg ? (i < 8 ? bn.v[i] : 0u) : 0u) + carry;
-                R[i] = (uint32_t)t;
-                carry = (uint32_t)(t >> 32);
-            }
+            for (int i = 0; i < 9; ++i) R[i] = adc32(R[i], neg ? (i < 8 ? bn.v[i] : 0u) : 0u, carry);
             borrow = neg && !carry ? 1u : 0u;  // still negative iff the addition did not wrap around
             qhat -= neg ? 1u : 0u;
         }

@@ -7,12 +7,12 @@ import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
 kind = os.environ.get("PROBE_GRAPH", "authv2")
-b = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512)
+b = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else C.build_bigint_class(k=32, rounds=int(os.environ.get("BIGINT_ROUNDS", "400")))
 g = pkg.Graph(b.to_bin())
 B = int(os.environ.get("PROBE_B", "1024"))
 rng = np.random.default_rng(1)
 rows = np.frombuffer(rng.bytes(B * g.n_inputs * 32), dtype=np.uint8).reshape(B, g.n_inputs, 32).copy()
-if kind == "authv2":
+if kind != "sha256":
     rows[:, :, 31] &= 0x1f
 else:
     rows[:, :, 1:] = 0; rows[:, :, 0] &= 1
