@@ -393,6 +393,17 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             out.consts.insert(out.consts.end(), m.v, m.v + 8);
         }
     st.n_const = out.consts.size() / 8;
+    // canonical (non-Montgomery) copies of the constants that BIT-class nodes take as second operand (shift amounts,
+    // masks): a bundle whose second operands all are such constants skips their conversion (HDR_BIT_BCANON)
+    std::unordered_map<uint32_t, uint32_t> canon_const;  // constant node -> table index of its canonical copy
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        if (class_of(n) != C_BIT || n.op == OP_BITX || g.nodes[n.b].kind != N_CONST || canon_const.count(n.b)) continue;
+        canon_const[n.b] = (uint32_t)(out.consts.size() / 8);
+        const Fr& v = g.const_values[g.nodes[n.b].a];
+        out.consts.insert(out.consts.end(), v.v, v.v + 8);
+    }
+    const uint32_t zero_const = (uint32_t)(out.consts.size() / 8);  // index of the trailing dummy (value 0)
     out.consts.insert(out.consts.end(), 8, 0u);  // trailing dummy entry: the table is never empty (prefetch target)
     out.n_const = (uint32_t)(out.consts.size() / 8);
 
@@ -651,7 +662,6 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint32_t> free_slots;
     std::vector<uint32_t> dying;  // nodes whose slot is released after the current bundle
     uint32_t n_slots = 0;
-    const uint32_t zero_const = (uint32_t)st.n_const;  // index of the trailing dummy (value 0)
     const uint32_t zero_off = (uint32_t)((uint64_t)zero_const * slot_bytes);
     auto mem_off = [&](uint32_t producer) -> uint64_t {
         if (g.nodes[producer].kind == N_CONST) return (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes;
@@ -678,6 +688,15 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         st.class_nodes[cl] += cnt;
         dying.clear();
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
+        bool b_canon = cl == C_BIT;  // every second operand that is read is a constant with a canonical copy
+        bool b_read = false;
+        for (uint32_t k = k0; b_canon && k < k1; ++k) {
+            const Node& n = g.nodes[order[k] & ~REQ_FLAG];
+            if (n.op == OP_BITX) continue;
+            b_read = true;
+            b_canon = canon_const.count(n.b) != 0;
+        }
+        b_canon = b_canon && b_read;
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k] & ~REQ_FLAG;
             const Node& n = g.nodes[i];
@@ -727,6 +746,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         break;
                     }
                     enc_operand(n.b, 1);
+                    if (b_canon) off[1] = (uint32_t)((uint64_t)canon_const[n.b] * slot_bytes);
                     break;
                 case N_TRES:
                     enc_operand(n.a, 0);
@@ -757,6 +777,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 lin_bits |= HDR_BITX_ALL;
                 st.n_bitx_bundles++;
             }
+            if (b_canon) lin_bits |= HDR_BIT_BCANON;
         }
         out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits;
         std::sort(dying.begin(), dying.end());
@@ -805,7 +826,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 7;
+    h.version = 8;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -820,7 +841,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 7 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 8 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

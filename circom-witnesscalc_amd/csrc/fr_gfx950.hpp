@@ -589,8 +589,8 @@ FRD void u256_divrem(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t top) {
 // shifted dividend is consumed 32 bits per step.  `digits` (1..8) = how many low quotient digits can be non-zero:
 // ceil((bitlen(a) - bitlen(b) + 1) / 32), or the wave-wide maximum of that so that the loop stays uniform (0: a < b
 // everywhere).  A step costs ~80 VALU instructions against ~35 per BIT of the restoring division above.
-FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t digits) {
-    const uint32_t L = u256_bitlen(b);   // 1..256 (callers pass b != 0)
+FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t digits, uint32_t bitlen_b = 0) {
+    const uint32_t L = bitlen_b ? bitlen_b : u256_bitlen(b);   // 1..256 (callers pass b != 0)
     const uint32_t sh = 256u - L;        // divisor shifted left by sh has its top bit set
     const Fr bn = sh ? u256_shl(b, sh) : b;
     // a << sh as 512 bits: hi:lo (sh = 0: hi = 0)

@@ -306,7 +306,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                     r = u256_select((e.v[0] & 1u) != 0u, fr_one(), fr_zero());
                     break;
                 }
-                const Fr y = fr_from_mont(b_op);
+                const Fr y = (h & HDR_BIT_BCANON) ? b_op : fr_from_mont(b_op);  // (canonical copies of constants)
                 uint32_t hi_or = 0;
 #pragma unroll
                 for (int i = 1; i < 8; ++i) hi_or |= y.v[i];
@@ -314,8 +314,8 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 const uint32_t n = is_x ? kx : big ? 0u : y.v[0];
                 Fr d;
                 if (sub == SUB_SHL || sub == SUB_SHR || is_x) {
-                    const Fr sl = u256_shl(x, n), sr = u256_shr(x, n);
-                    d = u256_select(sub == SUB_SHL, sl, sr);
+                    d = u256_shr(x, n);
+                    if (wave_any(sub == SUB_SHL)) d = u256_select(sub == SUB_SHL, u256_shl(x, n), d);  // (left shifts are rare)
                     d = u256_select(big && !is_x, fr_zero(), d);
                     if (is_x) {
                         d.v[0] &= 1u;
@@ -353,15 +353,12 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 ys.v[0] |= yz ? 1u : 0u;
                 // quotient digits (32 bits each) of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 bits
                 const uint32_t lx = u256_bitlen(x), ly = u256_bitlen(ys);
-                uint32_t dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;
+                const uint32_t my_dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;  // 0..8
+                uint32_t dig = 0;  // wave-wide maximum by ballots (cheaper than a shuffle reduction: the range is tiny)
 #pragma unroll
-                for (int off = 32; off; off >>= 1) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)dig, off);
-                    dig = dig > o ? dig : o;
-                }
-                dig = (uint32_t)__builtin_amdgcn_readfirstlane((int)dig);
+                for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
                 Fr q, rem;
-                u256_divrem_digits(q, rem, x, ys, dig);
+                u256_divrem_digits(q, rem, x, ys, dig, ly);
                 const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));
                 r = fr_mul_wave(d, fr_r2(), pv);
                 break;

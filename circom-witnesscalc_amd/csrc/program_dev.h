@@ -58,6 +58,9 @@ enum BundleClass : uint32_t {
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
 static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
+// C_BIT: every lane's second operand is a constant and arrives in canonical (non-Montgomery) form from a second copy in
+// the constant table: the bundle skips that operand's conversion out of Montgomery form
+static const uint32_t HDR_BIT_BCANON = 1u << 14;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
 static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
 static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;

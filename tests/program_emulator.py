@@ -43,7 +43,8 @@ class Blob:
         self.recs = take(self.n_bundles * self.G * 4)
         self.crefs = take(self.n_bundles * self.G)
         k = take(self.n_const * 8)
-        self.consts = [sum(k[8 * i + j] << (32 * j) for j in range(8)) * R_INV % model.M for i in range(self.n_const)]
+        self.consts_raw = [sum(k[8 * i + j] << (32 * j) for j in range(8)) for i in range(self.n_const)]
+        self.consts = [v * R_INV % model.M for v in self.consts_raw]
         assert self.n_const >= 1 and self.consts[-1] == 0  # trailing dummy entry (prefetch target)
         self.witness_refs = take(self.n_witness)
         self.div_lanes = take(self.n_div_requests)
@@ -82,7 +83,7 @@ def run(blob: Blob, inputs_row):
     for b in range(blob.n_bundles):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
-        assert h >> 14 == 0 and 1 <= cnt <= G
+        assert h >> 15 == 0 and 1 <= cnt <= G
         name = CLASS_NAMES[cls]
         stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
@@ -105,7 +106,11 @@ def run(blob: Blob, inputs_row):
                     continue
                 own_cell = stage + 2 * q * LDS_HALF_BYTES + j * T * 16
                 if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
-                    ops.append(mem_at(off, b - OPND_AHEAD - 1))
+                    if name == "BIT" and (h >> 14) & 1 and q == 1 and j < cnt:
+                        assert off % slot_bytes == 0 and off // slot_bytes < NC, "canonical second operands are constants"
+                        ops.append(blob.consts_raw[off // slot_bytes])  # canonical copy: no conversion in the kernel
+                    else:
+                        ops.append(mem_at(off, b - OPND_AHEAD - 1))
                 else:
                     assert off == zero_off, "ring operand must stage the zero constant"
                     rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
@@ -151,6 +156,8 @@ def run(blob: Blob, inputs_row):
         if name == "BIT":
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
             assert ((h >> 13) & 1) == (1 if all_x else 0), "BITX header bit must describe the records"
+        else:
+            assert (h >> 13) == 0
         assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
