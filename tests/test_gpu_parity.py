@@ -151,6 +151,12 @@ def test_compiler_rewrites_on_chain_heavy_graphs(pkg):
         _check(pkg, b.to_bin(), rows, tiles=(1, 2, 16, 64, 2 | DIVIDER, 8 | DIVIDER, 1 | GROUP, 8 | GROUP))
 
 
+def test_short_soak_random_graphs_batches_programs(pkg):
+    """120 random graphs (every op, panic edges, chain-heavy) x random batch sizes x random program keys."""
+    from tools import gpu_soak
+    assert gpu_soak.run(120, 4242, verbose=False) == 0
+
+
 def test_gadgets_and_ragged_batches(pkg):
     rnd = random.Random(5)
     data = C.build_gadgets().to_bin()

@@ -16,31 +16,38 @@ M = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 EDGE = [0, 1, 2, 3, 63, 64, 65, 127, 128, 253, 254, 255, 256, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, 1 << 64,
         (1 << 128) - 1, 1 << 200, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
 KEYS = [1, 2, 4, 8, 16, 32, 64, 1 | 0x100, 2 | 0x100, 8 | 0x100, 32 | 0x100, 1 | 0x200, 4 | 0x200, 16 | 0x200]
-n_seeds = int(os.environ.get("SOAK_SEEDS", "200"))
-rnd = random.Random(int(os.environ.get("SOAK_BASE", "12345")))
-bad = 0
-t0 = time.time()
-for s in range(n_seeds):
-    kind = rnd.choice(["dag", "dag", "dag_panic", "chains"])
-    if kind == "chains":
-        b, n_in = C.build_chain_heavy(rnd.randrange(1 << 30), n_chains=rnd.randrange(4, 20)), 6
-    else:
-        b, n_in = C.build_random_dag(rnd.randrange(1 << 30), n_ops=rnd.randrange(50, 600), panic_free=(kind == "dag")), 7
-    data = b.to_bin()
-    B = rnd.choice([1, 2, 3, 17, 64, 65, 200])
-    rows = [[1] + [rnd.randrange(M) if rnd.random() > 0.3 else rnd.choice(EDGE + [rnd.randrange(1 << 16)]) for _ in range(n_in - 1)] for _ in range(B)]
-    inp = cbind.ints_to_array(rows)
-    og = cbind.Graph(data)
-    want, wst = og.evaluate_batch(inp)
-    g = pkg.Graph(data)
-    for key in rnd.sample(KEYS, 3) + [0]:
-        g.set_tile_width(key)
-        got, st = g.calc_witness_batch(inp)
-        ok = wst == 0
-        if not (np.array_equal(st != 0, wst != 0) and np.array_equal(got[ok], want[ok])):
-            bad += 1
-            print("MISMATCH seed-index %d kind %s key %#x batch %d" % (s, kind, key, B), flush=True)
-    if s % 50 == 49:
-        print("%d graphs, %d mismatches, %.0f s" % (s + 1, bad, time.time() - t0), flush=True)
-print("soak done: %d graphs x 4 programs, %d mismatches" % (n_seeds, bad))
-sys.exit(1 if bad else 0)
+def run(n_seeds, base, verbose=True):
+    """returns the number of mismatching (graph, program) runs"""
+    rnd = random.Random(base)
+    bad = 0
+    t0 = time.time()
+    for s in range(n_seeds):
+        kind = rnd.choice(["dag", "dag", "dag_panic", "chains"])
+        if kind == "chains":
+            b, n_in = C.build_chain_heavy(rnd.randrange(1 << 30), n_chains=rnd.randrange(4, 20)), 6
+        else:
+            b, n_in = C.build_random_dag(rnd.randrange(1 << 30), n_ops=rnd.randrange(50, 600), panic_free=(kind == "dag")), 7
+        data = b.to_bin()
+        B = rnd.choice([1, 2, 3, 17, 64, 65, 200])
+        rows = [[1] + [rnd.randrange(M) if rnd.random() > 0.3 else rnd.choice(EDGE + [rnd.randrange(1 << 16)]) for _ in range(n_in - 1)] for _ in range(B)]
+        inp = cbind.ints_to_array(rows)
+        og = cbind.Graph(data)
+        want, wst = og.evaluate_batch(inp)
+        g = pkg.Graph(data)
+        for key in rnd.sample(KEYS, 3) + [0]:
+            g.set_tile_width(key)
+            got, st = g.calc_witness_batch(inp)
+            ok = wst == 0
+            if not (np.array_equal(st != 0, wst != 0) and np.array_equal(got[ok], want[ok])):
+                bad += 1
+                print("MISMATCH seed-index %d kind %s key %#x batch %d" % (s, kind, key, B), flush=True)
+        if verbose and s % 50 == 49:
+            print("%d graphs, %d mismatches, %.0f s" % (s + 1, bad, time.time() - t0), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(os.environ.get("SOAK_SEEDS", "200"))
+    bad = run(n, int(os.environ.get("SOAK_BASE", "12345")))
+    print("soak done: %d graphs x 4 programs, %d mismatches" % (n, bad))
+    sys.exit(1 if bad else 0)
