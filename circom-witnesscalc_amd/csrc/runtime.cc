@@ -190,7 +190,8 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
         if (t >= 1 && t <= 64 && !(t & (t - 1))) return key;
     }
     const uint32_t rule = gwb_pick_tile_width(batch);
-    if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph) return rule;
+    // tiny batches (the single-shot entry point): one tile either way, not worth compiling candidates
+    if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph || batch < 64) return rule;
     auto hit = g->chosen.find(batch);
     if (hit != g->chosen.end()) return hit->second;
     size_t divider_tiles = 768;
