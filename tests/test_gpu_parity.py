@@ -125,6 +125,15 @@ def test_golden_fixtures_through_gw_calc_witness(pkg):
     assert pkg.calc_witness(open(os.path.join(GOLD, "circuit1_inputs.json")).read(), data) == [1, 31817, 105, 303]
 
 
+def test_reference_test_circuits_shaped_through_the_c_abi(pkg):
+    """circuit{2,3,4,6}-shaped graphs + the reference's input files through gw_calc_witness (GPU) == big-int model."""
+    for name, build in (("circuit2", C.build_circuit2), ("circuit3", C.build_circuit3), ("circuit4", C.build_circuit4),
+                        ("circuit6_num2bits", C.build_circuit6)):
+        data = build().to_bin()
+        js = open(os.path.join(GOLD, name + "_inputs.json")).read()
+        assert pkg.calc_witness_wtns(js, data) == model.wtns_from_witness(model.calc_witness(js, data)), name
+
+
 def test_cli_twin(pkg, tmp_path):
     exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "calc-witness")
     out = tmp_path / "w.wtns"

@@ -159,3 +159,33 @@ def test_bigint_class_graph_oracles_agree():
     assert not st.any()
     for r, o in zip(rows, out):
         assert model.evaluate(nodes, r, wit) == cbind.array_to_ints(o)
+
+
+REF_SHAPED = {  # reference test circuits rebuilt by tools/graphgen, evaluated on the reference's own input files
+    "circuit2": (C.build_circuit2, lambda a, b: (1 if a == 0 else 0) * b + 2),
+    "circuit3": (C.build_circuit3, lambda a, b: a * b + 3),
+    "circuit4": (C.build_circuit4, lambda a, b: (a & 1) * ((a >> 1) & 1) + b),
+    "circuit6_num2bits": (C.build_circuit6, lambda a, b: (a >> 16) & ((1 << 216) - 1)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(REF_SHAPED))
+def test_reference_test_circuits_shaped(name):
+    """test_circuits/circuit{2,3,4,6}.circom-shaped graphs with the reference's own `*_inputs.json`: big-int model ==
+    C oracle == the circuit's arithmetic done by hand (plus a few more inputs, zero and field-edge values included)."""
+    build, expect = REF_SHAPED[name]
+    data = build().to_bin()
+    js = open(os.path.join(GOLD, name + "_inputs.json")).read()
+    d = json.loads(js)
+    a, b = int(d["a"][0]), int(d["b"][0]) if "b" in d else 0
+    w = model.calc_witness(js, data)
+    assert w[0] == 1 and w[1] == expect(a, b) % model.M and w[2] == a
+    og = cbind.Graph(data)
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    rows = [[1, a, b][:og.n_inputs]] + [[1, x, y][:og.n_inputs] for x in (0, 1, 2, 3, model.M - 1, 1 << 200) for y in (0, 7, model.M - 1)]
+    got, st = og.evaluate_batch(cbind.ints_to_array(rows))
+    for row, o in zip(rows, got):
+        vals = cbind.array_to_ints(o)
+        assert vals == model.evaluate(nodes, row, wit)
+        assert vals[1] == expect(row[1], row[2] if len(row) > 2 else 0) % model.M
+    assert not st.any()

@@ -392,6 +392,49 @@ def build_circuit1():
     return b
 
 
+def build_circuit2():
+    """test_circuits/circuit2.circom-shaped: c <== IsZero(a) * b + 2   (f2(30) = 2 is folded at compile time)."""
+    b = Builder()
+    (a,) = b.input("a")
+    (bb,) = b.input("b")
+    e = is_zero(b, a)
+    c = b.add(b.mul(e, bb), b.const(2))
+    b._witness = [b._witness[0], c, a, bb] + [w for w in b._witness[1:]]
+    return b
+
+
+def build_circuit3():
+    """test_circuits/circuit3.circom-shaped: d = [a, b]; c <== d[0] * d[1] + 3 through an anonymous component."""
+    b = Builder()
+    (a,) = b.input("a")
+    (bb,) = b.input("b")
+    c = b.add(b.mul(a, bb), b.const(3))
+    b.signal(c); b.signal(a); b.signal(bb)
+    return b
+
+
+def build_circuit4():
+    """test_circuits/circuit4.circom-shaped: n = Num2Bits(2)(a); c <== n.out[0] * n.out[1] + b."""
+    b = Builder()
+    (a,) = b.input("a")
+    (bb,) = b.input("b")
+    bits = num2bits(b, a, 2)
+    c = b.add(b.mul(bits[0], bits[1]), bb)
+    b._witness = [b._witness[0], c, a, bb] + [w for w in b._witness[1:]]
+    return b
+
+
+def build_circuit6():
+    """test_circuits/circuit6_num2bits.circom-shaped: idBits = Num2Bits(256)(a); c <== Bits2Num(216)(idBits[16..232)).
+    (Num2Bits(256) shifts by up to 255: amounts >= 254 give 0 in the reference, src/graph.rs:642-646.)"""
+    b = Builder()
+    (a,) = b.input("a")
+    bits = num2bits(b, a, 256)
+    out = bits2num(b, bits[16:256 - 16 - 8])
+    b._witness = [b._witness[0], out, a] + [w for w in b._witness[1:] if w != out]
+    return b
+
+
 def build_poseidon(n_inputs=1, name="a"):
     """circuit5_poseidon-shaped: Poseidon(n) over one input array `a` (BASELINE config 1)."""
     b = Builder()
