@@ -137,7 +137,7 @@ static void fuse_bit_extract(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 120, 110, 800, 38, 22, 22};
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 100, 110, 175, 38, 22, 22};
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -273,7 +273,7 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
 }
 
 double program_wave_cycles(const Program& p) {
-    static const double kCycles[C_COUNT] = {5000, 2350, 1150, 73500, 1250, 6000, 5600, 40000, 1900, 1450, 1450};
+    static const double kCycles[C_COUNT] = {5000, 2350, 1150, 73500, 1250, 4900, 5500, 8700, 1900, 1450, 1450};
     double c = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)p.stats.class_bundles[k];
     return c - (kCycles[C_BIT] - 1500.0) * (double)p.stats.n_bitx_bundles;
