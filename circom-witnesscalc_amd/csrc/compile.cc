@@ -613,6 +613,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     const uint32_t NB = (uint32_t)bundle_start.size();
     bundle_start.push_back((uint32_t)order.size());
     out.n_bundles = NB;
+    if ((uint64_t)NB * G * 16ull > 0xffffffffull) {  // the record stream is addressed through one 32-bit buffer window
+        err = "graph too large: " + std::to_string(NB) + " bundles of " + std::to_string(G) + " records exceed the 4 GiB record window";
+        return false;
+    }
 
     // ---- operand routing -------------------------------------------------------------------------------
     // RING: produced at most RING_BUNDLES bundles ago (any node slot) -> read from the wave's result ring in LDS.
