@@ -660,4 +660,69 @@ FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t d
     rem = sh ? u256_shr(r8, sh) : r8;
 }
 
+// Short division: a < 2^128 by b < 2^64 (b != 0) -- the operand sizes of limb-wise big-integer circuits (64-bit limbs:
+// products and remainders below 2^128, divisors of one limb).  Same digit-wise scheme as u256_divrem_digits with a
+// two-limb divisor normalised to 64 bits and a 96-bit running remainder; q < 2^128, rem < 2^64.
+FRD void u128_divrem_64(Fr& q, Fr& rem, const Fr& a, const Fr& b) {
+    const uint64_t bv = ((uint64_t)b.v[1] << 32) | b.v[0];
+    const uint32_t s = (uint32_t)(b.v[1] ? __builtin_clz(b.v[1]) : 32 + __builtin_clz(b.v[0] | 1u));  // 0..63 (bv != 0)
+    const uint64_t bn = bv << s;                      // top bit set
+    const uint32_t bn1 = (uint32_t)(bn >> 32), bn0 = (uint32_t)bn;
+    // a << s as six limbs (a < 2^128, s < 64)
+    uint32_t A[6];
+    {
+        const uint64_t a_lo = ((uint64_t)a.v[1] << 32) | a.v[0], a_hi = ((uint64_t)a.v[3] << 32) | a.v[2];
+        const uint64_t w0 = a_lo << s;
+        const uint64_t w1 = (a_hi << s) | (s ? a_lo >> (64 - s) : 0);
+        const uint64_t w2 = s ? a_hi >> (64 - s) : 0;
+        A[0] = (uint32_t)w0; A[1] = (uint32_t)(w0 >> 32); A[2] = (uint32_t)w1; A[3] = (uint32_t)(w1 >> 32);
+        A[4] = (uint32_t)w2; A[5] = (uint32_t)(w2 >> 32);
+    }
+    // running remainder R = (R2:R1:R0) < bn * 2^32; start with the top two limbs (A[5]:A[4] < 2^64 / ... < bn)
+    uint32_t R2 = 0, R1 = A[5], R0 = A[4];
+    q = fr_zero();
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+        R2 = R1; R1 = R0; R0 = A[j];
+        // qhat = floor((R2:R1) / bn1) capped, corrected exactly (as in u256_divrem_digits)
+        uint32_t qhat;
+        {
+            const uint64_t n64 = ((uint64_t)R2 << 32) | R1;
+            const double n = (double)R2 * 4294967296.0 + (double)R1;
+            double e = n / (double)bn1;
+            e = e < 4294967295.0 ? e : 4294967295.0;
+            uint32_t est = (uint32_t)e;
+#if defined(CWC_TEST_PERTURB_QHAT)
+            if ((CWC_TEST_PERTURB_QHAT) > 0 ? est != 0xffffffffu : est != 0u) est += (uint32_t)(CWC_TEST_PERTURB_QHAT);
+#endif
+            const int64_t r = (int64_t)(n64 - (uint64_t)est * bn1);
+            est = r < 0 ? est - 1u : ((uint64_t)r >= bn1 ? est + 1u : est);
+            qhat = R2 >= bn1 ? 0xffffffffu : est;
+        }
+        // (R2:R1:R0) -= qhat * (bn1:bn0)
+        const uint64_t p0 = (uint64_t)qhat * bn0;
+        const uint64_t p1 = (uint64_t)qhat * bn1 + (p0 >> 32);
+        uint32_t borrow = 0;
+        R0 = sbb32(R0, (uint32_t)p0, borrow);
+        R1 = sbb32(R1, (uint32_t)p1, borrow);
+        R2 = sbb32(R2, (uint32_t)(p1 >> 32), borrow);
+#pragma unroll
+        for (int fix = 0; fix < 2; ++fix) {  // qhat too large by at most two: add the divisor back
+            const bool neg = borrow != 0;
+            uint32_t carry = 0;
+            R0 = adc32(R0, neg ? bn0 : 0u, carry);
+            R1 = adc32(R1, neg ? bn1 : 0u, carry);
+            R2 = adc32(R2, 0u, carry);
+            borrow = neg && !carry ? 1u : 0u;
+            qhat -= neg ? 1u : 0u;
+        }
+        q.v[j] = qhat;
+    }
+    // R < bn, i.e. R2 == 0; remainder = (R1:R0) >> s
+    const uint64_t r64 = (((uint64_t)R1 << 32) | R0) >> s;
+    rem = fr_zero();
+    rem.v[0] = (uint32_t)r64;
+    rem.v[1] = (uint32_t)(r64 >> 32);
+}
+
 }  // namespace cwc

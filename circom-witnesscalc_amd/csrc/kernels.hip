@@ -358,7 +358,11 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
 #pragma unroll
                 for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
                 Fr q, rem;
-                u256_divrem_digits(q, rem, x, ys, dig, ly);
+                if (!wave_any(lx > 128u || ly > 64u)) {
+                    u128_divrem_64(q, rem, x, ys);  // limb-sized operands everywhere in the wave: short division
+                } else {
+                    u256_divrem_digits(q, rem, x, ys, dig, ly);
+                }
                 const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));
                 r = fr_mul_wave(d, fr_r2(), pv);
                 break;

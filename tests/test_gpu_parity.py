@@ -307,6 +307,30 @@ def test_bigint_class_graph(pkg):
     _check(pkg, b.to_bin(), rows, tiles=(1, 4, 64))
 
 
+def test_limb_sized_divisions_take_the_short_path(pkg):
+    """Idiv / Mod with dividends below 2^128 and divisors below 2^64 in every lane (the operand sizes of 64-bit-limb
+    big-integer circuits): the wave-uniform short division, against the C oracle; mixed with a full-width lane."""
+    b = Builder()
+    (x,) = b.input("x"); (y,) = b.input("y"); (z,) = b.input("z")
+    a = b.op("Band", x, b.const((1 << 128) - 1))
+    d = b.add(b.op("Band", y, b.const((1 << 64) - 1)), b.const(1))
+    dz = b.op("Band", y, b.const((1 << 64) - 1))                      # may be zero: b == 0 -> 0 (graph.rs:112-121)
+    for num, den in ((a, d), (a, dz), (d, a), (b.mul(d, d), d)):
+        b.signal(b.op("Idiv", num, den)); b.signal(b.op("Mod", num, den))
+    data = b.to_bin()
+    rnd = random.Random(21)
+    small = [0, 1, 2, 3, (1 << 32) - 1, 1 << 32, (1 << 63), (1 << 64) - 1, 1 << 64, (1 << 96) + 5, (1 << 127), (1 << 128) - 1]
+    rows = [[1, u, v, 0] for u in small for v in small] + [[1, rnd.randrange(M), rnd.randrange(M), 0] for _ in range(300)]
+    _check(pkg, data, rows, tiles=(1, 4, 64))
+    # a second graph where one division has full-width operands: the wave falls back to the general routine
+    b2 = Builder()
+    (x,) = b2.input("x"); (y,) = b2.input("y"); (z,) = b2.input("z")
+    a = b2.op("Band", x, b2.const((1 << 128) - 1))
+    d = b2.add(b2.op("Band", y, b2.const((1 << 64) - 1)), b2.const(1))
+    b2.signal(b2.op("Idiv", a, d)); b2.signal(b2.op("Mod", x, d)); b2.signal(b2.op("Idiv", x, y)); b2.signal(b2.op("Mod", a, y))
+    _check(pkg, b2.to_bin(), rows, tiles=(1, 4, 64))
+
+
 def test_power_of_two_division_rewrite_on_gpu(pkg):
     b = Builder()
     (x,) = b.input("x"); (y,) = b.input("y")

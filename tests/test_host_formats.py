@@ -293,13 +293,14 @@ def test_loader_and_compiler_under_sanitizers(tmp_path):
 
 
 @pytest.mark.parametrize("perturb", [None, 1, -1])
-def test_digitwise_division_on_host(tmp_path, perturb):
-    """u256_divrem_digits (Idiv / Mod bundles) == the bit-serial division, also when the floating-point quotient-digit
-    estimate is off by one in either direction."""
+@pytest.mark.parametrize("which", ["div_digits_test", "div_short_test"])
+def test_digitwise_division_on_host(tmp_path, perturb, which):
+    """u256_divrem_digits and u128_divrem_64 (Idiv / Mod bundles) == the bit-serial division, also when the
+    floating-point quotient-digit estimate is off by one in either direction."""
     import subprocess
-    exe = str(tmp_path / "div_digits_test")
+    exe = str(tmp_path / which)
     flags = [] if perturb is None else ["-DCWC_TEST_PERTURB_QHAT=%d" % perturb]
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags +
-                          ["-o", exe, os.path.join(ROOT, "tests", "native", "div_digits_test.cc")])
+                          ["-o", exe, os.path.join(ROOT, "tests", "native", which + ".cc")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
