@@ -104,6 +104,8 @@ def test_graph_validation_errors(pkg):
         ([("Input", 0), ("Duo", "Pow", 0, 0)], [0], "Pow"),                     # graph.rs:141-142
         ([("Input", 0), ("Uno", "Id", 0)], [0], "Id"),                          # graph.rs:195
         ([("Input", 0)], [3], "witness signal"),
+        # the graph of the reference's storage round-trip test (storage.rs:421-430) is not evaluable: rejected at load
+        ([("Input", 0), ("Const", 1), ("Uno", "Id", 4), ("Duo", "Mul", 5, 6), ("Tres", "TernCond", 7, 8, 9)], [4, 1], "not before it"),
     ]
     for nodes, wit, frag in bad:
         with pytest.raises(pkg.WitnessCalcError, match=frag):

@@ -79,6 +79,29 @@ def test_node_framing_vectors():
         assert model._decode_node(bytes.fromhex(hx)[1:])[0] == nodes[name][0]
 
 
+def test_storage_roundtrip_vector():
+    """reference src/storage.rs:420-464 (test_deserialize_inputs): the graph [Input(0), Constant(1), UnoOp(Id, 4),
+    Op(Mul, 5, 6), TresOp(TernCond, 7, 8, 9)] with witness [4, 1] and inputs sig1 -> (1, 3), sig2 -> (5, 1) survives
+    write -> read, and the trailing u64 points at a metadata record that decodes to the same witness list / input map.
+    (Operand indices are not checked at this level -- the reference's reader does not check them either.)"""
+    import struct
+    from tools.graphgen.builder import serialize_graph
+    nodes = [("Input", 0), ("Const", 1), ("Uno", "Id", 4), ("Duo", "Mul", 5, 6), ("Tres", "TernCond", 7, 8, 9)]
+    wit = [4, 1]
+    ins = {"sig1": (1, 3), "sig2": (5, 1)}
+    data = serialize_graph(nodes, wit, ins)
+    got_nodes, got_wit, got_ins = model.deserialize_witnesscalc_graph(data)
+    assert [tuple(n) for n in got_nodes] == nodes and list(got_wit) == wit and dict(got_ins) == ins
+    (md_off,) = struct.unpack_from("<Q", data, len(data) - 8)
+    # the metadata record alone: varint length + GraphMetadata{1: packed witness, 2: map entries}
+    md = data[md_off:len(data) - 8]
+    assert md[0] == len(md) - 1
+    assert md[1:1 + 4] == bytes([0x0a, 0x02, 0x04, 0x01])                      # witnessSignals = [4, 1], packed
+    assert b"sig1" in md and b"sig2" in md
+    # header: magic + u64 node count (storage.rs:145, :228)
+    assert data[:14] == b"wtns.graph.001" and struct.unpack_from("<Q", data, 14)[0] == 5
+
+
 def test_circuit1_fixture_end_to_end():
     data = open(os.path.join(GOLD, "circuit1.bin"), "rb").read()
     assert len(data) == 94 and C.build_circuit1().to_bin() == data
