@@ -208,6 +208,17 @@ FRD Fr fr_mul(const Fr& a, const Fr& b) {
 #endif
 }
 #if defined(__HIPCC__)
+// Per-lane add or subtract in one pass (bundles that mix both): m = all ones in subtracting lanes, subm / addm = the
+// lane masks of the subtracting / adding lanes (every lane in exactly one of them).
+__device__ __forceinline__ Fr fr_addsub_wave(const Fr& a, const Fr& b, const Fr& pv, uint32_t m, unsigned long long subm,
+                                             unsigned long long addm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_addsub_gfx950.inc"
+#else
+    (void)pv; (void)subm; (void)addm;
+    return m ? fr_sub(a, b) : fr_add(a, b);
+#endif
+}
 // Montgomery product as ONE asm block (accumulators in fixed VGPRs v160-v167): no compiler-inserted hazard padding, the
 // column shift is one v_pk_mov_b32, the conditional subtraction rides in the tails of the last columns.
 __device__ __forceinline__ Fr fr_mul_wave(const Fr& a, const Fr& b, const Fr& pv) {

@@ -225,8 +225,14 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
         if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul_wave(a_op, b_op, pv);
             // linear nodes riding in this bundle's free node slots (graph.rs:110-111)
-            if (h & HDR_LIN_ADD) r = u256_select(sub == SUB_ADD, fr_add_wave(a_op, b_op, pv), r);
-            if (h & HDR_LIN_SUB) r = u256_select(sub == SUB_SUB, fr_sub_wave(a_op, b_op, pv), r);
+            if ((h & (HDR_LIN_ADD | HDR_LIN_SUB)) == (HDR_LIN_ADD | HDR_LIN_SUB)) {
+                const unsigned long long subm = __ballot(sub == SUB_SUB);
+                r = u256_select(sub <= SUB_SUB, fr_addsub_wave(a_op, b_op, pv, sub == SUB_SUB ? ~0u : 0u, subm, ~subm), r);
+            } else if (h & HDR_LIN_ADD) {
+                r = u256_select(sub == SUB_ADD, fr_add_wave(a_op, b_op, pv), r);
+            } else if (h & HDR_LIN_SUB) {
+                r = u256_select(sub == SUB_SUB, fr_sub_wave(a_op, b_op, pv), r);
+            }
         } else if (__builtin_expect(cls == C_LIN, 1)) {
             // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
             // uniform (header bits); a mixed one computes both and selects per lane.
@@ -235,7 +241,8 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
             } else if (!(h & HDR_LIN_ADD)) {
                 r = fr_sub_wave(a_op, b_op, pv);
             } else {
-                r = u256_select(sub == SUB_ADD, fr_add_wave(a_op, b_op, pv), fr_sub_wave(a_op, b_op, pv));
+                const unsigned long long subm = __ballot(sub == SUB_SUB);
+                r = fr_addsub_wave(a_op, b_op, pv, sub == SUB_SUB ? ~0u : 0u, subm, ~subm);
             }
         } else
         switch (cls) {
