@@ -38,11 +38,24 @@ class WitnessCalcError(RuntimeError):
     pass
 
 
+def pinned_rows(shape):
+    """uint8 array in pinned host memory (gwb_host_alloc); freed when the array and its views are gone."""
+    import weakref
+    n = int(np.prod(shape))
+    ptr = lib().gwb_host_alloc(n)
+    if not ptr:
+        raise WitnessCalcError("gwb_host_alloc(%d) failed" % n)
+    buf = (ctypes.c_uint8 * max(n, 1)).from_address(ptr)
+    weakref.finalize(buf, lib().gwb_host_free, ptr)
+    return np.frombuffer(buf, dtype=np.uint8, count=n).reshape(shape)
+
+
 EXPORTED_SYMBOLS = [
     "gw_calc_witness", "gwb_graph_load", "gwb_graph_free", "gwb_graph_info", "gwb_graph_serialize",
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
     "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width", "gwb_inputs_from_json_batch", "gwb_wtns_save_batch",
+    "gwb_host_alloc", "gwb_host_free",
 ]
 
 
@@ -82,6 +95,10 @@ def lib():
         L.gwb_calc_witness_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, stp]
         L.gwb_calc_witness_batch_host.argtypes = [vp, vp, sz, vp, vp, stp]
         L.gwb_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+        L.gwb_host_alloc.restype = ctypes.c_void_p
+        L.gwb_host_alloc.argtypes = [sz]
+        L.gwb_host_free.restype = None
+        L.gwb_host_free.argtypes = [ctypes.c_void_p]
         L.gwb_wtns_size.restype = sz
         L.gwb_wtns_size.argtypes = [sz]
         L.gwb_wtns_from_witness.argtypes = [vp, sz, vp]
@@ -240,12 +257,17 @@ class Graph:
         _check(rc, st)
         return rows
 
-    def calc_witness_batch(self, inputs):
-        """Host buffers: inputs uint8 [B, n_inputs, 32] -> (witness uint8 [B, W, 32], status uint32 [B])."""
+    def calc_witness_batch(self, inputs, out=None):
+        """Host buffers: inputs uint8 [B, n_inputs, 32] -> (witness uint8 [B, W, 32], status uint32 [B]).
+        `out`: optional contiguous uint8 [B, W, 32] to fill (e.g. from pinned_rows, which skips the staging copy)."""
         inputs = np.ascontiguousarray(inputs, dtype=np.uint8)
         b = inputs.shape[0]
         assert inputs.shape[1:] == (self.n_inputs, 32), inputs.shape
-        wit = np.zeros((b, self.n_witness, 32), dtype=np.uint8)
+        if out is None:
+            wit = np.empty((b, self.n_witness, 32), dtype=np.uint8)
+        else:
+            wit = out
+            assert wit.dtype == np.uint8 and wit.shape == (b, self.n_witness, 32) and wit.flags["C_CONTIGUOUS"]
         status = np.zeros(b, dtype=np.uint32)
         st = GwStatus()
         rc = lib().gwb_calc_witness_batch_host(self._h, inputs.ctypes.data, b, wit.ctypes.data, status.ctypes.data,

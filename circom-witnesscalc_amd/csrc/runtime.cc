@@ -9,7 +9,9 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define GW_NO_INLINE_FREE_STATUS
@@ -119,6 +121,13 @@ struct gwb_graph {
     unsigned long long* d_prof = nullptr;  // diagnostic per-class stamps (gwb_profile_classes), else null
     struct ChunkEvents { hipEvent_t start, after_interp, after_pack; };
     std::vector<ChunkEvents> pending;  // HIP events of the last call, recorded on its launch stream
+    // host-buffer entry point: device rows and the pinned staging of the witness copy, kept between calls
+    void *h_in = nullptr, *h_out = nullptr, *h_st = nullptr;
+    size_t h_in_bytes = 0, h_out_bytes = 0, h_st_bytes = 0;
+    void* stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
     std::mutex mu;
 
     void drop_events() {
@@ -132,6 +141,13 @@ struct gwb_graph {
         for (int i = 0; i < kMaxLanes; ++i)
             if (d_vals[i]) (void)hipFree(d_vals[i]);
         drop_events();
+        for (void* p : {h_in, h_out, h_st})
+            if (p) (void)hipFree(p);
+        for (int i = 0; i < 2; ++i) {
+            if (stage[i]) (void)hipHostFree(stage[i]);
+            if (stage_done[i]) (void)hipEventDestroy(stage_done[i]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
@@ -342,28 +358,133 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     return "";
 }
 
-std::string run_host(gwb_graph* g, const void* inputs, size_t batch, void* witness, uint32_t* set_status) {
-    if (batch == 0) return "";
-    void *d_in = nullptr, *d_out = nullptr, *d_st = nullptr;
-    const size_t in_b = batch * (size_t)g->n_inputs * 32, out_b = batch * (size_t)g->n_witness * 32;
+// Host-buffer entry: rows in, rows out.  The witness rows are the big transfer (authV2-class: 2.4 MB per set), so
+// they come back in slices through two pinned staging buffers on a copy stream while worker threads move the previous
+// slice into the caller's (pageable) memory; a caller buffer that is already pinned (gwb_host_alloc, hipHostMalloc,
+// hipHostRegister) is the copy's destination directly.  Device buffers and staging are kept on the handle.
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+unsigned copy_threads() {
+    long v = 0;
+    if (const char* e = getenv("CWC_COPY_THREADS")) v = atol(e);
+    if (v <= 0) {
+        v = (long)std::thread::hardware_concurrency();
+        if (v > 16) v = 16;
+    }
+    return v < 1 ? 1u : (unsigned)v;
+}
+
+std::string device_to_host_rows(gwb_graph* g, void* dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return "";
+    if (!g->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+    if (is_pinned_host(dst)) {
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g->copy_stream));
+        HIP_TRY(hipStreamSynchronize(g->copy_stream));
+        return "";
+    }
+    size_t slice = 32u << 20;
+    if (const char* e = getenv("CWC_COPY_SLICE_MB")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 1024) slice = (size_t)v << 20;
+    }
+    if (g->stage_bytes < slice) {
+        for (int i = 0; i < 2; ++i) {
+            if (g->stage[i]) HIP_TRY(hipHostFree(g->stage[i]));
+            g->stage[i] = nullptr;
+        }
+        g->stage_bytes = 0;
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&g->stage[i], slice, hipHostMallocDefault));
+        g->stage_bytes = slice;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!g->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
+    const size_t n_slices = (bytes + slice - 1) / slice;
+    const unsigned n_workers = bytes < (8u << 20) ? 1u : copy_threads();
+    // workers: slice k is theirs once `ready` > k; each takes one stripe of it and counts itself in consumed[k]
+    std::atomic<long> ready{0};
+    std::atomic<bool> abort{false};
+    std::vector<std::atomic<unsigned>> consumed(n_slices);
+    for (auto& c : consumed) c.store(0);
+    auto stripe_copy = [&](unsigned w, size_t k) {
+        const size_t off = k * slice, len = bytes - off < slice ? bytes - off : slice;
+        const size_t per = ((len + n_workers - 1) / n_workers + 4095) & ~(size_t)4095;
+        const size_t a = (size_t)w * per, b = a + per < len ? a + per : len;
+        if (a < b) memcpy((char*)dst + off + a, (const char*)g->stage[k & 1] + a, b - a);
+    };
+    std::vector<std::thread> workers;
+    for (unsigned w = 1; w < n_workers; ++w)
+        workers.emplace_back([&, w]() {
+            for (size_t k = 0; k < n_slices; ++k) {
+                while (ready.load(std::memory_order_acquire) <= (long)k) {
+                    if (abort.load()) return;
+                    std::this_thread::yield();
+                }
+                stripe_copy(w, k);
+                consumed[k].fetch_add(1, std::memory_order_release);
+            }
+        });
     std::string err;
-    auto body = [&]() -> std::string {
-        HIP_TRY(hipMalloc(&d_in, in_b ? in_b : 32));
-        HIP_TRY(hipMalloc(&d_out, out_b ? out_b : 32));
-        HIP_TRY(hipMalloc(&d_st, batch * 4));
-        HIP_TRY(hipMemcpy(d_in, inputs, in_b, hipMemcpyHostToDevice));
-        std::string e = run_device(g, d_in, batch, d_out, (uint32_t*)d_st, nullptr);
-        if (!e.empty()) return e;
-        HIP_TRY(hipDeviceSynchronize());
-        if (out_b) HIP_TRY(hipMemcpy(witness, d_out, out_b, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(set_status, d_st, batch * 4, hipMemcpyDeviceToHost));
+    auto issue = [&](size_t k) -> std::string {
+        const size_t off = k * slice, len = bytes - off < slice ? bytes - off : slice;
+        HIP_TRY(hipMemcpyAsync(g->stage[k & 1], (const char*)d_src + off, len, hipMemcpyDeviceToHost, g->copy_stream));
+        HIP_TRY(hipEventRecord(g->stage_done[k & 1], g->copy_stream));
         return "";
     };
-    err = body();
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (d_st) (void)hipFree(d_st);
+    err = issue(0);
+    for (size_t k = 0; k < n_slices && err.empty(); ++k) {
+        if (k + 1 < n_slices) {
+            // buffer (k+1)&1 held slice k-1: every worker must be done with it before the next copy lands there
+            if (k >= 1)
+                while (consumed[k - 1].load(std::memory_order_acquire) < n_workers) std::this_thread::yield();
+            err = issue(k + 1);
+            if (!err.empty()) break;
+        }
+        if (hipEventSynchronize(g->stage_done[k & 1]) != hipSuccess) {
+            err = "hipEventSynchronize failed in the witness copy";
+            break;
+        }
+        ready.store((long)k + 1, std::memory_order_release);
+        stripe_copy(0, k);
+        consumed[k].fetch_add(1, std::memory_order_release);
+    }
+    if (!err.empty()) abort.store(true);
+    for (auto& t : workers) t.join();
+    if (!err.empty()) (void)hipStreamSynchronize(g->copy_stream);
     return err;
+}
+
+std::string run_host(gwb_graph* g, const void* inputs, size_t batch, void* witness, uint32_t* set_status) {
+    if (batch == 0) return "";
+    const size_t in_b = batch * (size_t)g->n_inputs * 32, out_b = batch * (size_t)g->n_witness * 32;
+    auto grow = [](void*& p, size_t& have, size_t need) -> std::string {
+        if (need <= have) return "";
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        have = 0;
+        HIP_TRY(hipMalloc(&p, need));
+        have = need;
+        return "";
+    };
+    std::string err = grow(g->h_in, g->h_in_bytes, in_b ? in_b : 32);
+    if (err.empty()) err = grow(g->h_out, g->h_out_bytes, out_b ? out_b : 32);
+    if (err.empty()) err = grow(g->h_st, g->h_st_bytes, batch * 4);
+    if (!err.empty()) return err;
+    HIP_TRY(hipMemcpy(g->h_in, inputs, in_b, hipMemcpyHostToDevice));
+    err = run_device(g, g->h_in, batch, g->h_out, (uint32_t*)g->h_st, nullptr);
+    if (!err.empty()) return err;
+    HIP_TRY(hipDeviceSynchronize());
+    err = device_to_host_rows(g, witness, g->h_out, out_b);
+    if (!err.empty()) return err;
+    HIP_TRY(hipMemcpy(set_status, g->h_st, batch * 4, hipMemcpyDeviceToHost));
+    return "";
 }
 
 std::string set_status_text(uint32_t bits) {
@@ -549,6 +670,19 @@ int gwb_calc_witness_batch_host(gwb_graph_t* g, const void* inputs, size_t batch
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");
     return 0;
+}
+
+void* gwb_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!check_device().empty() || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void gwb_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int gwb_last_timing(gwb_graph_t* g, gwb_timing_t* t) {

@@ -83,9 +83,14 @@ uint32_t gwb_pick_tile_width(size_t batch);
  *   hip_stream: hipStream_t or NULL.  Asynchronous: returns after enqueueing. */
 int gwb_calc_witness_batch_device(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                                   uint32_t *d_set_status, void *hip_stream, gw_status_t *status);
-/* Same with host buffers (copies in/out, synchronous). */
+/* Same with host buffers (copies in/out, synchronous).  The witness rows come back in slices through pinned staging
+ * while worker threads (CWC_COPY_THREADS, default min(cores, 16)) fill `witness`; a `witness` buffer from
+ * gwb_host_alloc (or any pinned allocation) is the destination of the device copy itself. */
 int gwb_calc_witness_batch_host(gwb_graph_t *g, const void *inputs, size_t batch, void *witness,
                                 uint32_t *set_status, gw_status_t *status);
+/* Pinned host memory for the rows of the host entry point (NULL on failure); release with gwb_host_free. */
+void *gwb_host_alloc(size_t bytes);
+void gwb_host_free(void *p);
 /* Kernel times of the last batch call on this handle (synchronizes on its events). */
 int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 

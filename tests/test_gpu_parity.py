@@ -340,3 +340,31 @@ def test_power_of_two_division_rewrite_on_gpu(pkg):
     b.signal(b.op("Idiv", x, y)); b.signal(b.op("Mod", x, y)); b.signal(b.op("Idiv", y, x)); b.signal(b.op("Mod", y, x))
     rows = [[1, a, c] for a in EDGE for c in (0, 1, 3, 1 << 64, M - 1, (1 << 100) + 7)]
     _check(pkg, b.to_bin(), rows, tiles=(1, 16, 64))
+
+
+def test_host_rows_sliced_staged_and_pinned(pkg, monkeypatch):
+    """gwb_calc_witness_batch_host brings the witness rows back in slices through pinned staging with several copy
+    threads, or straight into a pinned caller buffer (gwb_host_alloc); every variant must deliver the rows of the
+    oracle, whatever the slice size, thread count, or a buffer size that is not a multiple of either."""
+    rnd = random.Random(21)
+    data = C.build_poseidon(2).to_bin()
+    og = cbind.Graph(data)
+    rows = cbind.ints_to_array([_rand_row(rnd, 3, 0) for _ in range(3000)])  # 42 MB of witness rows
+    want, _ = og.evaluate_batch(rows)
+    g = pkg.Graph(data)
+    for slice_mb, threads in ((None, None), ("1", "5"), ("3", "1"), ("1", "16")):
+        for name, v in (("CWC_COPY_SLICE_MB", slice_mb), ("CWC_COPY_THREADS", threads)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, v)
+        for n in (3000, 2999, 37, 1):
+            got, st = g.calc_witness_batch(rows[:n])
+            assert not st.any() and np.array_equal(got, want[:n]), (slice_mb, threads, n)
+    pinned = pkg.pinned_rows((3000, g.n_witness, 32))
+    pinned[:] = 0xAA
+    got, st = g.calc_witness_batch(rows, out=pinned)
+    assert got is pinned and not st.any() and np.array_equal(pinned, want)
+    # a view into the middle of a pinned allocation is pinned too
+    got, st = g.calc_witness_batch(rows[5:105], out=pinned[100:200])
+    assert np.array_equal(pinned[100:200], want[5:105]) and np.array_equal(pinned[:100], want[:100]) and np.array_equal(pinned[200:], want[200:])
