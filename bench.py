@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024, help="input sets timed on one host core (0 = skip)")
     ap.add_argument("--extra-batch", type=int, default=8192,
                     help="also report (outside `value`) the throughput at this per-GPU batch, N=1 only; 0 = skip")
+    ap.add_argument("--host-path", type=int, default=1,
+                    help="also report (outside `value`) the PCIe-inclusive rate of the host-buffer entry point, N=1 only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,6 +163,8 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(data, rows, d_out, min(args.cpu_sample, B))
+        if world == 1 and args.host_path:
+            out["pcie_inclusive"] = host_path_point(pkg, g, rows, d_out)
         if world == 1 and args.extra_batch > B:
             out["large_batch"] = large_batch_point(pkg, g, args.graph, args.extra_batch, dev)
         sys.stdout.flush()
@@ -169,6 +173,22 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_path_point(pkg, g, rows, d_out):
+    """Informational only (never `value`): the same batch through gwb_calc_witness_batch_host -- input rows from host
+    memory, witness rows back into a pinned host buffer (gwb_host_alloc) and into a reused pageable one."""
+    res = {"unit": "witnesses/s", "witness_bytes": int(rows.shape[0]) * g.n_witness * 32}
+    want = d_out.cpu().numpy()
+    for name, out in (("pinned_destination", pkg.pinned_rows(want.shape)), ("pageable_destination", np.zeros_like(want))):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            wit, st = g.calc_witness_batch(rows, out=out)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        res[name] = {"value": rows.shape[0] / best, "ms_per_step": best * 1e3, "matches_device_path": bool(np.array_equal(wit, want))}
+    return res
 
 
 def large_batch_point(pkg, g, graph_kind, batch, dev):
