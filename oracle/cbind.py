@@ -82,8 +82,8 @@ class Graph:
         self.n_nodes, self.n_witness, self.n_inputs, self.n_op = [int(x) for x in info]
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:  # (module globals are gone at interpreter exit)
-            _lib.orc_graph_free(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:  # (module globals are None-d at interpreter exit)
+            _LIB.orc_graph_free(self._h)
             self._h = None
 
     def witness_signals(self):
