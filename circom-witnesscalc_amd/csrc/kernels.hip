@@ -202,7 +202,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
     for (uint32_t b = 0; b < NBND; ++b) {
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
-        const uint32_t h_n2 = hdr[clampb(b + 2)];
+        const uint32_t* const hp_n2 = hdr + clampb(b + 2);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         CWC_STAMP(st1);
         const uint32_t ctrl = rec_hi.x & CTRL_MASK;
@@ -211,18 +211,27 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
         const Fr a_op = ld_lds(la & 0xffffu), b_op = ld_lds(la >> 16);
         const uint2 rec_n2 = ld_rec2(b + 2, 0);    // {a_off, b_off} of bundle b+2
         const uint2 rec_hi_n1 = ld_rec2(b + 1, 1);
+        // header of bundle b+2: a scalar load issued behind the LDS reads and retired with them by the wait below (left
+        // to the compiler it lands after the staging loads, and its whole latency in front of the arithmetic: the
+        // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
+        uint32_t h_n2;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(h_n2) : "s"(hp_n2) : "memory");
         // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2] / REC[b mod 4]
-        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n1.x) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n1.x) : "memory");
         CWC_STAMP(st2);
         stage_operands(b + 2, rec_n2);
         stage_rec(b + 4);
         CWC_STAMP(st3);
 
         const uint32_t cls = h & HDR_CLASS_MASK;
+        // the two classes that are 97 % of the bundles are tested first, on a copy the compiler cannot fold into the
+        // switch below (folded, every bundle walks a binary search of taken branches)
+        uint32_t cls_hot = cls;
+        asm volatile("" : "+s"(cls_hot));
         const bool active = (ctrl & CTRL_ACTIVE) != 0;
         const uint32_t sub = ctrl & CTRL_SUB_MASK;
         Fr r;
-        if (__builtin_expect(cls == C_MUL, 1)) {  // graph.rs:105
+        if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul_wave(a_op, b_op, pv);
             // linear nodes riding in this bundle's free node slots (graph.rs:110-111)
             if ((h & (HDR_LIN_ADD | HDR_LIN_SUB)) == (HDR_LIN_ADD | HDR_LIN_SUB)) {
@@ -233,7 +242,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
             } else if (h & HDR_LIN_SUB) {
                 r = u256_select(sub == SUB_SUB, fr_sub_wave(a_op, b_op, pv), r);
             }
-        } else if (__builtin_expect(cls == C_LIN, 1)) {
+        } else if (__builtin_expect(cls_hot == C_LIN, 1)) {
             // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
             // uniform (header bits); a mixed one computes both and selects per lane.
             if (!(h & HDR_LIN_SUB)) {
