@@ -291,7 +291,7 @@ class Graph:
 
     def profile_classes(self, d_inputs, d_witness, d_status):
         """Diagnostic stamped build: {class: (cycles, 0, 0, bundles)} over sampled waves, plus "_sections":
-        {"MUL" / "LIN": (top + staged-operand wait, LDS reads, staging issue, arithmetic, stores + ring, bundles)}."""
+        {"MUL" / "LIN": (top + staged-operand wait, LDS reads + previous bundle's stores, staging issue, arithmetic, ring write, bundles)}."""
         out = np.zeros(64, dtype=np.uint64)
         st = GwStatus()
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),

@@ -186,10 +186,12 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
 
     // Software pipeline, everything through LDS.  While bundle b computes: its operands sit in STAGE[b mod 2] / the
     // RING; the memory operands of bundle b+1 are landing in STAGE[(b+1) mod 2]; those of bundle b+2 are requested as
-    // soon as bundle b has read its own (same STAGE cell); records run REC_AHEAD bundles ahead.  Vector-memory
-    // operations per iteration, in issue order: 4 operand loads, 1 record load, 2 stores -- the counted wait at the
-    // top of iteration b (vmcnt(9)) retires the operand loads of bundle b and the record load of bundle b+2, both issued
-    // in iteration b-2, and leaves the 9 younger operations in flight.
+    // soon as bundle b has read its own (same STAGE cell); records run REC_AHEAD bundles ahead.  The two stores of a
+    // bundle's results are issued in the NEXT iteration, behind that iteration's LDS reads (their issue time hides the
+    // LDS latency; the ring write stays at the end of the bundle, later bundles read it).  Vector-memory operations per
+    // iteration, in issue order: 2 stores (previous bundle), 4 operand loads, 1 record load -- the counted wait at the
+    // top of iteration b (vmcnt(7)) retires the operand loads of bundle b and the record load of bundle b+2, both
+    // issued in iteration b-2, and leaves the 7 operations of iteration b-1 in flight.
     static_assert(OPND_AHEAD == 2 && REC_AHEAD == 4, "the counted waits below are written for this pipeline depth");
 #pragma unroll
     for (uint32_t q = 0; q < REC_AHEAD; ++q) stage_rec(q);
@@ -199,11 +201,13 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
     uint2 rec_hi = ld_rec2(0, 1);  // {dst | ctrl, a_lds | b_lds << 16} of the current bundle
     uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Fr r_prev = fr_zero();  // results of the previous bundle, stored one iteration late (first iteration: zeros -> trash slot)
+    uint32_t doff_prev = (p.n_const + p.n_slots) * 2u * HI | t16;
     for (uint32_t b = 0; b < NBND; ++b) {
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
         const uint32_t* const hp_n2 = hdr + clampb(b + 2);
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         CWC_STAMP(st1);
         const uint32_t ctrl = rec_hi.x & CTRL_MASK;
         const uint32_t doff = (rec_hi.x & ~CTRL_MASK) | t16;
@@ -216,6 +220,10 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
         // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
         uint32_t h_n2;
         asm volatile("s_load_dword %0, %1, 0x0" : "=s"(h_n2) : "s"(hp_n2) : "memory");
+        // results of bundle b-1 -> tile (unconditional: values without a slot and inactive node slots go to the tile's
+        // trash slot; a fixed number of vector-memory operations per bundle is what makes the counted wait possible)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
         // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2] / REC[b mod 4]
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n1.x) : "memory");
         CWC_STAMP(st2);
@@ -392,10 +400,8 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
             default: r = fr_zero(); break;
         }
         CWC_STAMP(st4);
-        // unconditional store (values without a slot and inactive node slots go to the tile's trash slot): a fixed
-        // number of vector-memory operations per bundle is what makes the counted wait above possible
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[0], r.v[1], r.v[2], r.v[3]}, rsrc, (int)doff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r.v[4], r.v[5], r.v[6], r.v[7]}, rsrc, (int)doff + (int)HI, 0, 0);
+        r_prev = r;
+        doff_prev = doff;
         {   // publish the results of this bundle in the ring (read by later bundles of this wave, in order)
             uint4* q = reinterpret_cast<uint4*>(ldsb + LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES + lane16);
             q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
@@ -419,14 +425,17 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
             if (cls == C_MUL || cls == C_LIN) {
                 unsigned long long* q = psec[cls == C_MUL ? 0 : 1];
                 q[0] += st1 - st0;    // top of the loop + counted wait for the staged operands
-                q[1] += st2 - st1;    // operand / record reads from LDS
+                q[1] += st2 - st1;    // operand / record reads from LDS, the previous bundle's stores issued behind them
                 q[2] += st3 - st2;    // issuing the staging loads
                 q[3] += st4 - st3;    // class dispatch + arithmetic
-                q[4] += t_now - st4;  // stores, ring write
+                q[4] += t_now - st4;  // ring write
                 q[5] += 1;
             }
         }
     }
+    // the last bundle's results
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
     if (PROF && lane == 0 && (tile % 64u) == 0u) {
 #pragma unroll
         for (int c = 0; c < (int)C_COUNT; ++c) {

@@ -35,5 +35,5 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
             print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  share %.1f%%" % (k, n // nw, cyc / n, 100.0 * cyc / tot))
     for k, v in sections.items():
         if v[5]:
-            print("   %s sections (cycles/bundle, each includes one ~40-cycle stamp): top+vmcnt wait %.0f | LDS reads %.0f | staging issue %.0f | arithmetic %.0f | stores+ring %.0f" % (
+            print("   %s sections (cycles/bundle, each includes one ~40-cycle stamp): top+vmcnt wait %.0f | LDS reads + previous stores %.0f | staging issue %.0f | arithmetic %.0f | ring write %.0f" % (
                 (k,) + tuple(x / v[5] for x in v[:5])))
