@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 
 #include "program.hpp"
@@ -180,6 +181,8 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
         return idx;
     };
     std::vector<uint32_t> leaves;
+    typedef std::pair<uint64_t, uint32_t> LeafKey;  // (ready time, ~position in `leaves`)
+    std::vector<LeafKey> latest;
     std::vector<std::pair<uint64_t, uint32_t>> work;
     for (size_t i = 0; i < N; ++i) {
         const Node& n = g.nodes[i];
@@ -200,17 +203,26 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
         const uint64_t cost = kClassCost[n.op == OP_MUL ? C_MUL : C_LIN];
         const uint64_t direct = std::max(rt[c.a], rt[c.b]) + cost;
         // flatten: keep opening the latest-ready leaf while it is a node of the same operation
+        // (a max-heap on (ready time, earliest position in `leaves`): the leaf a linear scan for the first maximum finds)
         leaves.clear();
         leaves.push_back(c.a);
         leaves.push_back(c.b);
+        latest.clear();
+        latest.push_back(LeafKey(rt[c.a], ~0u));
+        latest.push_back(LeafKey(rt[c.b], ~1u));
+        std::make_heap(latest.begin(), latest.end());
         bool opened = false;
         while (leaves.size() < kMaxLeaves) {
-            size_t worst = 0;
-            for (size_t q = 1; q < leaves.size(); ++q)
-                if (rt[leaves[q]] > rt[leaves[worst]]) worst = q;
+            const uint32_t worst = ~latest.front().second;
             const uint32_t L = leaves[worst];
             if (!is_ac(L, n.op)) break;
+            std::pop_heap(latest.begin(), latest.end());
+            latest.pop_back();
             leaves[worst] = h.nodes[L].a;
+            latest.push_back(LeafKey(rt[h.nodes[L].a], ~worst));
+            std::push_heap(latest.begin(), latest.end());
+            latest.push_back(LeafKey(rt[h.nodes[L].b], ~(uint32_t)leaves.size()));
+            std::push_heap(latest.begin(), latest.end());
             leaves.push_back(h.nodes[L].b);
             opened = true;
         }
@@ -311,6 +323,15 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
     }
     Graph g = g_in;
+    // CWC_DEBUG_COMPILE_TIMES=1: seconds per phase on stderr
+    const bool phase_times = getenv("CWC_DEBUG_COMPILE_TIMES") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!phase_times) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "compile T=%u: %-28s %.3f s\n", T, name, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
     rewrite_pow2_divisions(g);
     size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
@@ -355,6 +376,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
     st.algorithmic_bytes_per_set = 32ull * (arity_sum + 2 * st.n_input_nodes + 2 * st.n_witness);
 
+    phase("validate");
     // ---- levels ----
     std::vector<uint32_t> level(N, 0);
     uint32_t depth = 0;
@@ -370,11 +392,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     }
     st.depth = depth;
 
+    phase("levels");
     // ---- exact depth-reducing rewrite (the statistics above describe the graph as loaded) ----
     if (bit_fusion && !getenv("CWC_NO_BIT_FUSION")) {
         fuse_bit_extract(g);
         N = g.nodes.size();
         for (const Node& n : g.nodes) st.n_bitx_nodes += n.kind == N_DUO && n.op == OP_BITX;
+        phase("bit-extract fusion");
     }
     if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
         // whole chains at T = 1 (small batches: depth is everything); at most 8 leaves per tree otherwise, where the
@@ -384,6 +408,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     }
     for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
 
+    phase("rewrites");
     // ---- constants -> table (Montgomery form), node -> ref ----
     std::vector<uint32_t> ref(N, 0);  // for consts: REF_CONST|idx ; for others: slot (filled later)
     for (size_t i = 0; i < N; ++i)
@@ -407,6 +432,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     out.consts.insert(out.consts.end(), 8, 0u);  // trailing dummy entry: the table is never empty (prefetch target)
     out.n_const = (uint32_t)(out.consts.size() / 8);
 
+    phase("constants");
     // ---- schedule: order of evaluated nodes (inputs + ops) and bundle boundaries ----
     // G == 1: file order (the reference's own loop order; best locality, every bundle is one node anyway).
     // G  > 1: list scheduling.  One bundle = up to G ready nodes of ONE class; a node is ready when all its
@@ -618,6 +644,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         return false;
     }
 
+    phase("schedule");
     // ---- operand routing -------------------------------------------------------------------------------
     // RING: produced at most RING_BUNDLES bundles ago (any node slot) -> read from the wave's result ring in LDS.
     // MEM : everything else (older values, constants, every third operand) -> its slot in the tile, staged into LDS
@@ -656,6 +683,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
     }
 
+    phase("routing");
     // ---- slot allocation (LIFO free list: a just-freed slot is still hot in cache) + encoding ----
     // Slot numbering inside a tile: constants first (index = constant index), then value slots, then the trash slot.
     const uint64_t slot_bytes = 32ull * T;
@@ -816,6 +844,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     out.n_witness = (uint32_t)g.witness_signals.size();
     out.witness_refs.resize(out.n_witness);
     for (size_t i = 0; i < g.witness_signals.size(); ++i) out.witness_refs[i] = ref[g.witness_signals[i]];
+    phase("slots + encoding");
     return true;
 }
 
