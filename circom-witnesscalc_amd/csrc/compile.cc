@@ -291,6 +291,11 @@ double program_wave_cycles(const Program& p) {
     return c - (kCycles[C_BIT] - 1500.0) * (double)p.stats.n_bitx_bundles;
 }
 
+// the multiplication and inversion bundles' part of it (bundles that are bound by instruction issue)
+double program_wave_cycles_mul_div(const Program& p) {
+    return 2350.0 * (double)p.stats.class_bundles[C_MUL] + 73500.0 * (double)p.stats.class_bundles[C_DIV];
+}
+
 static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, Program& out, std::string& err);
 
 // The list scheduler is a heuristic and exact rewrites shift how the chains of a graph line up in bundles: the program

@@ -65,16 +65,20 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t byte
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
-// W = interpreter waves per workgroup that share one divider wave (0: no divider wave, workgroup = one wave).
-template <int T, bool PROF, int W>
-__global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
+// W = interpreter waves that share one divider wave (0: no divider waves).  PACK = such units per workgroup: PACK
+// interpreter waves (W = 0), or PACK x (W interpreters + their divider) with the interpreters first.  The waves of a
+// workgroup are dealt round the CU's four SIMDs, so four-wave workgroups put one wave on every SIMD where single-wave
+// (or two-wave) workgroups land unevenly: 1024 tiles without dividers take 23.2 ms as 256 x 4 waves, 31.4 ms as 1024 x 1.
+template <int T, bool PROF, int W, int PACK>
+__global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
                                                     const uint32_t* __restrict__ crefs, InterpDims p, WsTable wst,
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
     constexpr uint32_t HI = 16u * T;  // byte distance between the two 16-byte halves of a value in a slot
     constexpr bool DIVIDER = W > 0;
-    constexpr uint32_t NW = W > 0 ? (uint32_t)W : 1u;               // interpreter waves per workgroup
+    constexpr uint32_t NW = (W > 0 ? (uint32_t)W : 1u) * (uint32_t)PACK;  // interpreter waves per workgroup
+    constexpr uint32_t WD = W > 0 ? (uint32_t)W : 1u;                       // interpreters per divider wave
     constexpr uint32_t AREA = lds_area_bytes((uint32_t)W, LDS_BYTES);  // LDS of one interpreter wave
     constexpr uint32_t ML = mbox_lanes((uint32_t)W), MB = mbox_bytes((uint32_t)W);
     const uint32_t batch = p.batch;
@@ -94,6 +98,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
     const i32x4 rsrc_w = make_rsrc_words(tile_base, (uint32_t)tile_bytes);
     const i32x4 rsrc_rec = make_rsrc_words(recs, p.n_bundles * (uint32_t)G * 16u);
+    static_assert(NW + PACK <= 16, "sequence words: 64 bytes");
     __shared__ uint4 lds[(NW * AREA + (DIVIDER ? NW * MB + 64u : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into a wave's area
     const uint32_t area = wave * AREA;  // this interpreter wave's LDS area (0 for single-wave workgroups)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)(char*)lds + area;
@@ -101,30 +106,33 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
     char* const ldsb = reinterpret_cast<char*>(lds) + area;
     char* const mbox_all = reinterpret_cast<char*>(lds) + NW * AREA;        // mailboxes, then the sequence words
     char* const mbox = mbox_all + (wave < NW ? wave : 0u) * MB;             // this interpreter's mailbox
-    volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(mbox_all + NW * MB);  // [NW] posted, [NW] = served
+    volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(mbox_all + NW * MB);  // [NW] posted, then [PACK] served
     if (DIVIDER) {
-        if (threadIdx.x <= NW) seq[threadIdx.x] = 0;  // sequence words start at zero
+        if (threadIdx.x < NW + (uint32_t)PACK) seq[threadIdx.x] = 0;  // sequence words start at zero
         __syncthreads();
-        const uint32_t first_tile = blockIdx.x * NW;
-        const uint32_t n_active = n_tiles - first_tile < NW ? n_tiles - first_tile : NW;  // interpreters with a tile
-        if (wave == NW) {
-            // ---- divider wave: serves the division requests in order (graph.rs:109: b == 0 -> 0).  Request k of
-            // every interpreter has the same div_lanes[k] active lanes; they are packed into passes of 64 lanes.
+        if (wave >= NW) {
+            // ---- divider wave d: serves the division requests of interpreters [d * W, d * W + W) in order
+            // (graph.rs:109: b == 0 -> 0).  Request k of every interpreter has the same div_lanes[k] active lanes;
+            // they are packed into passes of 64 lanes.
+            const uint32_t first_w = (wave - NW) * WD, first_tile = blockIdx.x * NW + first_w;
+            if (first_tile >= n_tiles) return;
+            const uint32_t n_active = n_tiles - first_tile < WD ? n_tiles - first_tile : WD;  // its interpreters with a tile
+            char* const mbox_d = mbox_all + first_w * MB;
             for (uint32_t k = 0; k < p.n_div_requests; ++k) {
                 bool ok = true;
-                for (uint32_t w = 0; w < n_active; ++w) ok = ok && mbox_wait(seq + w, k + 1);
+                for (uint32_t w = 0; w < n_active; ++w) ok = ok && mbox_wait(seq + first_w + w, k + 1);
                 if (!ok) {
                     if (set < batch) atomicOr(&status[set], ST_DIVIDER_TIMEOUT);
                     break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t lanes_k = NW == 1 ? 64u : p.div_lanes[k];
+                const uint32_t lanes_k = WD == 1 ? 64u : p.div_lanes[k];
                 const uint32_t total = n_active * lanes_k;
                 for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
                     const uint32_t g = g0 + lane;
                     const bool valid = g < total;
                     const uint32_t w = valid ? g / lanes_k : 0u, i = valid ? g % lanes_k : 0u;
-                    char* mb = mbox_all + w * MB + 16u * i;
+                    char* mb = mbox_d + w * MB + 16u * i;
                     const uint4* qa = reinterpret_cast<const uint4*>(mb);
                     const uint4* qb = reinterpret_cast<const uint4*>(mb + 32u * ML);
                     Fr a = fr_from_u4(qa[0], qa[ML]), b = fr_from_u4(qb[0], qb[ML]);
@@ -138,12 +146,12 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) seq[NW] = k + 1;
+                if (lane == 0) seq[wave] = k + 1;  // (served word of divider d = seq[NW + d])
             }
             return;
         }
-        if (tile_raw >= n_tiles) return;  // an interpreter wave without a tile (last workgroup)
     }
+    if (tile_raw >= n_tiles) return;  // an interpreter wave without a tile (last workgroup)
     uint32_t div_seq = 0;  // requests posted / collected so far (interpreter wave)
 
     auto ld = [&](uint32_t off) -> Fr {  // synchronous load of a slot (third operands only)
@@ -201,6 +209,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
     uint2 rec_hi = ld_rec2(0, 1);  // {dst | ctrl, a_lds | b_lds << 16} of the current bundle
     uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_wave0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     Fr r_prev = fr_zero();  // results of the previous bundle, stored one iteration late (first iteration: zeros -> trash slot)
     uint32_t doff_prev = (p.n_const + p.n_slots) * 2u * HI | t16;
     for (uint32_t b = 0; b < NBND; ++b) {
@@ -289,7 +298,7 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
                 r = fr_zero();
                 if (DIVIDER) {
                     ++div_seq;
-                    if (!mbox_wait(seq + NW, div_seq)) err_bits |= ST_DIVIDER_TIMEOUT;
+                    if (!mbox_wait(seq + NW + wave / WD, div_seq)) err_bits |= ST_DIVIDER_TIMEOUT;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if (lane < ML) {
                         const uint4* qr = reinterpret_cast<const uint4*>(mbox + lane16);
@@ -436,6 +445,13 @@ __global__ __launch_bounds__((W + 1) * 64) void interp_kernel(const uint32_t* __
     // the last bundle's results
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+    if (PROF && lane == 0) {  // every interpreter wave: longest / shortest / summed run time of the loop
+        const unsigned long long cyc = __builtin_amdgcn_s_memtime() - t_wave0;
+        atomicMax(&prof[54], cyc);
+        atomicMax(&prof[55], (1ull << 40) - cyc);
+        atomicAdd(&prof[62], cyc);
+        atomicAdd(&prof[63], 1ull);
+    }
     if (PROF && lane == 0 && (tile % 64u) == 0u) {
 #pragma unroll
         for (int c = 0; c < (int)C_COUNT; ++c) {
@@ -489,18 +505,21 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
 }
 
 // ---- launchers (called from runtime.cc) -----------------------------------------------------------
-hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p, const WsTable& wst,
-                         const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
-    const uint32_t tiles = (batch + T - 1) / T, nw = W ? W : 1u;
-    dim3 grid((tiles + nw - 1) / nw), block((W + 1) * 64);
+hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p,
+                         const WsTable& wst, const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
+    const uint32_t tiles = (batch + T - 1) / T, nw = (W ? W : 1u) * pack;
+    if (nw == 0) return hipErrorInvalidValue;
+    dim3 grid((tiles + nw - 1) / nw), block((W ? (W + 1) * pack : pack) * 64);
     const uint4* in = (const uint4*)inputs;
     const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes};
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-#define CWC_LAUNCH3(TT, PP, WW) interp_kernel<TT, PP, WW><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
-#define CWC_LAUNCH2(TT, PP)                               \
-    if (W == 0) CWC_LAUNCH3(TT, PP, 0);                   \
-    else if (W == 1) CWC_LAUNCH3(TT, PP, 1);              \
-    else if (W == 4) CWC_LAUNCH3(TT, PP, 4);              \
+#define CWC_LAUNCH3(TT, PP, WW, KK) interp_kernel<TT, PP, WW, KK><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
+#define CWC_LAUNCH2(TT, PP)                                  \
+    if (W == 0 && pack == 1) CWC_LAUNCH3(TT, PP, 0, 1);      \
+    else if (W == 0 && pack == 4) CWC_LAUNCH3(TT, PP, 0, 4); \
+    else if (W == 1 && pack == 1) CWC_LAUNCH3(TT, PP, 1, 1); \
+    else if (W == 1 && pack == 2) CWC_LAUNCH3(TT, PP, 1, 2); \
+    else if (W == 4 && pack == 1) CWC_LAUNCH3(TT, PP, 4, 1); \
     else return hipErrorInvalidValue;
 #define CWC_LAUNCH(TT)                                    \
     case TT:                                              \
@@ -510,7 +529,9 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t n_div_requests, const 
         CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32)
         case 64:
             if (W != 0) return hipErrorInvalidValue;
-            if (prof) CWC_LAUNCH3(64, true, 0); else CWC_LAUNCH3(64, false, 0);
+            if (pack == 4) { if (prof) CWC_LAUNCH3(64, true, 0, 4); else CWC_LAUNCH3(64, false, 0, 4); }
+            else if (pack == 1) { if (prof) CWC_LAUNCH3(64, true, 0, 1); else CWC_LAUNCH3(64, false, 0, 1); }
+            else return hipErrorInvalidValue;
             break;
         default: return hipErrorInvalidValue;
     }

@@ -54,6 +54,7 @@ static inline uint32_t key_divider_waves(uint32_t key) { return key & KEY_GROUP 
 // Lone-wave shader cycles of a program's bundles (measured per class on MI355X, profiles/r01_class_profile.txt): what the
 // compiler uses to choose between schedule variants and the runtime to choose a program for a batch.
 double program_wave_cycles(const Program& p);
+double program_wave_cycles_mul_div(const Program& p);
 
 // pointer-free serialisation (what is broadcast between GPUs)
 std::vector<uint8_t> program_to_blob(const Program& p);

@@ -20,8 +20,8 @@
 #include "program.hpp"
 
 namespace cwc {
-hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p, const WsTable& wst,
-                         const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof);
+hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p,
+                         const WsTable& wst, const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof);
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream);
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
 }  // namespace cwc
@@ -84,6 +84,17 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
     return "";
+}
+
+// Interpreter waves per workgroup for programs without a divider wave: workgroups of four deal the waves evenly round
+// the four SIMDs of a CU (kernels.hip); below one wave per SIMD of the chip single-wave workgroups spread further.
+// CWC_WAVES_PER_WORKGROUP (1 or 4) overrides.
+uint32_t waves_per_workgroup(uint32_t divider, uint64_t tiles) {
+    const char* e = getenv("CWC_WAVES_PER_WORKGROUP");
+    if (divider == 1) return e ? (atoi(e) >= 4 ? 2u : 1u) : (tiles > 256 ? 2u : 1u);  // units of (interpreter + divider)
+    if (divider) return 1;
+    if (e) return atoi(e) == 4 ? 4u : 1u;
+    return tiles > 512 ? 4u : 1u;
 }
 
 uint64_t workspace_budget() {
@@ -183,16 +194,23 @@ std::string check_device() {
 }
 
 // Cost model behind the automatic program choice.  A wave's time is the sum of its bundles (lone-wave shader cycles
-// per bundle class, profiles/r01_class_profile.txt); waves slow each other down as the CUs fill (measured on the
-// authV2-class graph: x1.0 at 512 waves, x1.4 at 1024, x1.6 at 2048), and beyond 2048 waves they run in rounds.
+// per bundle class, profiles/r01_class_profile.txt).  Launched as four-wave workgroups the waves sit one per SIMD up to
+// 1024 of them and cost what a lone wave costs; from there to 2048 some SIMDs hold two and the kernel takes what those
+// take: measured x1.3 for the multiplier / inversion bundles (issue-bound, two waves overlap well) and x1.9 for the
+// rest (LDS / vector-memory bound), i.e. x1.28-1.36 for the authV2-class graph and x1.75-2.0 for sha256; beyond 2048
+// waves they run in rounds.  A divider wave per interpreter counts as a wave of its CU but idles about half of the time
+// (x1.33 measured at 1024 pairs); one divider per four interpreters means five-wave workgroups, one per CU (LDS): x1.23
+// at 1024 tiles, rounds of 1024 tiles beyond.  (profiles/r01_sweep_batch_tile.txt)
 double estimate_cycles(const Program& p, size_t batch) {
     const double per_wave = program_wave_cycles(p);
+    const double heavy = program_wave_cycles_mul_div(p);
     const double waves = (double)((batch + p.T - 1) / p.T);
-    // divider waves are busy about half of the time (W = 1) and take a wave slot of their CU
-    const double with_dividers = waves * (p.divider == 1 ? 1.3 : p.divider == 4 ? 1.1 : 1.0);
-    const double resident = with_dividers < 2048 ? with_dividers : 2048;
-    const double crowd = resident <= 512 ? 1.0 : resident <= 1024 ? 1.0 + 0.4 * (resident - 512) / 512 : 1.4 + 0.2 * (resident - 1024) / 1024;
-    const double rounds = waves <= 2048 ? 1.0 : waves / 2048;
+    const double two_per_simd = (1.3 * heavy + 1.9 * (per_wave - heavy)) / per_wave;
+    if (p.divider == 4) return per_wave * 1.23 * (waves <= 1024 ? 1.0 : waves / 1024);
+    const double resident = waves * (p.divider == 1 ? 2.0 : 1.0);
+    double crowd = resident <= 1024 ? 1.0 : two_per_simd;
+    if (p.divider == 1 && resident > 1024) crowd = 1.0 + 0.75 * (crowd - 1.0);
+    const double rounds = resident <= 2048 ? 1.0 : resident / 2048;
     return per_wave * crowd * rounds;
 }
 
@@ -210,20 +228,24 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph || batch < 64) return rule;
     auto hit = g->chosen.find(batch);
     if (hit != g->chosen.end()) return hit->second;
-    size_t divider_tiles = 768;
+    size_t divider_tiles = 1024;
     if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
+    const bool debug = getenv("CWC_DEBUG_COST") != nullptr;
+    const bool has_div = g->stats.class_nodes[C_DIV] > 0;
     const uint32_t t0 = rule & ~KEY_MODE_MASK;
     uint32_t best = rule;
     double best_cost = -1;
-    for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2) {
+    for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2)
+    for (uint32_t mode : {0u, KEY_DIVIDER, KEY_GROUP}) {
         const size_t tiles = (batch + t - 1) / t;
         if (tiles > 4 * 2048) continue;
-        const bool has_div = g->stats.class_nodes[C_DIV] > 0;
-        const bool divider = tiles <= divider_tiles && has_div;
-        // one divider wave per four interpreter waves: measured to pay only while one such workgroup per CU covers the
-        // batch (a CU holds a single five-wave workgroup of this kernel)
-        const bool group = !divider && has_div && tiles > 768 && tiles <= 1024 && t <= 32 && !getenv("CWC_NO_GROUP_DIVIDER");
-        const uint32_t key = t | (divider ? KEY_DIVIDER : group ? KEY_GROUP : 0u);
+        // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
+        // workgroup per CU covers more than half of the batch at once
+        const bool divider_fits = has_div && tiles <= divider_tiles;
+        if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
+        if (mode == KEY_DIVIDER && !divider_fits) continue;
+        if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
+        const uint32_t key = t | mode;
         const Program* p = nullptr;
         auto up = g->progs.find(key);
         if (up != g->progs.end()) {
@@ -241,6 +263,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
             p = slot.get();
         }
         const double cost = estimate_cycles(*p, batch);
+        if (debug) fprintf(stderr, "cost model: batch %zu key %#x -> %.1f Mcycles\n", batch, key, cost / 1e6);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = key;
@@ -347,7 +370,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventCreate(&e2));
         HIP_TRY(hipEventRecord(e0, stream));
-        HIP_TRY(launch_interp(T, p.divider, p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
+        HIP_TRY(launch_interp(T, p.divider, waves_per_workgroup(p.divider, (nb + T - 1) / T), p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
         HIP_TRY(hipEventRecord(e2, stream));

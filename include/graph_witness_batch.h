@@ -97,7 +97,9 @@ int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
 /* Diagnostic build of the interpreter with in-kernel cycle stamps, shader cycles summed over the sampled waves:
  * out64[class*4 + 0] = cycles of the class's bundles, out64[class*4 + 3] = bundles; for MUL (k = 0) and LIN (k = 1)
  * bundles out64[48 + 8*k + {0: loop top + wait for staged operands, 1: LDS operand reads with the previous bundle's
- * stores issued behind them, 2: issuing the staging loads, 3: dispatch + arithmetic, 4: ring write, 5: bundles}].  out64 must hold 64 words. */
+ * stores issued behind them, 2: issuing the staging loads, 3: dispatch + arithmetic, 4: ring write, 5: bundles}];
+ * over all interpreter waves: out64[54] = longest run time of the loop, out64[55] = 2^40 - shortest, out64[62] = sum,
+ * out64[63] = waves.  out64 must hold 64 words. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out64, gw_status_t *status);
 

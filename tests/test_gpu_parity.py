@@ -368,3 +368,23 @@ def test_host_rows_sliced_staged_and_pinned(pkg, monkeypatch):
     # a view into the middle of a pinned allocation is pinned too
     got, st = g.calc_witness_batch(rows[5:105], out=pinned[100:200])
     assert np.array_equal(pinned[100:200], want[5:105]) and np.array_equal(pinned[:100], want[:100]) and np.array_equal(pinned[200:], want[200:])
+
+
+@pytest.mark.parametrize("waves", ["1", "4"])
+def test_workgroup_shapes_give_identical_witnesses(pkg, monkeypatch, waves):
+    """The interpreter launches single-wave workgroups or four-wave ones (four interpreters, or two interpreter +
+    divider pairs: CWC_WAVES_PER_WORKGROUP, chosen by tile count otherwise); ragged batches leave interpreter waves
+    (and whole pairs) of the last workgroup without a tile.  Same witnesses either way."""
+    monkeypatch.setenv("CWC_WAVES_PER_WORKGROUP", waves)
+    rnd = random.Random(31)
+    data = C.build_gadgets().to_bin()
+    og = cbind.Graph(data)
+    g = pkg.Graph(data)
+    for n in (1, 2, 3, 5, 9, 37):
+        rows = cbind.ints_to_array([_rand_row(rnd, 7) for _ in range(n)])
+        want, wst = og.evaluate_batch(rows)
+        for tw in (1, 2, 4, 1 | DIVIDER, 2 | DIVIDER, 4 | GROUP):
+            g.set_tile_width(tw)
+            got, st = g.calc_witness_batch(rows)
+            assert np.array_equal(st != 0, wst != 0), (n, tw)
+            assert np.array_equal(got[wst == 0], want[wst == 0]), (n, tw)

@@ -28,8 +28,10 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     tiles = (B + (tw & 0xff) - 1) // (tw & 0xff)
     nw = max(1, tiles // 64 + (1 if tiles % 64 else 0))
     sections = prof.pop("_sections")
+    wv = prof.pop("_waves")
     tot = sum(v[0] for v in prof.values())
     print("T=%d%s B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw & 0xff, " + divider wave" if tw & 0x100 else "", B, t["interp_ms"], nw, tot / nw))
+    print("   interpreter waves %d: loop cycles min %.3g mean %.3g max %.3g" % (wv["n"], wv["min_cycles"], wv["mean_cycles"], wv["max_cycles"]))
     for k, (cyc, _a, _b, n) in prof.items():
         if n:
             print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  share %.1f%%" % (k, n // nw, cyc / n, 100.0 * cyc / tot))
