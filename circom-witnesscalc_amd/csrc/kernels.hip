@@ -96,7 +96,6 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const uint32_t chunk = tile / wst.tiles_per_chunk, tile_in_chunk = tile % wst.tiles_per_chunk;
     char* tile_base = reinterpret_cast<char*>(wst.base[chunk]) + (uint64_t)tile_in_chunk * tile_bytes;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
-    const i32x4 rsrc_w = make_rsrc_words(tile_base, (uint32_t)tile_bytes);
     const i32x4 rsrc_rec = make_rsrc_words(recs, p.n_bundles * (uint32_t)G * 16u);
     static_assert(NW + PACK <= 16, "sequence words: 64 bytes");
     __shared__ uint4 lds[(NW * AREA + (DIVIDER ? NW * MB + 64u : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into a wave's area
@@ -173,13 +172,24 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     auto stage_rec = [&](uint32_t bundle) {  // records of `bundle` -> REC ring (the same record for the T lanes of a node slot)
         dma16(lds0 + LDS_REC_OFF + (bundle % REC_AHEAD) * REC_BYTES, j16, rsrc_rec, clampb(bundle) * (uint32_t)G * 16u);
     };
+    // The four loads of a bundle's memory operands share ONE M0 write (20 instead of 30 cycles per load,
+    // tools/ubench/dma_interleave.hip): the instruction offset k * 1 KiB places load k in its quarter of the STAGE cell;
+    // it also moves the memory address, which the scalar offset takes back -- through a descriptor that starts
+    // DMA_BIAS bytes in front of the tile, so that the scalar offsets stay non-negative.
+    constexpr uint32_t DMA_BIAS = 3u * LDS_HALF_BYTES;
+    const i32x4 rsrc_dma = make_rsrc_words(tile_base - DMA_BIAS, (uint32_t)tile_bytes + DMA_BIAS);
+    const uint32_t dma_soff0 = DMA_BIAS, dma_soff1 = DMA_BIAS + HI - LDS_HALF_BYTES, dma_soff2 = DMA_BIAS - 2u * LDS_HALF_BYTES,
+                   dma_soff3 = DMA_BIAS + HI - 3u * LDS_HALF_BYTES;
+    static_assert(LDS_HALF_BYTES == 1024, "instruction offsets below are written out");
     auto stage_operands = [&](uint32_t bundle, const uint2& offs) {  // memory operands of `bundle` -> STAGE ring
         const uint32_t s = lds0 + LDS_STAGE_OFF + (bundle % OPND_AHEAD) * STAGE_BYTES;
         const uint32_t ao = offs.x + t16, bo = offs.y + t16;
-        dma16(s, ao, rsrc_w, 0);
-        dma16(s + LDS_HALF_BYTES, ao, rsrc_w, HI);
-        dma16(s + 2 * LDS_HALF_BYTES, bo, rsrc_w, 0);
-        dma16(s + 3 * LDS_HALF_BYTES, bo, rsrc_w, HI);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %3, %5 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %2, %3, %6 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %2, %3, %7 offen offset:3072 lds"
+                     :: "s"(s), "v"(ao), "v"(bo), "s"(rsrc_dma), "s"(dma_soff0), "s"(dma_soff1), "s"(dma_soff2), "s"(dma_soff3) : "memory");
     };
     uint32_t err_bits = 0;
     Fr pv = fr_p();  // the modulus in VGPRs for fr_add_wave / fr_sub_wave
