@@ -117,13 +117,11 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    interp_ms, pack_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        tm = g.last_timing()  # HIP events recorded by the library on the launch stream, around each kernel
-        interp_ms.append(tm["interp_ms"])
-        pack_ms.append(tm["pack_ms"])
+        if os.environ.get("BENCH_SYNC_EACH_STEP"):  # diagnostic: the host waits for every step (exposes launch latency)
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -134,6 +132,12 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     bad_sets = int((d_st != 0).sum().item())
+    # HIP events the library recorded on the launch stream around each kernel of the timed steps (read after the run:
+    # no synchronization inside the timed region)
+    tm = g.last_timing()
+    interp_ms, pack_ms = g.timing_history(args.steps * tm["n_launches"])
+    assert len(interp_ms) == min(args.steps * tm["n_launches"], 256)
+    interp_ms, pack_ms = interp_ms * tm["n_launches"], pack_ms * tm["n_launches"]  # per step
 
     if rank == 0:
         total_sets = world * B * args.steps

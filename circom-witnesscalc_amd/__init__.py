@@ -55,7 +55,7 @@ EXPORTED_SYMBOLS = [
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
     "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width", "gwb_inputs_from_json_batch", "gwb_wtns_save_batch",
-    "gwb_host_alloc", "gwb_host_free",
+    "gwb_host_alloc", "gwb_host_free", "gwb_timing_history",
 ]
 
 
@@ -99,6 +99,8 @@ def lib():
         L.gwb_host_alloc.argtypes = [sz]
         L.gwb_host_free.restype = None
         L.gwb_host_free.argtypes = [ctypes.c_void_p]
+        L.gwb_timing_history.restype = ctypes.c_int
+        L.gwb_timing_history.argtypes = [ctypes.c_void_p, sz, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(sz)]
         L.gwb_wtns_size.restype = sz
         L.gwb_wtns_size.argtypes = [sz]
         L.gwb_wtns_from_witness.argtypes = [vp, sz, vp]
@@ -288,6 +290,16 @@ class Graph:
         rc = lib().gwb_calc_witness_batch_device(self._h, d_inputs.data_ptr(), b, d_witness.data_ptr(),
                                                  d_status.data_ptr(), s.cuda_stream, ctypes.byref(st))
         _check(rc, st)
+
+    def timing_history(self, max_launches):
+        """(interp_ms, pack_ms) float32 arrays of the most recent launches on this handle, oldest first (synchronizes
+        on their events); for timing a run of asynchronous calls without a synchronization inside it."""
+        a = np.zeros(max_launches, dtype=np.float32)
+        b = np.zeros(max_launches, dtype=np.float32)
+        n = ctypes.c_size_t(0)
+        if lib().gwb_timing_history(self._h, max_launches, a.ctypes.data, b.ctypes.data, ctypes.byref(n)) != 0:
+            raise WitnessCalcError("gwb_timing_history failed")
+        return a[:n.value], b[:n.value]
 
     def profile_classes(self, d_inputs, d_witness, d_status):
         """Diagnostic stamped build: {class: (cycles, 0, 0, bundles)} over sampled waves, plus "_sections":

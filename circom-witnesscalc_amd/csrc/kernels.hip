@@ -121,7 +121,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 bool ok = true;
                 for (uint32_t w = 0; w < n_active; ++w) ok = ok && mbox_wait(seq + first_w + w, k + 1);
                 if (!ok) {
-                    if (set < batch) atomicOr(&status[set], ST_DIVIDER_TIMEOUT);
+                    if (first_tile * T + t < batch) atomicOr(&status[first_tile * T + t], ST_DIVIDER_TIMEOUT);  // (its first interpreter's sets)
                     break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -152,6 +152,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     }
     if (tile_raw >= n_tiles) return;  // an interpreter wave without a tile (last workgroup)
     uint32_t div_seq = 0;  // requests posted / collected so far (interpreter wave)
+    if (j == 0 && set < batch) status[set] = 0;  // this tile's status words (error bits are OR-ed in at the end)
 
     auto ld = [&](uint32_t off) -> Fr {  // synchronous load of a slot (third operands only)
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);

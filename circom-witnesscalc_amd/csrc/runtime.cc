@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <atomic>
+#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
@@ -131,7 +132,11 @@ struct gwb_graph {
     gwb_timing_t timing{};
     unsigned long long* d_prof = nullptr;  // diagnostic per-class stamps (gwb_profile_classes), else null
     struct ChunkEvents { hipEvent_t start, after_interp, after_pack; };
-    std::vector<ChunkEvents> pending;  // HIP events of the last call, recorded on its launch stream
+    // HIP events of the most recent launches, recorded on their launch streams (the last `last_call_launches` of them
+    // belong to the last call); the oldest are recycled beyond kHistory launches
+    static const size_t kHistory = 256;
+    std::deque<ChunkEvents> pending;
+    size_t last_call_launches = 0;
     // host-buffer entry point: device rows and the pinned staging of the witness copy, kept between calls
     void *h_in = nullptr, *h_out = nullptr, *h_st = nullptr;
     size_t h_in_bytes = 0, h_out_bytes = 0, h_st_bytes = 0;
@@ -350,13 +355,12 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         g->filled_tiles_per_chunk = chunk_tiles;
         g->filled_chunks = per_launch;
     }
-    g->drop_events();
+    g->last_call_launches = 0;
     g->timing = gwb_timing_t{};
     g->timing.tile_width = T;
     g->timing.divider = p.divider;
     g->timing.n_bundles = p.n_bundles;
     g->timing.n_slots = p.n_slots;
-    HIP_TRY(hipMemsetAsync(d_status, 0, batch * sizeof(uint32_t), stream));
     const size_t launch_sets = per_launch * chunk_sets;
     for (size_t s0 = 0; s0 < batch; s0 += launch_sets) {
         const uint32_t nb = (uint32_t)((batch - s0) < launch_sets ? (batch - s0) : launch_sets);
@@ -366,15 +370,21 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         wst.n_chunks = (uint32_t)((nb + chunk_sets - 1) / chunk_sets);
         for (uint32_t l = 0; l < wst.n_chunks; ++l) wst.base[l] = g->d_vals[l];
         hipEvent_t e0, e1, e2;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventCreate(&e2));
+        if (g->pending.size() >= gwb_graph::kHistory) {  // recycle the oldest launch's events
+            e0 = g->pending.front().start, e1 = g->pending.front().after_interp, e2 = g->pending.front().after_pack;
+            g->pending.pop_front();
+        } else {
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventCreate(&e2));
+        }
         HIP_TRY(hipEventRecord(e0, stream));
         HIP_TRY(launch_interp(T, p.divider, waves_per_workgroup(p.divider, (nb + T - 1) / T), p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
         HIP_TRY(hipEventRecord(e2, stream));
         g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});
+        g->last_call_launches++;
         g->timing.n_launches++;
     }
     g->timing_pending = true;
@@ -713,7 +723,8 @@ int gwb_last_timing(gwb_graph_t* g, gwb_timing_t* t) {
     std::lock_guard<std::mutex> lk(g->mu);
     if (g->timing_pending) {
         float interp = 0.f, pack = 0.f;
-        for (auto& c : g->pending) {
+        for (size_t k = g->pending.size() - g->last_call_launches; k < g->pending.size(); ++k) {
+            auto& c = g->pending[k];
             float a = 0.f, b = 0.f;
             if (hipEventSynchronize(c.after_pack) != hipSuccess || hipEventElapsedTime(&a, c.start, c.after_interp) != hipSuccess ||
                 hipEventElapsedTime(&b, c.after_interp, c.after_pack) != hipSuccess)
@@ -726,6 +737,20 @@ int gwb_last_timing(gwb_graph_t* g, gwb_timing_t* t) {
         g->timing_pending = false;
     }
     *t = g->timing;
+    return 0;
+}
+
+int gwb_timing_history(gwb_graph_t* g, size_t max_launches, float* interp_ms, float* pack_ms, size_t* n_out) {
+    if (!g || !n_out || (max_launches && (!interp_ms || !pack_ms))) return 1;
+    std::lock_guard<std::mutex> lk(g->mu);
+    const size_t n = g->pending.size() < max_launches ? g->pending.size() : max_launches;
+    for (size_t i = 0; i < n; ++i) {  // chronological, ending with the most recent launch
+        auto& c = g->pending[g->pending.size() - n + i];
+        if (hipEventSynchronize(c.after_pack) != hipSuccess || hipEventElapsedTime(&interp_ms[i], c.start, c.after_interp) != hipSuccess ||
+            hipEventElapsedTime(&pack_ms[i], c.after_interp, c.after_pack) != hipSuccess)
+            return 1;
+    }
+    *n_out = n;
     return 0;
 }
 

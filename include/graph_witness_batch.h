@@ -93,6 +93,9 @@ void *gwb_host_alloc(size_t bytes);
 void gwb_host_free(void *p);
 /* Kernel times of the last batch call on this handle (synchronizes on its events). */
 int gwb_last_timing(gwb_graph_t *g, gwb_timing_t *t);
+/* Kernel times (ms) of the most recent launches on this handle, oldest first, at most max_launches (the handle keeps
+ * the events of its last 256 launches); lets a caller time a run of asynchronous calls without synchronizing in it. */
+int gwb_timing_history(gwb_graph_t *g, size_t max_launches, float *interp_ms, float *pack_ms, size_t *n_out);
 
 /* Diagnostic build of the interpreter with in-kernel cycle stamps, shader cycles summed over the sampled waves:
  * out64[class*4 + 0] = cycles of the class's bundles, out64[class*4 + 3] = bundles; for MUL (k = 0) and LIN (k = 1)
