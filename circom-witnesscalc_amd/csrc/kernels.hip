@@ -254,10 +254,49 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         const uint32_t cls = h & HDR_CLASS_MASK;
         // the two classes that are 97 % of the bundles are tested first, on a copy the compiler cannot fold into the
         // switch below (folded, every bundle walks a binary search of taken branches)
-        uint32_t cls_hot = cls;
+        uint32_t cls_hot = cls, cls_hot2 = cls;  // (two copies: one would be turned into a switch of its own)
         asm volatile("" : "+s"(cls_hot));
+        asm volatile("" : "+s"(cls_hot2));
         const bool active = (ctrl & CTRL_ACTIVE) != 0;
         const uint32_t sub = ctrl & CTRL_SUB_MASK;
+        // end of an iteration: results into the ring, pipeline registers forward.  Every class path ends with its own
+        // copy (`finish(r); continue;`): with one shared tail behind the dispatch the compiler carries "which path was
+        // taken" flags through it and the hot paths pay a chain of extra branches.
+        auto finish = [&](const Fr& r) {
+            CWC_STAMP(st4);
+            r_prev = r;
+            doff_prev = doff;
+            {   // publish the results of this bundle in the ring (read by later bundles of this wave, in order)
+                uint4* q = reinterpret_cast<uint4*>(ldsb + LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES + lane16);
+                q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+                q[LDS_HALF_BYTES / 16] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+            }
+            rec_hi = rec_hi_n1;
+            h_cur = h_n1;
+            h_n1 = h_n2;
+            // Later bundles read these stores from other lanes of this wave; a wave's vector-memory instructions
+            // execute in order, the fence only keeps the compiler from reordering them.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (PROF) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring write belongs to this bundle
+                const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+    #pragma unroll
+                for (int c = 0; c < (int)C_COUNT; ++c)
+                    if (cls == (uint32_t)c) {
+                        pf[c][0] += t_now - st0;  // cycles of this bundle in the pipelined loop (stamp bookkeeping excluded)
+                        pf[c][1] += 1;
+                    }
+                if (cls == C_MUL || cls == C_LIN) {
+                    unsigned long long* q = psec[cls == C_MUL ? 0 : 1];
+                    q[0] += st1 - st0;    // top of the loop + counted wait for the staged operands
+                    q[1] += st2 - st1;    // operand / record reads from LDS, the previous bundle's stores issued behind them
+                    q[2] += st3 - st2;    // issuing the staging loads
+                    q[3] += st4 - st3;    // class dispatch + arithmetic
+                    q[4] += t_now - st4;  // ring write
+                    q[5] += 1;
+                }
+            }
+        };
         Fr r;
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul_wave(a_op, b_op, pv);
@@ -270,7 +309,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             } else if (h & HDR_LIN_SUB) {
                 r = u256_select(sub == SUB_SUB, fr_sub_wave(a_op, b_op, pv), r);
             }
-        } else if (__builtin_expect(cls_hot == C_LIN, 1)) {
+            finish(r);
+            continue;
+        }
+        if (__builtin_expect(cls_hot2 == C_LIN, 1)) {
             // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
             // uniform (header bits); a mixed one computes both and selects per lane.
             if (!(h & HDR_LIN_SUB)) {
@@ -281,7 +323,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const unsigned long long subm = __ballot(sub == SUB_SUB);
                 r = fr_addsub_wave(a_op, b_op, pv, sub == SUB_SUB ? ~0u : 0u, subm, ~subm);
             }
-        } else
+            finish(r);
+            continue;
+        }
         switch (cls) {
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
                 const uint32_t idx = crefs[(size_t)b * G + j];
@@ -419,39 +463,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             }
             default: r = fr_zero(); break;
         }
-        CWC_STAMP(st4);
-        r_prev = r;
-        doff_prev = doff;
-        {   // publish the results of this bundle in the ring (read by later bundles of this wave, in order)
-            uint4* q = reinterpret_cast<uint4*>(ldsb + LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES + lane16);
-            q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-            q[LDS_HALF_BYTES / 16] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-        }
-        rec_hi = rec_hi_n1;
-        h_cur = h_n1;
-        h_n1 = h_n2;
-        // Later bundles read these stores from other lanes of this wave; a wave's vector-memory instructions
-        // execute in order, the fence only keeps the compiler from reordering them.
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (PROF) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring write belongs to this bundle
-            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
-#pragma unroll
-            for (int c = 0; c < (int)C_COUNT; ++c)
-                if (cls == (uint32_t)c) {
-                    pf[c][0] += t_now - st0;  // cycles of this bundle in the pipelined loop (stamp bookkeeping excluded)
-                    pf[c][1] += 1;
-                }
-            if (cls == C_MUL || cls == C_LIN) {
-                unsigned long long* q = psec[cls == C_MUL ? 0 : 1];
-                q[0] += st1 - st0;    // top of the loop + counted wait for the staged operands
-                q[1] += st2 - st1;    // operand / record reads from LDS, the previous bundle's stores issued behind them
-                q[2] += st3 - st2;    // issuing the staging loads
-                q[3] += st4 - st3;    // class dispatch + arithmetic
-                q[4] += t_now - st4;  // ring write
-                q[5] += 1;
-            }
-        }
+        finish(r);
     }
     // the last bundle's results
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
