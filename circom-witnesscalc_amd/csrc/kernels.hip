@@ -96,7 +96,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const uint32_t chunk = tile / wst.tiles_per_chunk, tile_in_chunk = tile % wst.tiles_per_chunk;
     char* tile_base = reinterpret_cast<char*>(wst.base[chunk]) + (uint64_t)tile_in_chunk * tile_bytes;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
-    const i32x4 rsrc_rec = make_rsrc_words(recs, p.n_bundles * (uint32_t)G * 16u);
+    const i32x4 rsrc_rec = make_rsrc_words(recs, (p.n_bundles + REC_AHEAD) * (uint32_t)G * 16u);  // (incl. the zero padding behind the last bundle)
     static_assert(NW + PACK <= 16, "sequence words: 64 bytes");
     __shared__ uint4 lds[(NW * AREA + (DIVIDER ? NW * MB + 64u : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into a wave's area
     const uint32_t area = wave * AREA;  // this interpreter wave's LDS area (0 for single-wave workgroups)
@@ -171,7 +171,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     if (NBND == 0) return;
     auto clampb = [&](uint32_t b) { return b < NBND ? b : NBND - 1; };
     auto stage_rec = [&](uint32_t bundle) {  // records of `bundle` -> REC ring (the same record for the T lanes of a node slot)
-        dma16(lds0 + LDS_REC_OFF + (bundle % REC_AHEAD) * REC_BYTES, j16, rsrc_rec, clampb(bundle) * (uint32_t)G * 16u);
+        // (the record array is padded by REC_AHEAD bundles: no clamp)
+        dma16(lds0 + LDS_REC_OFF + (bundle % REC_AHEAD) * REC_BYTES, j16, rsrc_rec, bundle * (uint32_t)G * 16u);
     };
     // The four loads of a bundle's memory operands share ONE M0 write (20 instead of 30 cycles per load,
     // tools/ubench/dma_interleave.hip): the instruction offset k * 1 KiB places load k in its quarter of the STAGE cell;
@@ -221,12 +222,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_wave0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t hdr_off_n2 = 8u;  // byte offset of the header two bundles ahead
     Fr r_prev = fr_zero();  // results of the previous bundle, stored one iteration late (first iteration: zeros -> trash slot)
     uint32_t doff_prev = (p.n_const + p.n_slots) * 2u * HI | t16;
     for (uint32_t b = 0; b < NBND; ++b) {
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
-        const uint32_t* const hp_n2 = hdr + clampb(b + 2);
         asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         CWC_STAMP(st1);
         const uint32_t ctrl = rec_hi.x & CTRL_MASK;
@@ -239,7 +240,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // to the compiler it lands after the staging loads, and its whole latency in front of the arithmetic: the
         // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
         uint32_t h_n2;
-        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(h_n2) : "s"(hp_n2) : "memory");
+        asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");  // (the header array is padded: no clamp)
+        hdr_off_n2 += 4u;
         // results of bundle b-1 -> tile (unconditional: values without a slot and inactive node slots go to the tile's
         // trash slot; a fixed number of vector-memory operations per bundle is what makes the counted wait possible)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);

@@ -61,7 +61,8 @@ struct DeviceProgram {
 std::string upload_program(DeviceProgram& dp) {
     const Program& p = dp.host;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_hdr = 0, o_recs = o_hdr + al(p.hdr.size() * 4), o_crefs = o_recs + al(p.recs.size() * 4),
+    // (the interpreter reads the header two bundles ahead without a clamp: 16 bytes of zero padding behind the array)
+    const size_t o_hdr = 0, o_recs = o_hdr + al(p.hdr.size() * 4 + 16), o_crefs = o_recs + al(p.recs.size() * 4 + REC_AHEAD * 1024u),  // (records are staged REC_AHEAD bundles ahead, unclamped)
                  o_consts = o_crefs + al(p.crefs.size() * 4), o_wit = o_consts + al(p.consts.size() * 4 + 32),
                  o_div = o_wit + al(p.witness_refs.size() * 4 + 4), total = o_div + al(p.div_lanes.size() * 4 + 4);
     HIP_TRY(hipMalloc(&dp.d_blob, total));
