@@ -388,3 +388,27 @@ def test_workgroup_shapes_give_identical_witnesses(pkg, monkeypatch, waves):
             got, st = g.calc_witness_batch(rows)
             assert np.array_equal(st != 0, wst != 0), (n, tw)
             assert np.array_equal(got[wst == 0], want[wst == 0]), (n, tw)
+
+
+def test_timing_history_covers_asynchronous_calls(pkg):
+    """gwb_timing_history: the handle keeps the HIP events of its most recent launches, so a run of asynchronous calls
+    can be timed after the fact (bench.py does); gwb_last_timing keeps describing the last call only."""
+    import torch
+    data = C.build_poseidon(2).to_bin()
+    g = pkg.Graph(data)
+    rnd = random.Random(41)
+    rows = cbind.ints_to_array([_rand_row(rnd, 3, 0) for _ in range(96)])
+    d_in = torch.from_numpy(rows).cuda()
+    d_out = torch.empty((96, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(96, dtype=torch.int32, device="cuda")
+    g.set_tile_width(4)
+    for _ in range(5):
+        g.calc_witness_batch_device(d_in, d_out, d_st)  # no synchronization in between
+    interp, pack = g.timing_history(3)
+    assert len(interp) == 3 and len(pack) == 3 and (interp > 0).all() and (pack > 0).all()
+    interp_all, _ = g.timing_history(1000)
+    assert 5 <= len(interp_all) <= 256
+    tm = g.last_timing()
+    assert tm["n_launches"] == 1 and abs(tm["interp_ms"] - float(interp[-1])) < 1e-6
+    want, _ = cbind.Graph(data).evaluate_batch(rows)
+    assert np.array_equal(d_out.cpu().numpy(), want) and not d_st.any().item()
