@@ -308,6 +308,19 @@ def test_digitwise_division_on_host(tmp_path, perturb, which):
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
 
 
+@pytest.mark.parametrize("constant_time", [False, True])
+def test_field_inversion_on_host(tmp_path, constant_time):
+    """fr_inv (safegcd divsteps, the inversion of the Div bundles) == Fermat's x^(r-2), x * inv(x) == 1, inv(0) == 0,
+    with the variable-time inner loop the kernels use and with the constant-time one."""
+    import subprocess
+    exe = str(tmp_path / "inv_test")
+    flags = ["-DCWC_CONSTANT_TIME_INVERSE"] if constant_time else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags +
+                          ["-o", exe, os.path.join(ROOT, "tests", "native", "inv_test.cc")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
+
+
 def test_schedule_quality_guard(pkg):
     """Bundle counts of the bench workloads must not silently regress (a wave's time is the sum of its bundles):
     round-1 values + 3 %.  authV2-class at T = 2 with the divider wave: 20 402 bundles (13 113 MUL, 6 637 LIN, 265
