@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <unordered_map>
 
 #include "program.hpp"
@@ -301,11 +302,17 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
 // The list scheduler is a heuristic and exact rewrites shift how the chains of a graph line up in bundles: the program
 // is compiled with and without the bit-extract fusion and the cheaper schedule (program_wave_cycles) is kept.
 bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err) {
-    if (!compile_variant(g, T, divider, true, out, err)) return false;
-    if (out.stats.n_bitx_nodes == 0 || getenv("CWC_NO_BIT_FUSION") || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
+    bool may_fuse = false;  // a bit extract needs a Band (as loaded, or made from a Mod by a power of two)
+    for (const Node& n : g.nodes) may_fuse |= n.kind == N_DUO && (n.op == OP_BAND || n.op == OP_MOD);
+    if (!may_fuse || getenv("CWC_NO_BIT_FUSION") || getenv("CWC_NO_SCHEDULE_VARIANTS")) return compile_variant(g, T, divider, true, out, err);
+    // both variants at once (the unfused one on a second thread; it is dropped when the graph has nothing to fuse)
     Program alt;
     std::string err2;
-    if (compile_variant(g, T, divider, false, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+    auto other = std::async(std::launch::async, [&]() { return compile_variant(g, T, divider, false, alt, err2); });
+    const bool ok = compile_variant(g, T, divider, true, out, err);
+    const bool alt_ok = other.get();
+    if (!ok) return false;
+    if (out.stats.n_bitx_nodes != 0 && alt_ok && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
     return true;
 }
 
