@@ -8,7 +8,6 @@
 
 #include <algorithm>
 #include <chrono>
-#include <future>
 #include <unordered_map>
 
 #include "program.hpp"
@@ -162,6 +161,15 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
         size_t operator()(const uint64_t& k) const { return (size_t)(k * 0x9E3779B97F4A7C15ull >> 16); }
     };
     std::unordered_map<uint64_t, uint32_t, KeyHash> vn[2];  // value numbering of Add (0) / Mul (1) nodes by operand pair
+    {
+        size_t n_add = 0, n_mul = 0;
+        for (const Node& n : g.nodes) {
+            n_add += n.kind == N_DUO && n.op == OP_ADD;
+            n_mul += n.kind == N_DUO && n.op == OP_MUL;
+        }
+        vn[0].reserve(n_add + n_add / 4);
+        vn[1].reserve(n_mul + n_mul / 4);
+    }
     auto emit = [&](const Node& n, uint64_t t) -> uint32_t {
         h.nodes.push_back(n);
         rt.push_back(t);
@@ -185,6 +193,7 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
     typedef std::pair<uint64_t, uint32_t> LeafKey;  // (ready time, ~position in `leaves`)
     std::vector<LeafKey> latest;
     std::vector<std::pair<uint64_t, uint32_t>> work;
+    std::vector<uint64_t> times;
     for (size_t i = 0; i < N; ++i) {
         const Node& n = g.nodes[i];
         if (n.kind == N_CONST) continue;
@@ -233,7 +242,7 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
             work.clear();
             for (uint32_t L : leaves) work.emplace_back(rt[L], L);
             std::sort(work.begin(), work.end());
-            std::vector<uint64_t> times;
+            times.clear();
             for (auto& w : work) times.push_back(w.first);
             while (times.size() > 1) {  // combine the two earliest
                 const uint64_t t = std::max(times[0], times[1]) + cost;
@@ -302,17 +311,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
 // The list scheduler is a heuristic and exact rewrites shift how the chains of a graph line up in bundles: the program
 // is compiled with and without the bit-extract fusion and the cheaper schedule (program_wave_cycles) is kept.
 bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err) {
-    bool may_fuse = false;  // a bit extract needs a Band (as loaded, or made from a Mod by a power of two)
-    for (const Node& n : g.nodes) may_fuse |= n.kind == N_DUO && (n.op == OP_BAND || n.op == OP_MOD);
-    if (!may_fuse || getenv("CWC_NO_BIT_FUSION") || getenv("CWC_NO_SCHEDULE_VARIANTS")) return compile_variant(g, T, divider, true, out, err);
-    // both variants at once (the unfused one on a second thread; it is dropped when the graph has nothing to fuse)
+    if (!compile_variant(g, T, divider, true, out, err)) return false;
+    if (out.stats.n_bitx_nodes == 0 || getenv("CWC_NO_BIT_FUSION") || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
+    // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
+    // authV2-class graph, and slower for multi-million-node graphs)
     Program alt;
     std::string err2;
-    auto other = std::async(std::launch::async, [&]() { return compile_variant(g, T, divider, false, alt, err2); });
-    const bool ok = compile_variant(g, T, divider, true, out, err);
-    const bool alt_ok = other.get();
-    if (!ok) return false;
-    if (out.stats.n_bitx_nodes != 0 && alt_ok && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+    if (compile_variant(g, T, divider, false, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
     return true;
 }
 
