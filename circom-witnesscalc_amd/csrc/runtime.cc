@@ -11,6 +11,7 @@
 #include <mutex>
 #include <atomic>
 #include <deque>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
@@ -241,33 +242,42 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     const uint32_t t0 = rule & ~KEY_MODE_MASK;
     uint32_t best = rule;
     double best_cost = -1;
+    std::vector<uint32_t> keys;
     for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2)
-    for (uint32_t mode : {0u, KEY_DIVIDER, KEY_GROUP}) {
-        const size_t tiles = (batch + t - 1) / t;
-        if (tiles > 4 * 2048) continue;
-        // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
-        // workgroup per CU covers more than half of the batch at once
-        const bool divider_fits = has_div && tiles <= divider_tiles;
-        if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
-        if (mode == KEY_DIVIDER && !divider_fits) continue;
-        if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
-        const uint32_t key = t | mode;
+        for (uint32_t mode : {0u, KEY_DIVIDER, KEY_GROUP}) {
+            const size_t tiles = (batch + t - 1) / t;
+            if (tiles > 4 * 2048) continue;
+            // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
+            // workgroup per CU covers more than half of the batch at once
+            const bool divider_fits = has_div && tiles <= divider_tiles;
+            if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
+            if (mode == KEY_DIVIDER && !divider_fits) continue;
+            if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
+            keys.push_back(t | mode);
+        }
+    // the candidates that are not compiled yet, each on a thread of its own (the compiler only reads the graph)
+    std::vector<std::pair<uint32_t, std::future<std::unique_ptr<Program>>>> jobs;
+    for (uint32_t key : keys)
+        if (!g->progs.count(key) && !g->compiled.count(key)) {
+            const Graph* graph = &g->graph;
+            jobs.emplace_back(key, std::async(std::launch::async, [graph, key]() {
+                                  std::unique_ptr<Program> p(new Program());
+                                  std::string err;
+                                  if (!compile_program(*graph, key & ~KEY_MODE_MASK, key_divider_waves(key), *p, err)) p.reset();
+                                  return p;
+                              }));
+        }
+    for (auto& j : jobs) {
+        std::unique_ptr<Program> p = j.second.get();
+        if (p) g->compiled[j.first] = std::move(p);
+    }
+    for (uint32_t key : keys) {
         const Program* p = nullptr;
         auto up = g->progs.find(key);
-        if (up != g->progs.end()) {
-            p = &up->second->host;
-        } else {
-            auto& slot = g->compiled[key];
-            if (!slot) {
-                slot.reset(new Program());
-                std::string err;
-                if (!compile_program(g->graph, t, key_divider_waves(key), *slot, err)) {
-                    g->compiled.erase(key);
-                    continue;
-                }
-            }
-            p = slot.get();
-        }
+        auto pre = g->compiled.find(key);
+        if (up != g->progs.end()) p = &up->second->host;
+        else if (pre != g->compiled.end()) p = pre->second.get();
+        else continue;  // (did not compile: not a candidate)
         const double cost = estimate_cycles(*p, batch);
         if (debug) fprintf(stderr, "cost model: batch %zu key %#x -> %.1f Mcycles\n", batch, key, cost / 1e6);
         if (best_cost < 0 || cost < best_cost) {
