@@ -219,6 +219,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     stage_operands(0, ld_rec2(0, 0));
     stage_operands(1, ld_rec2(1, 0));
     uint2 rec_hi = ld_rec2(0, 1);  // {dst | ctrl, a_lds | b_lds << 16} of the current bundle
+    uint2 rec_hi_n1 = ld_rec2(1, 1);  // ... of the next one (the record of bundle b+2 is read whole in iteration b)
     uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_wave0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -234,8 +235,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         const uint32_t doff = (rec_hi.x & ~CTRL_MASK) | t16;
         const uint32_t la = rec_hi.y + (t16 | (t16 << 16));
         const Fr a_op = ld_lds(la & 0xffffu), b_op = ld_lds(la >> 16);
-        const uint2 rec_n2 = ld_rec2(b + 2, 0);    // {a_off, b_off} of bundle b+2
-        const uint2 rec_hi_n1 = ld_rec2(b + 1, 1);
+        // the record of bundle b+2, whole: {a_off, b_off} for its staging loads now, the other half two iterations on
+        const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
+        const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
         // header of bundle b+2: a scalar load issued behind the LDS reads and retired with them by the wait below (left
         // to the compiler it lands after the staging loads, and its whole latency in front of the arithmetic: the
         // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
@@ -247,7 +249,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
         // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2] / REC[b mod 4]
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n1.x) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
         CWC_STAMP(st2);
         stage_operands(b + 2, rec_n2);
         stage_rec(b + 4);
@@ -274,6 +276,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 q[LDS_HALF_BYTES / 16] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
             }
             rec_hi = rec_hi_n1;
+            rec_hi_n1 = rec_hi_n2;
             h_cur = h_n1;
             h_n1 = h_n2;
             // Later bundles read these stores from other lanes of this wave; a wave's vector-memory instructions
