@@ -352,8 +352,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     rewrite_pow2_divisions(g);
     size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
-    if (divider != 0 && divider != 1 && divider != 4) {
-        err = "divider waves serve 1 or 4 interpreter waves";
+    if (divider != 0 && divider != 1 && divider != 3 && divider != 4) {
+        err = "divider waves serve 1, 3 or 4 interpreter waves";
         return false;
     }
     if (G == 1) divider = 0;  // T = 64 keeps the reference's node order, one node per bundle
@@ -891,7 +891,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 8 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 8 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

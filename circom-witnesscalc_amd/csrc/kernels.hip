@@ -547,6 +547,7 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     else if (W == 0 && pack == 4) CWC_LAUNCH3(TT, PP, 0, 4); \
     else if (W == 1 && pack == 1) CWC_LAUNCH3(TT, PP, 1, 1); \
     else if (W == 1 && pack == 2) CWC_LAUNCH3(TT, PP, 1, 2); \
+    else if (W == 3 && pack == 1) CWC_LAUNCH3(TT, PP, 3, 1); \
     else if (W == 4 && pack == 1) CWC_LAUNCH3(TT, PP, 4, 1); \
     else return hipErrorInvalidValue;
 #define CWC_LAUNCH(TT)                                    \

@@ -48,8 +48,10 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
 // "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER | KEY_GROUP
 static const uint32_t KEY_DIVIDER = 0x100u;  // one divider wave per interpreter wave
 static const uint32_t KEY_GROUP = 0x200u;    // one divider wave per four interpreter waves
-static const uint32_t KEY_MODE_MASK = KEY_DIVIDER | KEY_GROUP;
-static inline uint32_t key_divider_waves(uint32_t key) { return key & KEY_GROUP ? 4u : key & KEY_DIVIDER ? 1u : 0u; }
+static const uint32_t KEY_TRIPLE = 0x400u;   // one divider wave per three interpreter waves (a four-wave workgroup: one wave per SIMD)
+static const uint32_t KEY_MODE_MASK = KEY_DIVIDER | KEY_GROUP | KEY_TRIPLE;
+static inline uint32_t key_divider_waves(uint32_t key) { return key & KEY_GROUP ? 4u : key & KEY_TRIPLE ? 3u : key & KEY_DIVIDER ? 1u : 0u; }
+static inline uint32_t key_mode_of_divider(uint32_t divider) { return divider == 4 ? KEY_GROUP : divider == 3 ? KEY_TRIPLE : divider ? KEY_DIVIDER : 0u; }
 
 // Lone-wave shader cycles of a program's bundles (measured per class on MI355X, profiles/r01_class_profile.txt): what the
 // compiler uses to choose between schedule variants and the runtime to choose a program for a batch.

@@ -214,6 +214,9 @@ double estimate_cycles(const Program& p, size_t batch) {
     const double waves = (double)((batch + p.T - 1) / p.T);
     const double two_per_simd = (1.3 * heavy + 1.9 * (per_wave - heavy)) / per_wave;
     if (p.divider == 4) return per_wave * 1.23 * (waves <= 1024 ? 1.0 : waves / 1024);
+    // three interpreters + their divider = a four-wave workgroup, one per CU: every wave has its SIMD up to 768 tiles;
+    // the shared divider costs 8 % against a divider per interpreter (measured at 512 tiles: 16.8 vs 15.6 ms)
+    if (p.divider == 3) return per_wave * 1.08 * (waves <= 768 ? 1.0 : two_per_simd * (waves <= 1536 ? 1.0 : waves / 1536));
     const double resident = waves * (p.divider == 1 ? 2.0 : 1.0);
     double crowd = resident <= 1024 ? 1.0 : two_per_simd;
     if (p.divider == 1 && resident > 1024) crowd = 1.0 + 0.75 * (crowd - 1.0);
@@ -244,7 +247,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     double best_cost = -1;
     std::vector<uint32_t> keys;
     for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2)
-        for (uint32_t mode : {0u, KEY_DIVIDER, KEY_GROUP}) {
+        for (uint32_t mode : {0u, KEY_DIVIDER, KEY_TRIPLE, KEY_GROUP}) {
             const size_t tiles = (batch + t - 1) / t;
             if (tiles > 4 * 2048) continue;
             // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
@@ -252,6 +255,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
             const bool divider_fits = has_div && tiles <= divider_tiles;
             if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
             if (mode == KEY_DIVIDER && !divider_fits) continue;
+            if (mode == KEY_TRIPLE && !(has_div && tiles > 512 && tiles <= 768 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
             if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
             keys.push_back(t | mode);
         }
@@ -689,7 +693,8 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
 
 int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
     const uint32_t T = key & ~KEY_MODE_MASK;
-    if (!g || T > 64 || (T & (T - 1)) || (key & KEY_MODE_MASK && T == 0) || (key & KEY_MODE_MASK) == KEY_MODE_MASK) return 1;
+    const uint32_t mode = key & KEY_MODE_MASK;
+    if (!g || T > 64 || (T & (T - 1)) || (mode && T == 0) || (mode & (mode - 1))) return 1;  // (at most one divider mode)
     g->forced_T = key;
     return 0;
 }
@@ -868,7 +873,7 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     err = check_device();
     if (err.empty()) err = upload_program(*dp);
     if (!err.empty()) return fail(status, err);
-    const uint32_t T = dp->host.T | (dp->host.divider == 4 ? KEY_GROUP : dp->host.divider ? KEY_DIVIDER : 0u);
+    const uint32_t T = dp->host.T | key_mode_of_divider(dp->host.divider);
     g->progs[T] = std::move(dp);
     *out = g.release();
     set_status(status, OK, "");

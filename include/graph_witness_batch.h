@@ -71,6 +71,9 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
 /* ... or with GWB_TILE_GROUP_DIVIDER = one divider wave per FOUR interpreter waves, which packs their division requests
  * into the lanes of one inversion (throughput regime, widths up to 32). */
 #define GWB_TILE_GROUP_DIVIDER 0x200u
+/* ... or with GWB_TILE_TRIPLE_DIVIDER = one divider wave per THREE interpreter waves: a four-wave workgroup, one wave on
+ * every SIMD of its CU, so 768 tiles run at the speed of one (the choice for 513..768 tiles). */
+#define GWB_TILE_TRIPLE_DIVIDER 0x400u
 /* 0 = choose from the batch size (default); else a program key */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
 /* the program key the library chooses for a batch of this size */

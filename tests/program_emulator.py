@@ -48,7 +48,7 @@ class Blob:
         assert self.n_const >= 1 and self.consts[-1] == 0  # trailing dummy entry (prefetch target)
         self.witness_refs = take(self.n_witness)
         self.div_lanes = take(self.n_div_requests)
-        assert self.divider in (0, 1, 4) and pos <= len(data)  # (an exported blob carries the input map behind the program)
+        assert self.divider in (0, 1, 3, 4) and pos <= len(data)  # (an exported blob carries the input map behind the program)
 
 
 def run(blob: Blob, inputs_row):

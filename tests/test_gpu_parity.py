@@ -28,9 +28,10 @@ def _rand_row(rnd, n, small=0.3):
 
 DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER
 GROUP = 0x200    # GWB_TILE_GROUP_DIVIDER
+TRIPLE = 0x400   # GWB_TILE_TRIPLE_DIVIDER
 
 
-def _check(pkg, data, rows, tiles=(1, 4, 64, 1 | DIVIDER, 4 | DIVIDER, 4 | GROUP)):
+def _check(pkg, data, rows, tiles=(1, 4, 64, 1 | DIVIDER, 4 | DIVIDER, 4 | GROUP, 2 | TRIPLE)):
     g = pkg.Graph(data)
     og = cbind.Graph(data)
     inp = cbind.ints_to_array(rows)
@@ -383,7 +384,7 @@ def test_workgroup_shapes_give_identical_witnesses(pkg, monkeypatch, waves):
     for n in (1, 2, 3, 5, 9, 37):
         rows = cbind.ints_to_array([_rand_row(rnd, 7) for _ in range(n)])
         want, wst = og.evaluate_batch(rows)
-        for tw in (1, 2, 4, 1 | DIVIDER, 2 | DIVIDER, 4 | GROUP):
+        for tw in (1, 2, 4, 1 | DIVIDER, 2 | DIVIDER, 4 | GROUP, 1 | TRIPLE, 4 | TRIPLE):
             g.set_tile_width(tw)
             got, st = g.calc_witness_batch(rows)
             assert np.array_equal(st != 0, wst != 0), (n, tw)

@@ -152,10 +152,11 @@ def test_wtns_framing(pkg):
 
 DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER: programs for the asynchronous divider wave
 GROUP = 0x200    # GWB_TILE_GROUP_DIVIDER: one divider wave per four interpreter waves
+TRIPLE = 0x400   # GWB_TILE_TRIPLE_DIVIDER: one divider wave per three interpreter waves
 
 
 @pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64, 1 | DIVIDER, 2 | DIVIDER, 8 | DIVIDER, 32 | DIVIDER,
-                                  1 | GROUP, 4 | GROUP, 32 | GROUP])
+                                  1 | GROUP, 4 | GROUP, 32 | GROUP, 1 | TRIPLE, 2 | TRIPLE, 16 | TRIPLE])
 def test_graph_compiler_emulated(pkg, tile):
     """Level scheduling, bundling, slot reuse and operand encoding for every tile width and both division
     strategies (host logic only)."""
@@ -168,9 +169,9 @@ def test_graph_compiler_emulated(pkg, tile):
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
         g = pkg.Graph(data)
         blob = pe.Blob(g.export_blob(key))
-        assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 4 if key & GROUP else 0)
+        assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 4 if key & GROUP else 3 if key & TRIPLE else 0)
         n_div = sum(1 for n in nodes if n[0] == "Duo" and n[1] == "Div")
-        if key & (DIVIDER | GROUP):
+        if key & (DIVIDER | GROUP | TRIPLE):
             assert blob.stats["class_nodes"][9] == blob.stats["class_nodes"][10] == n_div and blob.stats["class_nodes"][3] == 0
         else:
             assert blob.stats["class_nodes"][3] == n_div and blob.n_div_requests == 0
@@ -246,7 +247,7 @@ def test_power_of_two_division_rewrite_is_exact(pkg):
         assert pe.run(blob, [1, xv])[0] == model.evaluate(nodes, [1, xv], wit)
 
 
-@pytest.mark.parametrize("key", [2, 2 | DIVIDER, 16, 4 | GROUP])
+@pytest.mark.parametrize("key", [2, 2 | DIVIDER, 16, 4 | GROUP, 2 | TRIPLE])
 def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
     """Tree-height reduction, shared subexpressions, dead-node elimination, linear riders in multiplication bundles and
     request/collect divisions: long Add / Mul chains with constants, repeated operands, witness elements in the middle of

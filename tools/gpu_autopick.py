@@ -27,5 +27,5 @@ for kind, builder in (("authv2", C.build_authv2_class()), ("sha256", C.build_sha
             best = min(best, time.perf_counter() - t0)
         tm = g.last_timing()
         print("%-7s B=%-6d auto -> T=%-2d%s  %7.1f ms  %9.0f wit/s  (first call incl. compiles %.1f s)" % (
-            kind, B, tm["tile_width"], {0: "  ", 1: "+D", 4: "+G"}[tm["divider"]], best * 1e3, B / best, first), flush=True)
+            kind, B, tm["tile_width"], {0: "  ", 1: "+D", 3: "+3", 4: "+G"}[tm["divider"]], best * 1e3, B / best, first), flush=True)
         del d_in, d_out, d_st

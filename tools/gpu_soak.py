@@ -15,7 +15,7 @@ from tools.graphgen import circuits as C
 M = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 EDGE = [0, 1, 2, 3, 63, 64, 65, 127, 128, 253, 254, 255, 256, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, 1 << 64,
         (1 << 128) - 1, 1 << 200, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
-KEYS = [1, 2, 4, 8, 16, 32, 64, 1 | 0x100, 2 | 0x100, 8 | 0x100, 32 | 0x100, 1 | 0x200, 4 | 0x200, 16 | 0x200]
+KEYS = [1, 2, 4, 8, 16, 32, 64, 1 | 0x100, 2 | 0x100, 8 | 0x100, 32 | 0x100, 1 | 0x200, 4 | 0x200, 16 | 0x200, 1 | 0x400, 2 | 0x400, 8 | 0x400]
 def run(n_seeds, base, verbose=True):
     """returns the number of mismatching (graph, program) runs"""
     rnd = random.Random(base)

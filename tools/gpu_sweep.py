@@ -30,7 +30,7 @@ def run(kind, builder, cases):
             tm = g.last_timing()
             ok = np.array_equal(d_out[[0, B // 2, B - 1]].cpu().numpy(), want) and int((d_st != 0).sum()) == 0
             print("  %-7s B=%-6d T=%-2d%s launches=%-2d wall %8.1f ms -> %9.0f wit/s  %.3g field-ops/s  alg-roofline frac %.3f  parity=%s" % (
-                kind, B, tm["tile_width"], {0: "  ", 1: "+D", 4: "+G"}[tm["divider"]], tm["n_launches"], best * 1e3, B / best, g.n_op * B / best,
+                kind, B, tm["tile_width"], {0: "  ", 1: "+D", 3: "+3", 4: "+G"}[tm["divider"]], tm["n_launches"], best * 1e3, B / best, g.n_op * B / best,
                 g.algorithmic_bytes_per_set * B / best / 8e12, ok), flush=True)
         del d_in, d_out, d_st
         torch.cuda.empty_cache()
