@@ -139,6 +139,15 @@ static void fuse_bit_extract(Graph& g) {
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
 static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 100, 110, 175, 38, 22, 22};
+// The same for graphs whose linear nodes outnumber their multiplications (sha256-like: wide, LIN bundles are half of
+// the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
+// first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
+// narrow linear steps in between) loses 3 % with it and keeps the measured ratio.
+static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22};
+// What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
+// a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
+// at the end of round 1 (MUL 2 100, LIN 670, request / collect 1 300).
+static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26};
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -149,7 +158,7 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 100, 110, 17
 // round).  The intermediate nodes of the chain are still computed wherever something else (a witness element, another
 // node) needs them; common subexpressions are shared; nodes that end up unused are dropped.
 // Only Add/Mul nodes are touched, so every operation that can fail (graph.rs:634, :686-716) survives unchanged.
-static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
+static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost) {
     const size_t N = g.nodes.size();
     Graph h;
     h.const_values = g.const_values;
@@ -184,7 +193,7 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
         auto& table = vn[op == OP_MUL];
         auto it = table.find(key);
         if (it != table.end()) return it->second;
-        const uint64_t cost = kClassCost[op == OP_MUL ? C_MUL : C_LIN];
+        const uint64_t cost = class_cost[op == OP_MUL ? C_MUL : C_LIN];
         const uint32_t idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
         table.emplace(key, idx);
         return idx;
@@ -207,10 +216,10 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves) {
             if (ar >= 1) t = rt[c.a];
             if (ar >= 2) t = std::max(t, rt[c.b]);
             if (ar >= 3) t = std::max(t, rt[c.c]);
-            m[i] = emit(c, t + kClassCost[class_of(n)]);
+            m[i] = emit(c, t + class_cost[class_of(n)]);
             continue;
         }
-        const uint64_t cost = kClassCost[n.op == OP_MUL ? C_MUL : C_LIN];
+        const uint64_t cost = class_cost[n.op == OP_MUL ? C_MUL : C_LIN];
         const uint64_t direct = std::max(rt[c.a], rt[c.b]) + cost;
         // flatten: keep opening the latest-ready leaf while it is a node of the same operation
         // (a max-heap on (ready time, earliest position in `leaves`): the leaf a linear scan for the first maximum finds)
@@ -417,10 +426,20 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (const Node& n : g.nodes) st.n_bitx_nodes += n.kind == N_DUO && n.op == OP_BITX;
         phase("bit-extract fusion");
     }
+    // scheduling weights by class: linear-heavy graphs (more Add / Sub than Mul nodes) take the heavier linear weight
+    const uint32_t* class_cost = kClassCost;
+    {
+        size_t n_lin = 0, n_mul = 0;
+        for (const Node& n : g.nodes) {
+            n_lin += n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_SUB);
+            n_mul += n.kind == N_DUO && n.op == OP_MUL;
+        }
+        if (n_lin > n_mul && !getenv("CWC_NO_LIN_HEAVY_WEIGHTS")) class_cost = kClassCostLinHeavy;
+    }
     if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
         // whole chains at T = 1 (small batches: depth is everything); at most 8 leaves per tree otherwise, where the
         // extra nodes of wide trees cost lanes and memory traffic (measured on sha256_512: 293 k vs 265 k wit/s at 4096 sets)
-        reduce_tree_height(g, G >= 64 ? 64 : 8);
+        reduce_tree_height(g, G >= 64 ? 64 : 8, class_cost);
         N = g.nodes.size();
     }
     for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
@@ -472,7 +491,6 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 order.push_back((uint32_t)i);
             }
     } else {
-        const uint32_t* class_cost = kClassCost;
         std::vector<uint64_t> height(N, 0);
         std::vector<uint32_t> indeg(N, 0);
         std::vector<std::vector<uint32_t>> users;  // adjacency (only non-const producers)
@@ -588,7 +606,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     out.div_lanes.push_back((uint32_t)in_flight.size() * T);
                     in_flight.clear();
                     out.n_div_requests++;
-                    clock += class_cost[C_LIN];
+                    clock += kClockCost[C_DIVGET];
                     continue;
                 }
                 if (best == C_DIV) {  // a second request has to wait for the first one: run the best other class
@@ -645,11 +663,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             if (best == C_DIV && divider) {
                 emit_bundle(picked, true, false);
                 in_flight = picked;
-                clock += class_cost[C_LIN];
-                in_flight_ready = clock + class_cost[C_DIV];
+                clock += kClockCost[C_DIVREQ];
+                in_flight_ready = clock + kClockCost[C_DIV];
             } else {
                 emit_bundle(picked, false, false);
-                clock += class_cost[best];
+                clock += kClockCost[best];
             }
         }
     }

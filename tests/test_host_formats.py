@@ -324,18 +324,19 @@ def test_field_inversion_on_host(tmp_path, constant_time):
 
 def test_schedule_quality_guard(pkg):
     """Bundle counts of the bench workloads must not silently regress (a wave's time is the sum of its bundles):
-    round-1 values + 3 %.  authV2-class at T = 2 with the divider wave: 20 402 bundles (13 113 MUL, 6 637 LIN, 265
-    requests); sha256_512 at T = 1: 6 055."""
+    round-1 values + 3 %.  authV2-class at T = 2 with the divider wave: 21 003 bundles (13 026 MUL, 7 323 LIN, 265
+    requests -- more linear bundles than a faster scheduler clock would give, but no waiting in the collect bundles);
+    sha256_512 at T = 1: 5 399."""
     import struct
     g = pkg.Graph(C.build_authv2_class().to_bin())
     blob = g.export_blob(2 | DIVIDER)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
     cb = dict(zip(pe.CLASS_NAMES, h[12:][17:28]))
-    assert h[4] <= 21000 and cb["MUL"] <= 13500 and cb["LIN"] <= 6850 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0
+    assert h[4] <= 21650 and cb["MUL"] <= 13450 and cb["LIN"] <= 7550 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0
     blob = g.export_blob(4)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
     cb = dict(zip(pe.CLASS_NAMES, h[12:][17:28]))
     assert h[4] <= 25900 and cb["DIV"] <= 275
     g = pkg.Graph(C.build_sha256(512).to_bin())
     h = struct.unpack_from(pe.HDR_FMT, g.export_blob(1), 0)
-    assert h[4] <= 6250
+    assert h[4] <= 5600
