@@ -439,7 +439,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
         // whole chains at T = 1 (small batches: depth is everything); at most 8 leaves per tree otherwise, where the
         // extra nodes of wide trees cost lanes and memory traffic (measured on sha256_512: 293 k vs 265 k wit/s at 4096 sets)
-        reduce_tree_height(g, G >= 64 ? 64 : 8, class_cost);
+        size_t leaves = G >= 64 ? 64 : 8;
+        if (const char* e = getenv("CWC_TREE_LEAVES")) leaves = (size_t)std::max(2, atoi(e));  // (A/B knob)
+        reduce_tree_height(g, leaves, class_cost);
         N = g.nodes.size();
     }
     for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
@@ -540,7 +542,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         // operations between a node and the nearest division that depends on it (saturating)
         static const uint32_t kFar = 0xffffu;
-        uint32_t div_wait_ops = 6;
+        // (with a divider wave a request costs two cheap bundles, not an inversion: waiting for fewer siblings pays --
+        // measured 3 against 6: +1.4 % at 1024 sets, +2.6 % at 2048)
+        uint32_t div_wait_ops = divider ? 3 : 6;
         if (const char* e = getenv("CWC_SCHED_DIV_WAIT")) div_wait_ops = (uint32_t)atoi(e);
         std::vector<uint16_t> dist_to_div(N, (uint16_t)kFar);
         for (size_t i = N; i-- > 0;) {
