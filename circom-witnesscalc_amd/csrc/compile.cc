@@ -542,9 +542,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         // operations between a node and the nearest division that depends on it (saturating)
         static const uint32_t kFar = 0xffffu;
-        // (with a divider wave a request costs two cheap bundles, not an inversion: waiting for fewer siblings pays --
-        // measured 3 against 6: +1.4 % at 1024 sets, +2.6 % at 2048)
-        uint32_t div_wait_ops = divider ? 3 : 6;
+        // (measured 3 against 6 and 10: +1.4 % at 1024 sets and +2.6 % at 2048 with divider waves, +1.4 % at 8192 and
+        // 16384 sets with inline inversions)
+        uint32_t div_wait_ops = 3;
         if (const char* e = getenv("CWC_SCHED_DIV_WAIT")) div_wait_ops = (uint32_t)atoi(e);
         std::vector<uint16_t> dist_to_div(N, (uint16_t)kFar);
         for (size_t i = N; i-- > 0;) {
