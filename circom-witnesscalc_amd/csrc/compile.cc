@@ -138,7 +138,7 @@ static void fuse_bit_extract(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 22, 1470, 25, 100, 110, 175, 38, 22, 22};
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
 // The same for graphs whose linear nodes outnumber their multiplications (sha256-like: wide, LIN bundles are half of
 // the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
 // first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
