@@ -138,16 +138,16 @@ static void fuse_bit_extract(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
 // The same for graphs whose linear nodes outnumber their multiplications (sha256-like: wide, LIN bundles are half of
 // the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
 // first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
 // narrow linear steps in between) loses 3 % with it and keeps the measured ratio.
-static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22};
+static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26};
 // What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
 // at the end of round 1 (MUL 2 100, LIN 670, request / collect 1 300).
-static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26};
+static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24};
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -303,34 +303,68 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
     g.nodes.swap(kept);
 }
 
+// Lone-wave shader cycles per bundle class in the product kernel (stamped build minus its five ~40-cycle stamps,
+// profiles/r02_class_profile.txt; check: 12 953 MUL + 7 258 LIN + 265 request / collect pairs -> 32.8 M cycles = 13.7 ms
+// at 2.4 GHz against 13.6 ms measured for the round-1 program).
+static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 2200, 8500, 1450, 1490, 3700, 1306};
+static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60;
 double program_wave_cycles(const Program& p) {
-    static const double kCycles[C_COUNT] = {5000, 2350, 1150, 73500, 1250, 4900, 5500, 8700, 1900, 1450, 1450};
     double c = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)p.stats.class_bundles[k];
-    return c - (kCycles[C_BIT] - 1500.0) * (double)p.stats.n_bitx_bundles;
+    return c - (kCycles[C_BIT] - kCyclesBitx) * (double)p.stats.n_bitx_bundles + kCyclesCoopRiders * (double)p.stats.n_coop_rider_bundles;
 }
 
 // the multiplication and inversion bundles' part of it (bundles that are bound by instruction issue)
 double program_wave_cycles_mul_div(const Program& p) {
-    return 2350.0 * (double)p.stats.class_bundles[C_MUL] + 73500.0 * (double)p.stats.class_bundles[C_DIV];
+    return kCycles[C_MUL] * (double)p.stats.class_bundles[C_MUL] + kCycles[C_MULQ] * (double)p.stats.class_bundles[C_MULQ] +
+           kCycles[C_DIV] * (double)p.stats.class_bundles[C_DIV];
 }
 
-static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, Program& out, std::string& err);
+// When a multiplication step becomes a narrow (four lanes per product) bundle: `fill` or more ready multiplications make
+// a full-width bundle instead (it costs the same with 10 or 32 nodes); otherwise a narrow one if the multiplications
+// within `slack` (scheduler cost units, a multiplication level is 47) of the most urgent ready node fit it.  The rest
+// stays ready.  fill = 0: never narrow.
+struct CoopPolicy {
+    uint32_t fill;
+    uint64_t slack;
+};
+static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err);
 
-// The list scheduler is a heuristic and exact rewrites shift how the chains of a graph line up in bundles: the program
-// is compiled with and without the bit-extract fusion and the cheaper schedule (program_wave_cycles) is kept.
+// The list scheduler is a heuristic, and exact rewrites and the narrow-bundle policy shift how the chains of a graph line
+// up in bundles: the program is compiled with and without the bit-extract fusion, then under a few narrow-bundle
+// policies, and the cheapest schedule by the measured cycles per bundle class (program_wave_cycles) is kept -- the
+// policies are not fitted to one graph, the cost model picks per graph and tile width.
 bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err) {
-    if (!compile_variant(g, T, divider, true, out, err)) return false;
-    if (out.stats.n_bitx_nodes == 0 || getenv("CWC_NO_BIT_FUSION") || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
+    const uint32_t G = T ? 64 / T : 1;
+    CoopPolicy base{G, ~0ull};  // narrow whenever everything ready fits
+    if (const char* e = getenv("CWC_COOP_FILL")) base.fill = (uint32_t)atol(e);
+    if (const char* e = getenv("CWC_COOP_SLACK")) base.slack = (uint64_t)atol(e);
+    const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
+    if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
+    if (!compile_variant(g, T, divider, true, base, out, err)) return false;
+    if (getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
     // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
     // authV2-class graph, and slower for multi-million-node graphs)
-    Program alt;
-    std::string err2;
-    if (compile_variant(g, T, divider, false, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+    bool fusion = true;
+    if (out.stats.n_bitx_nodes != 0 && !getenv("CWC_NO_BIT_FUSION")) {
+        Program alt;
+        std::string err2;
+        if (compile_variant(g, T, divider, false, base, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) {
+            out = std::move(alt);
+            fusion = false;
+        }
+    }
+    if (base.fill == 0 || forced || g.nodes.size() > 2000000) return true;  // (huge graphs: one schedule, compile time counts)
+    const CoopPolicy more[] = {{0, 0}, {std::max(12u, G * 3 / 8), 0}, {G / 2, 94}, {G * 5 / 8, 94}};
+    for (const CoopPolicy& pol : more) {
+        Program alt;
+        std::string err2;
+        if (compile_variant(g, T, divider, fusion, pol, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+    }
     return true;
 }
 
-static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, Program& out, std::string& err) {
+static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
@@ -484,12 +518,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint32_t> use_bundle_of(N, 0xffffffffu);  // bundle that reads the node's operands (differs for a
                                                           // division handed to the divider wave: request vs. collect)
     std::vector<uint32_t> bundle_start;  // index into order
+    std::vector<uint8_t> bundle_coop;    // the bundle is a narrow multiplication bundle (C_MULQ: four lanes per product)
     static const uint32_t REQ_FLAG = 0x80000000u;         // order[] entry: the request half of a division
     if (G == 1) {
         for (size_t i = 0; i < N; ++i)
             if (g.nodes[i].kind != N_CONST) {
                 bundle_of[i] = use_bundle_of[i] = (uint32_t)bundle_start.size();
                 bundle_start.push_back((uint32_t)order.size());
+                bundle_coop.push_back(0);
                 order.push_back((uint32_t)i);
             }
     } else {
@@ -578,9 +614,16 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         uint64_t clock = 0;
         std::vector<uint32_t> in_flight;  // nodes of the pending request
         uint64_t in_flight_ready = 0;
-        auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect) {
+        // Narrow multiplication bundles: when no more multiplications are ready than four-lane products fit a wave, the
+        // bundle is compiled for the lane-cooperative multiplier (about half the cycles of a full-width multiplication
+        // bundle); linear nodes cannot ride in it.
+        const size_t coop_cap = policy.fill ? coop_nodes(T) : 0;
+        const uint64_t coop_slack = policy.slack;
+        const size_t coop_fill = policy.fill;
+        auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false) {
             const uint32_t b = (uint32_t)bundle_start.size();
             bundle_start.push_back((uint32_t)order.size());
+            bundle_coop.push_back(coop ? 1 : 0);
             for (uint32_t i : nodes) {
                 if (request) {
                     use_bundle_of[i] = b;
@@ -644,7 +687,33 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             auto& h = heap[best];
             // a request must fit the interpreter's mailbox (mbox_lanes active lanes = node slots x T)
             const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : G;
-            while (!h.empty() && picked.size() < cap) {
+            bool coop = false;
+            if (best == C_MUL && coop_cap) {
+                // Narrow or full-width?  The ready multiplications in priority order; the ones within `coop_slack` of the
+                // most urgent node's height cannot wait.  If they fit a narrow bundle it is one (cheapest step for the
+                // critical chain; its free groups take the next most urgent multiplications, then linear riders) and the
+                // rest stays ready: work with slack piles up until it becomes urgent itself and then fills full-width
+                // bundles properly (a full-width bundle costs the same with 10 or 32 nodes).
+                std::vector<Key> cand;
+                while (!h.empty() && cand.size() < G) {
+                    std::pop_heap(h.begin(), h.end());
+                    cand.push_back(h.back());
+                    h.pop_back();
+                }
+                size_t n_urgent = 0;
+                while (n_urgent < cand.size() && (coop_slack >= cand[0].first || cand[n_urgent].first >= cand[0].first - coop_slack)) ++n_urgent;
+                coop = n_urgent <= coop_cap && (cand.size() <= coop_cap || cand.size() < coop_fill);
+                const size_t take = coop ? std::min(coop_cap, cand.size()) : cand.size();
+                for (size_t q = 0; q < cand.size(); ++q) {
+                    if (q < take) {
+                        picked.push_back(tie_reverse ? cand[q].second : ~cand[q].second);
+                    } else {
+                        h.push_back(cand[q]);
+                        std::push_heap(h.begin(), h.end());
+                    }
+                }
+            }
+            while (!coop && !h.empty() && picked.size() < cap) {
                 std::pop_heap(h.begin(), h.end());
                 picked.push_back(tie_reverse ? h.back().second : ~h.back().second);
                 h.pop_back();
@@ -653,10 +722,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             // A wave's time is the sum of its bundles and a multiplication bundle costs the same however few of its
             // node slots are used: ready Add/Sub nodes ride in its free slots (the kernel then also runs the ~40-slot
             // linear body, header bits) instead of asking for a bundle of their own later.
-            if (best == C_MUL && picked.size() < G && !heap[C_LIN].empty() && ride_along) {
+            const size_t slots = coop ? coop_cap : G;  // (a narrow bundle takes riders too: groups of four lanes add / subtract)
+            if (best == C_MUL && picked.size() < slots && !heap[C_LIN].empty() && ride_along) {
                 auto& hl = heap[C_LIN];
                 std::vector<uint32_t> riders;
-                while (!hl.empty() && picked.size() + riders.size() < G) {
+                while (!hl.empty() && picked.size() + riders.size() < slots) {
                     std::pop_heap(hl.begin(), hl.end());
                     riders.push_back(tie_reverse ? hl.back().second : ~hl.back().second);
                     hl.pop_back();
@@ -670,8 +740,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 clock += kClockCost[C_DIVREQ];
                 in_flight_ready = clock + kClockCost[C_DIV];
             } else {
-                emit_bundle(picked, false, false);
-                clock += kClockCost[best];
+                emit_bundle(picked, false, false, coop);
+                clock += kClockCost[coop ? (int)C_MULQ : best];
             }
         }
     }
@@ -754,7 +824,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
         const bool request = (order[k0] & REQ_FLAG) != 0, collect = is_collect(order[k0]);
-        const int cl = request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : class_of(g.nodes[order[k0]]);
+        const bool coop = bundle_coop[b] != 0;
+        const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ node's record is written COOP_LANES times (positions 4j .. 4j+3)
+        const int cl = request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
         st.class_bundles[cl]++;
         st.class_nodes[cl] += cnt;
         dying.clear();
@@ -782,11 +854,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 }
             }
             if (!request) ref[i] = slot;  // 0xffffffff: no slot (every use comes from the ring)
-            uint32_t* r = &out.recs[((size_t)b * G + js) * 4];
-            r[2] = slot;
+            uint32_t r[4] = {0, 0, slot, 0};
             // default: both operands unused -> staging loads of the zero constant, LDS reads of the own stage cells
             uint32_t off[2] = {zero_off, zero_off};
-            uint32_t lds[2] = {stage + js * T * 16u, stage + 2u * LDS_HALF_BYTES + js * T * 16u};
+            uint32_t lds[2] = {stage + js * rep * T * 16u, stage + 2u * LDS_HALF_BYTES + js * rep * T * 16u};  // (C_MULQ: value t + T * js is loaded by lane 4 * T * js + t)
             auto enc_operand = [&](uint32_t producer, int q) {
                 if (route(producer, i, q) == SRC_RING) {
                     lds[q] = LDS_RING_OFF + (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
@@ -828,7 +899,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             r[0] = off[0];
             r[1] = off[1];
             r[3] = lds[0] | (lds[1] << 16);
-            ctrl_of[(size_t)b * G + js] = (uint8_t)ctrl;
+            for (uint32_t x = 0; x < rep; ++x) {
+                memcpy(&out.recs[((size_t)b * G + js * rep + x) * 4], r, sizeof r);
+                ctrl_of[(size_t)b * G + js * rep + x] = (uint8_t)ctrl;
+            }
             const uint32_t ops[3] = {n.a, n.b, n.c};
             for (int q = 0; q < (collect ? 0 : arity_of(n)); ++q) {
                 uint32_t o = ops[q];
@@ -836,9 +910,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             }
         }
         uint32_t lin_bits = 0;
-        if (cl == C_LIN || cl == C_MUL)
+        if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {
-                const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK;
+                const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0) * rep] & CTRL_SUB_MASK;
                 lin_bits |= sub == SUB_SUB ? HDR_LIN_SUB : sub == SUB_ADD ? HDR_LIN_ADD : 0u;
             }
         if (cl == C_BIT) {
@@ -850,6 +924,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             }
             if (b_canon) lin_bits |= HDR_BIT_BCANON;
         }
+        if (cl == C_MULQ && lin_bits) st.n_coop_rider_bundles++;
         out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits;
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
@@ -863,7 +938,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // second pass: destination byte offsets (trash slot = n_slots) + ctrl, and inactive padding records
     const uint32_t trash_off = (uint32_t)(((uint64_t)NC + n_slots) * slot_bytes);
     for (uint32_t b = 0; b < NB; ++b) {
-        const uint32_t cnt = bundle_start[b + 1] - bundle_start[b];
+        const uint32_t rep = bundle_coop[b] ? COOP_LANES : 1u;
+        const uint32_t cnt = (bundle_start[b + 1] - bundle_start[b]) * rep;  // record positions in use
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         for (uint32_t q = 0; q < cnt; ++q) {
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
@@ -874,7 +950,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
             r[0] = r[1] = zero_off;
             r[2] = trash_off | (ctrl_of[(size_t)b * G] & CTRL_SUB_MASK);
-            r[3] = (stage + q * T * 16u) | ((stage + 2u * LDS_HALF_BYTES + q * T * 16u) << 16);
+            const uint32_t cell = (q / rep) * rep * T * 16u;  // (C_MULQ: the four positions of an idle group read one zero cell)
+            r[3] = (stage + cell) | ((stage + 2u * LDS_HALF_BYTES + cell) << 16);
             out.crefs[(size_t)b * G + q] = out.crefs[(size_t)b * G];
         }
     }
@@ -898,7 +975,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 8;
+    h.version = 9;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -913,7 +990,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 8 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 9 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

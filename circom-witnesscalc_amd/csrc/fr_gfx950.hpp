@@ -229,6 +229,29 @@ __device__ __forceinline__ Fr fr_mul_wave(const Fr& a, const Fr& b, const Fr& pv
     return fr_mul(a, b);
 #endif
 }
+// Lane-cooperative Montgomery product (narrow multiplication bundles, class C_MULQ): four adjacent lanes share one
+// product.  Lane 4v + q passes all of a, limbs 2q and 2q+1 of b (b0, b1) and of the modulus (n0, n1) and receives limbs
+// 2q, 2q+1 of a*b/2^256 mod r.  148 issue slots against 322 for fr_mul_wave; every lane of the wave must hold operands
+// below r (idle groups: zeros).  Generated and emulated by tools/codegen/gen_fr_mul_coop.py.
+__device__ __forceinline__ void fr_mul_coop4(const Fr& a, uint32_t b0, uint32_t b1, uint32_t n0, uint32_t n1, uint32_t* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_mul_coop4_gfx950.inc"
+#else
+    (void)a; (void)b0; (void)b1; (void)n0; (void)n1;
+    out[0] = out[1] = 0;
+#endif
+}
+// The same with linear nodes riding along (graph.rs:110-111): groups whose sub is SUB_ADD (0) / SUB_SUB (1) return
+// (a + b) / (a - b) mod r; aq0, aq1 = the lane's limbs 2q, 2q+1 of a.  167 issue slots.
+__device__ __forceinline__ void fr_mul_coop4r(const Fr& a, uint32_t aq0, uint32_t aq1, uint32_t b0, uint32_t b1, uint32_t n0, uint32_t n1, uint32_t sub,
+                                              uint32_t* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_mul_coop4r_gfx950.inc"
+#else
+    (void)a; (void)aq0; (void)aq1; (void)b0; (void)b1; (void)n0; (void)n1; (void)sub;
+    out[0] = out[1] = 0;
+#endif
+}
 #endif
 FRD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 

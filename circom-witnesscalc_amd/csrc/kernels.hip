@@ -197,6 +197,18 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     Fr pv = fr_p();  // the modulus in VGPRs for fr_add_wave / fr_sub_wave
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pv.v[i]));
+    // Narrow multiplication bundles (C_MULQ): lane 4v + q works on limbs 2q, 2q+1 of value v = t + T * j (cell v of the
+    // ring / stage like everywhere else); per-lane constants of that mapping
+    constexpr bool COOP = (uint32_t)T <= COOP_MAX_T;
+    const uint32_t cq = lane & 3u, cv = lane >> 2;
+    const uint32_t t16c = 16u * (cv % T);                                        // set of the lane's value
+    const uint32_t coop_chunk = (cq >> 1) * LDS_HALF_BYTES + (cq & 1u) * 8u;     // its 8 bytes inside a [half][cell][16 B] image
+    const uint32_t coop_ring_off = 16u * cv + coop_chunk;
+    const uint32_t coop_dst_off = t16c + (cq >> 1) * HI + (cq & 1u) * 8u;        // ... inside a slot of the tile
+    uint32_t nq0 = cq == 0 ? CWC_P0 : cq == 1 ? CWC_P2 : cq == 2 ? CWC_P4 : CWC_P6;
+    uint32_t nq1 = cq == 0 ? CWC_P1 : cq == 1 ? CWC_P3 : cq == 2 ? CWC_P5 : CWC_P7;
+    asm volatile("" : "+v"(nq0), "+v"(nq1));
+    const uint32_t trash_doff = (p.n_const + p.n_slots) * 2u * HI | t16;
     unsigned long long pf[C_COUNT][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
     if (PROF) {
 #pragma unroll
@@ -225,12 +237,63 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const unsigned long long t_wave0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t hdr_off_n2 = 8u;  // byte offset of the header two bundles ahead
     Fr r_prev = fr_zero();  // results of the previous bundle, stored one iteration late (first iteration: zeros -> trash slot)
-    uint32_t doff_prev = (p.n_const + p.n_slots) * 2u * HI | t16;
+    uint32_t doff_prev = trash_doff;
     for (uint32_t b = 0; b < NBND; ++b) {
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
         asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         CWC_STAMP(st1);
+        if constexpr (COOP) {
+            uint32_t cls_q = h & HDR_CLASS_MASK;
+            asm volatile("" : "+s"(cls_q));
+            if (cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
+                const uint32_t la = rec_hi.y + (t16c | (t16c << 16));
+                const Fr a_op = ld_lds(la & 0xffffu);
+                const uint2 bq = *reinterpret_cast<const uint2*>(ldsb + (la >> 16) + coop_chunk);
+                const uint2 aq = *reinterpret_cast<const uint2*>(ldsb + (la & 0xffffu) + coop_chunk);  // (for linear riders)
+                const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
+                const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
+                uint32_t h_n2;
+                asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+                hdr_off_n2 += 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(aq.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                CWC_STAMP(st2);
+                stage_operands(b + 2, rec_n2);
+                stage_rec(b + 4);
+                CWC_STAMP(st3);
+                uint32_t out[2];
+                if (h & (HDR_LIN_ADD | HDR_LIN_SUB)) {  // linear nodes ride in groups of their own (ctrl sub-op per record)
+                    fr_mul_coop4r(a_op, aq.x, aq.y, bq.x, bq.y, nq0, nq1, rec_hi.x & CTRL_SUB_MASK, out);
+                } else {
+                    fr_mul_coop4(a_op, bq.x, bq.y, nq0, nq1, out);
+                }
+                CWC_STAMP(st4);
+                // results: the lane's 8 bytes into the ring cell of its value and straight into the value's slot (the
+                // delayed stores of the next iteration go to the trash slot); one vector-memory operation more than the
+                // other iterations issue, which only makes the counted wait above retire one older store as well
+                *reinterpret_cast<uint2*>(ldsb + LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES + coop_ring_off) = make_uint2(out[0], out[1]);
+                {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{out[0], out[1]}, rsrc, (int)((rec_hi.x & ~CTRL_MASK) + coop_dst_off), 0, 0);
+                }
+                doff_prev = trash_doff;
+                rec_hi = rec_hi_n1;
+                rec_hi_n1 = rec_hi_n2;
+                h_cur = h_n1;
+                h_n1 = h_n2;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (PROF) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+                    pf[C_MULQ][0] += t_now - st0;
+                    pf[C_MULQ][1] += 1;
+                    (void)st2; (void)st3; (void)st4;
+                }
+                continue;
+            }
+        }
         const uint32_t ctrl = rec_hi.x & CTRL_MASK;
         const uint32_t doff = (rec_hi.x & ~CTRL_MASK) | t16;
         const uint32_t la = rec_hi.y + (t16 | (t16 << 16));

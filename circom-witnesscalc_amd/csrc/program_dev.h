@@ -28,8 +28,15 @@ enum BundleClass : uint32_t {
     // programs compiled for the asynchronous divider (one extra wavefront per tile): a division is split into
     C_DIVREQ = 9,   // ... handing the operands to the divider wave (no result), and
     C_DIVGET = 10,  // ... collecting the quotients a while later (same node slots as the request)
-    C_COUNT = 11
+    // narrow multiplication bundle (at most coop_nodes(T) nodes, tile widths up to COOP_MAX_T): four adjacent lanes share
+    // one product -- lane 4v + q holds limbs 2q, 2q+1 of b and of the modulus, all of a -- which takes 148 issue slots
+    // instead of 322 (fr_mul_coop4_gfx950.inc); value v = t + T * j sits in ring / stage cell v as in every other bundle.
+    // The node's record is written four times (record positions 4j .. 4j+3): lane l takes record l / T like everywhere.
+    C_MULQ = 11,    // graph.rs:105
+    C_COUNT = 12
 };
+static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4;
+CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_LANES * T) : 0u; }  // nodes of a C_MULQ bundle
 
 // Program format v4 -- every operand of a bundle is read from the wave's LDS at a host-computed address, and the
 // interpreter spends no vector instruction on decoding or address arithmetic beyond adding the lane's 16*t.

@@ -15,12 +15,14 @@ LDS_RING_OFF = 0
 LDS_STAGE_OFF = LDS_RING_OFF + RING_BUNDLES * RING_SLOT_BYTES
 LDS_REC_OFF = LDS_STAGE_OFF + OPND_AHEAD * STAGE_BYTES
 SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS": ["Lt", "Gt", "Leq", "Geq"],
-             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor", "BitX"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Add", "Sub", "Mul"], "DIV": ["Div"]}
+             "BIT": ["Shl", "Shr", "Bor", "Band", "Bxor", "BitX"], "IDIVMOD": ["Idiv", "Mod"], "MUL": ["Add", "Sub", "Mul"], "DIV": ["Div"],
+             "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I32Q"
+HDR_FMT = "<12I35Q"
 HDR_SIZE = struct.calcsize(HDR_FMT)
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
+COOP_LANES, COOP_MAX_T = 4, 4
 
 
 class Blob:
@@ -30,7 +32,7 @@ class Blob:
          self.n_witness, self.divider, self.n_div_requests, _res) = h[:12]
         st = h[12:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:17], class_bundles=st[17:28], n_op_compiled=st[28], n_bitx_bundles=st[29], n_bitx_nodes=st[30], algorithmic_bytes_per_set=st[31])
+                          class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -85,6 +87,10 @@ def run(blob: Blob, inputs_row):
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         assert h >> 15 == 0 and 1 <= cnt <= G
         name = CLASS_NAMES[cls]
+        # narrow multiplication bundle: four lanes per product, a node's record sits at positions 4j .. 4j+3 and its
+        # value t + T * j is staged by lane 4 * T * j + t
+        rep = COOP_LANES if name == "MULQ" else 1
+        assert name != "MULQ" or (T <= COOP_MAX_T and cnt * rep <= G)
         stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
         lin_seen = 0
@@ -93,8 +99,12 @@ def run(blob: Blob, inputs_row):
             request = {}
         if name == "DIVGET":
             assert blob.divider and mailbox is not None and len(mailbox) == cnt, "collect must mirror the request"
-        for j in range(G):
-            a_off, b_off, dctl, lds = blob.recs[(b * G + j) * 4:(b * G + j) * 4 + 4]
+        for pos in range(G):
+            j = pos // rep
+            a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
+            if pos % rep:
+                assert blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4] == blob.recs[(b * G + j * rep) * 4:(b * G + j * rep) * 4 + 4], "the lanes of a product share one record"
+                continue
             ctrl, dst = dctl & CTRL_MASK, dctl & ~CTRL_MASK
             assert bool(ctrl & CTRL_ACTIVE) == (j < cnt)
             ops = []
@@ -104,7 +114,7 @@ def run(blob: Blob, inputs_row):
                     assert off == zero_off and la % 16 == 0 and la // 16 < 254
                     ops.append(la // 16)
                     continue
-                own_cell = stage + 2 * q * LDS_HALF_BYTES + j * T * 16
+                own_cell = stage + 2 * q * LDS_HALF_BYTES + j * rep * T * 16
                 if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
                     if name == "BIT" and (h >> 14) & 1 and q == 1 and j < cnt:
                         assert off % slot_bytes == 0 and off // slot_bytes < NC, "canonical second operands are constants"
@@ -134,10 +144,11 @@ def run(blob: Blob, inputs_row):
                 v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
             else:
                 op = SUB_NAMES[name][sub]
+                assert op is not None
                 if op == "BitX":
                     results.append((dst, (ops[0] >> ops[1]) & 1))
                     continue
-                if name in ("LIN", "MUL") and op != "Mul":
+                if name in ("LIN", "MUL", "MULQ") and op != "Mul":
                     lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
                 try:
                     v = model.eval_duo(op, ops[0], ops[1])
