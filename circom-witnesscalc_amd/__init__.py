@@ -34,6 +34,13 @@ class Timing(ctypes.Structure):
                 ("divider", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
+class Handoff(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("form", ctypes.c_uint32), ("hip_stream", ctypes.c_void_p), ("done_event", ctypes.c_void_p)]
+
+
+FORM_CANONICAL, FORM_MONTGOMERY = 0, 1
+
+
 class WitnessCalcError(RuntimeError):
     pass
 
@@ -55,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
     "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width", "gwb_inputs_from_json_batch", "gwb_wtns_save_batch",
-    "gwb_host_alloc", "gwb_host_free", "gwb_timing_history",
+    "gwb_host_alloc", "gwb_host_free", "gwb_timing_history", "gwb_calc_witness_batch_handoff", "gwb_ubench_modmul",
 ]
 
 
@@ -110,6 +117,9 @@ def lib():
         L.gwb_profile_classes.argtypes = [vp, vp, sz, vp, vp, vp, stp]
         L.gwb_inputs_from_json_batch.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), stp]
         L.gwb_wtns_save_batch.argtypes = [vp, sz, sz, ctypes.c_char_p, stp]
+        L.gwb_calc_witness_batch_handoff.argtypes = [vp, vp, sz, vp, vp, ctypes.POINTER(Handoff), stp]
+        L.gwb_ubench_modmul.restype = ctypes.c_double
+        L.gwb_ubench_modmul.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         L.gwb_pick_tile_width.restype = ctypes.c_uint32
         L.gwb_pick_tile_width.argtypes = [sz]
         _lib = L
@@ -138,6 +148,11 @@ def wtns_save_batch(witness, path_pattern):
     st = GwStatus()
     rc = lib().gwb_wtns_save_batch(witness.ctypes.data, witness.shape[1], witness.shape[0], path_pattern.encode(), ctypes.byref(st))
     _check(rc, st)
+
+
+def ubench_modmul(waves_per_simd=4, iters=2000):
+    """Chip-wide one-lane Montgomery products per second (gwb_ubench_modmul)."""
+    return float(lib().gwb_ubench_modmul(waves_per_simd, iters))
 
 
 def pick_tile_width(batch):
@@ -277,9 +292,10 @@ class Graph:
         _check(rc, st)
         return wit, status
 
-    def calc_witness_batch_device(self, d_inputs, d_witness, d_status, stream=None):
+    def calc_witness_batch_device(self, d_inputs, d_witness, d_status, stream=None, montgomery=False, done_event=None):
         """Device-resident: torch uint8 cuda tensors [B, n_inputs, 32] -> [B, W, 32], int32/uint32 [B].
-        Asynchronous on `stream` (torch.cuda.Stream) or the current torch stream."""
+        Asynchronous on `stream` (torch.cuda.Stream) or the current torch stream.  montgomery / done_event
+        (torch.cuda.Event, recorded behind the call's last kernel): the prover hand-off of gwb_calc_witness_batch_handoff."""
         import torch
         b = d_inputs.shape[0]
         assert d_inputs.is_cuda and d_witness.is_cuda and d_status.is_cuda
@@ -287,8 +303,16 @@ class Graph:
         assert tuple(d_inputs.shape[1:]) == (self.n_inputs, 32) and tuple(d_witness.shape) == (b, self.n_witness, 32)
         s = stream if stream is not None else torch.cuda.current_stream()
         st = GwStatus()
-        rc = lib().gwb_calc_witness_batch_device(self._h, d_inputs.data_ptr(), b, d_witness.data_ptr(),
-                                                 d_status.data_ptr(), s.cuda_stream, ctypes.byref(st))
+        if montgomery or done_event is not None:
+            if done_event is not None:
+                done_event.record(s)  # (creates the underlying hipEvent_t; the library records it again behind its kernels)
+            h = Handoff(ctypes.sizeof(Handoff), FORM_MONTGOMERY if montgomery else FORM_CANONICAL, s.cuda_stream,
+                        done_event.cuda_event if done_event is not None else None)
+            rc = lib().gwb_calc_witness_batch_handoff(self._h, d_inputs.data_ptr(), b, d_witness.data_ptr(), d_status.data_ptr(),
+                                                      ctypes.byref(h), ctypes.byref(st))
+        else:
+            rc = lib().gwb_calc_witness_batch_device(self._h, d_inputs.data_ptr(), b, d_witness.data_ptr(),
+                                                     d_status.data_ptr(), s.cuda_stream, ctypes.byref(st))
         _check(rc, st)
 
     def timing_history(self, max_launches):

@@ -410,6 +410,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
 
     // ---- validate (assert_valid, reference src/graph.rs:343-356; evaluate() itself does not check) ----
     const size_t n_in_buf = inputs_buffer_size(g);
+    // (the reference sizes the buffer from the leading Input nodes, lib.rs:138-152, and panics on anything beyond; here
+    // the buffer covers every Input index and every signal of the input map -- within a sane bound: rows are n x 32 bytes)
+    if (n_in_buf > (1u << 27)) {
+        err = "inputs buffer of " + std::to_string(n_in_buf) + " elements is too large (an input map entry or Input index beyond 2^27)";
+        return false;
+    }
     uint64_t arity_sum = 0;
     for (size_t i = 0; i < N; ++i) {
         const Node& n = g.nodes[i];
@@ -961,6 +967,71 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     out.witness_refs.resize(out.n_witness);
     for (size_t i = 0; i < g.witness_signals.size(); ++i) out.witness_refs[i] = ref[g.witness_signals[i]];
     phase("slots + encoding");
+    return true;
+}
+
+// ---- structural validation of a program that did not come out of compile_program (an imported blob) ----------------
+// Everything the interpreter and the pack kernel address through the program is checked against the tile and LDS
+// geometry: a truncated or corrupted broadcast must fail here, not read or write out of bounds on the device.
+bool validate_program(const Program& p, std::string& err) {
+    auto bad = [&](const std::string& m) {
+        err = "invalid program: " + m;
+        return false;
+    };
+    const uint32_t T = p.T, G = p.G;
+    if (T == 0 || T > 64 || (T & (T - 1)) || G != 64 / T) return bad("tile geometry");
+    if (p.divider != 0 && p.divider != 1 && p.divider != 3 && p.divider != 4) return bad("divider mode");
+    if (p.divider && T == 64) return bad("divider program at tile width 64");
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
+    if (p.n_const == 0 || p.n_slots == 0 || tile_bytes > 0xffffffffull) return bad("tile size");
+    if ((uint64_t)p.n_bundles * G * 16ull > 0xffffffffull) return bad("record stream size");
+    if (p.hdr.size() != p.n_bundles || p.recs.size() != (size_t)p.n_bundles * G * 4 || p.crefs.size() != (size_t)p.n_bundles * G ||
+        p.consts.size() != (size_t)p.n_const * 8 || p.witness_refs.size() != p.n_witness || p.div_lanes.size() != p.n_div_requests)
+        return bad("array sizes");
+    const uint32_t slot_bytes = 32u * T, HI = 16u * T;
+    const uint64_t trash_off = ((uint64_t)p.n_const + p.n_slots) * slot_bytes;
+    uint32_t n_req = 0, n_get = 0;
+    bool in_flight = false;
+    for (uint32_t b = 0; b < p.n_bundles; ++b) {
+        const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
+        if (cls >= C_COUNT || (h >> 15) != 0) return bad("bundle " + std::to_string(b) + ": header");
+        const uint32_t rep = cls == C_MULQ ? COOP_LANES : 1u;
+        if (cnt == 0 || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
+        if (cls == C_MULQ && T > COOP_MAX_T) return bad("bundle " + std::to_string(b) + ": narrow bundle at this tile width");
+        if ((cls == C_DIVREQ || cls == C_DIVGET) && !p.divider) return bad("bundle " + std::to_string(b) + ": request / collect without a divider");
+        if (cls == C_DIV && p.divider) return bad("bundle " + std::to_string(b) + ": inline division in a divider program");
+        if (cls == C_DIVREQ) {
+            if (in_flight || n_req >= p.n_div_requests || cnt * T > mbox_lanes(p.divider) || p.div_lanes[n_req] != cnt * T) return bad("bundle " + std::to_string(b) + ": division request");
+            in_flight = true;
+            ++n_req;
+        }
+        if (cls == C_DIVGET) {
+            if (!in_flight) return bad("bundle " + std::to_string(b) + ": collect without a request");
+            in_flight = false;
+            ++n_get;
+        }
+        for (uint32_t q = 0; q < G; ++q) {
+            const uint32_t* r = &p.recs[((size_t)b * G + q) * 4];
+            // staging loads: 16 bytes per lane at off + 16 t and at off + HI + 16 t
+            for (int k = 0; k < 2; ++k)
+                if ((r[k] % slot_bytes) != 0 || (uint64_t)r[k] + slot_bytes > tile_bytes) return bad("bundle " + std::to_string(b) + ": operand offset");
+            const uint32_t dst = r[2] & ~CTRL_MASK;
+            if ((dst % slot_bytes) != 0 || dst < (uint64_t)p.n_const * slot_bytes || dst > trash_off) return bad("bundle " + std::to_string(b) + ": destination");
+            const uint32_t la = r[3] & 0xffffu, lb = r[3] >> 16;
+            const bool bitx = cls == C_BIT && (r[2] & CTRL_SUB_MASK) == SUB_BITX;
+            if ((la % 16) != 0 || la + 16u * (T - 1) + LDS_HALF_BYTES + 16u > LDS_BYTES) return bad("bundle " + std::to_string(b) + ": LDS address");
+            // (a bit-extract lane carries its shift amount there; idle lanes of such a bundle keep a stage address, unused)
+            const bool active = (r[2] & CTRL_ACTIVE) != 0;
+            if (bitx ? (active && lb / 16 >= 254) : ((lb % 16) != 0 || lb + 16u * (T - 1) + LDS_HALF_BYTES + 16u > LDS_BYTES)) return bad("bundle " + std::to_string(b) + ": LDS address");
+            const uint32_t cr = p.crefs[(size_t)b * G + q];
+            if (cls == C_INPUT && cr >= p.n_inputs) return bad("bundle " + std::to_string(b) + ": input index");
+            if (cls == C_TERN && ((cr % slot_bytes) != 0 || (uint64_t)cr + slot_bytes > tile_bytes)) return bad("bundle " + std::to_string(b) + ": third operand");
+        }
+        (void)HI;
+    }
+    if (in_flight || n_req != p.n_div_requests || n_get != n_req) return bad("division requests");
+    for (uint32_t w : p.witness_refs)
+        if ((w & REF_CONST) ? (w & ~REF_CONST) >= p.n_const : w >= p.n_slots) return bad("witness reference");
     return true;
 }
 

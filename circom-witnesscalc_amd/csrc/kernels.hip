@@ -573,6 +573,8 @@ __global__ __launch_bounds__(256) void fill_consts_kernel(ProgramDev p, WsTable 
 
 // Block = 64 witness indices x min(T, 4) sets of ONE tile: the waves of a block read the same 128-byte lines of the
 // tile's slots ([slot][half][T][16 B]) at the same time, so each line comes from HBM once instead of once per set.
+// MONT: the rows keep the interpreter's Montgomery form (x * 2^256 mod r) for a consumer that computes in it.
+template <bool MONT>
 __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
     const uint32_t w = blockIdx.x * 64u + threadIdx.x;
     if (w >= p.n_witness) return;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
             const uint32_t set = tile * T + t;
             if (set >= batch) break;
             const uint4* q = q0 + t;
-            const Fr c = fr_from_mont(fr_from_u4(q[0], q[T]));
+            const Fr c = MONT ? fr_from_u4(q[0], q[T]) : fr_from_mont(fr_from_u4(q[0], q[T]));
             uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
             o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
             o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
@@ -640,11 +642,31 @@ hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& ws
     return hipGetLastError();
 }
 
-hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream) {
+hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream, bool montgomery) {
     if (p.n_witness == 0 || batch == 0) return hipSuccess;
     const uint32_t n_tiles = (batch + T - 1) / T;
     dim3 grid((p.n_witness + 63) / 64, n_tiles < 32768u ? n_tiles : 32768u), block(64, T < 4 ? T : 4);
-    pack_kernel<<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
+    if (montgomery) pack_kernel<true><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
+    else pack_kernel<false><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
+    return hipGetLastError();
+}
+
+// Diagnostic (bench.py's compute ceiling): every lane of `waves_per_simd` waves on every SIMD runs a dependent chain of
+// one-lane Montgomery products; returns nothing, the caller times the launch.
+__global__ __launch_bounds__(1024) void modmul_ubench_kernel(uint32_t* sink, uint32_t iters) {
+    Fr a = fr_r2(), b = fr_one();
+    a.v[0] ^= threadIdx.x + blockIdx.x * 977u;
+    Fr pv = fr_p();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pv.v[i]));
+    for (uint32_t it = 0; it < iters; ++it) {
+        a = fr_mul_wave(a, b, pv);
+        b = fr_mul_wave(b, a, pv);
+    }
+    if (a.v[0] == 0x1234567u && b.v[3] == 7u) sink[0] = a.v[1];
+}
+hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream) {
+    modmul_ubench_kernel<<<n_cus, 256 * waves_per_simd, 0, stream>>>(sink, iters);
     return hipGetLastError();
 }
 

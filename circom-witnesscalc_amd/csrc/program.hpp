@@ -59,6 +59,10 @@ static inline uint32_t key_mode_of_divider(uint32_t divider) { return divider ==
 double program_wave_cycles(const Program& p);
 double program_wave_cycles_mul_div(const Program& p);
 
+// Structural check of a program from outside compile_program (imported blob): every offset, index and LDS address the
+// kernels take from it lies inside the tile / LDS / input geometry.
+bool validate_program(const Program& p, std::string& err);
+
 // pointer-free serialisation (what is broadcast between GPUs)
 std::vector<uint8_t> program_to_blob(const Program& p);
 bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string& err);

@@ -24,7 +24,8 @@
 namespace cwc {
 hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p,
                          const WsTable& wst, const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof);
-hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream);
+hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream, bool montgomery);
+hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream);
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
 }  // namespace cwc
 
@@ -47,6 +48,19 @@ int fail(gw_status_t* st, const std::string& msg) {
     set_status(st, ERROR, msg);
     return 1;
 }
+// No C++ exception may cross the C boundary: allocation failures on huge or hostile inputs become status ERROR.
+template <class F>
+int guarded(gw_status_t* st, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(st, "out of memory");
+    } catch (const std::exception& e) {
+        return fail(st, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(st, "internal error");
+    }
+}
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
@@ -57,6 +71,12 @@ struct DeviceProgram {
     Program host;
     void* d_blob = nullptr;
     ProgramDev dev{};
+    DeviceProgram() = default;
+    DeviceProgram(const DeviceProgram&) = delete;
+    DeviceProgram& operator=(const DeviceProgram&) = delete;
+    ~DeviceProgram() {
+        if (d_blob) (void)hipFree(d_blob);
+    }
 };
 
 std::string upload_program(DeviceProgram& dp) {
@@ -146,6 +166,12 @@ struct gwb_graph {
     size_t stage_bytes = 0;
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
+    // Calls on one handle share the value workspace and the constant fill: work enqueued on a different stream than the
+    // previous call's waits for that call's last kernel (an event recorded behind it), so calls execute in enqueue order
+    // whatever streams they name.
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
     std::mutex mu;
 
     void drop_events() {
@@ -154,8 +180,7 @@ struct gwb_graph {
     }
 
     ~gwb_graph() {
-        for (auto& kv : progs)
-            if (kv.second->d_blob) (void)hipFree(kv.second->d_blob);
+        progs.clear();  // (DeviceProgram frees its device blob)
         for (int i = 0; i < kMaxLanes; ++i)
             if (d_vals[i]) (void)hipFree(d_vals[i]);
         drop_events();
@@ -166,6 +191,7 @@ struct gwb_graph {
             if (stage_done[i]) (void)hipEventDestroy(stage_done[i]);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (last_done) (void)hipEventDestroy(last_done);
     }
 };
 
@@ -319,7 +345,7 @@ std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
 }
 
 std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d_witness, uint32_t* d_status,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool montgomery = false, hipEvent_t done_event = nullptr) {
     if (batch == 0) return "";
     if (batch > 0x7fffffffull) return "batch too large";
     const uint32_t key = pick_tile_width(g, batch);
@@ -328,6 +354,8 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     if (!err.empty()) return err;
     const Program& p = dp->host;
     const uint32_t T = p.T;
+    if (!g->last_done) HIP_TRY(hipEventCreateWithFlags(&g->last_done, hipEventDisableTiming));
+    if (g->has_last && g->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, g->last_done, 0));
     // Workspace: tiles of (constants | value slots | trash slot), grouped into separately allocated chunks of at most
     // CWC_WORKSPACE_GB; larger batches than WS_MAX_CHUNKS chunks hold are evaluated in several launches.
     const uint64_t bytes_per_tile = ws_tile_bytes(p.n_const, p.n_slots, T);
@@ -350,7 +378,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     bool refill = g->filled_prog != dp || g->filled_tiles_per_chunk != chunk_tiles || g->filled_chunks < per_launch;
     for (size_t l = 0; l < per_launch; ++l) {
         if (need > g->vals_bytes[l]) {
-            if (g->d_vals[l]) HIP_TRY(hipFree(g->d_vals[l]));
+            if (g->d_vals[l]) HIP_TRY(hipFree(g->d_vals[l]));  // (hipFree waits for the device: earlier calls are done with it)
             g->d_vals[l] = nullptr;
             g->vals_bytes[l] = 0;
             g->filled_prog = nullptr;
@@ -389,20 +417,28 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
             e0 = g->pending.front().start, e1 = g->pending.front().after_interp, e2 = g->pending.front().after_pack;
             g->pending.pop_front();
         } else {
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventCreate(&e2));
+            e0 = e1 = e2 = nullptr;
+            const bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess;
+            if (!ok) {
+                for (hipEvent_t e : {e0, e1, e2})
+                    if (e) (void)hipEventDestroy(e);
+                return "hipEventCreate failed";
+            }
         }
+        g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});  // (owned by the handle from here on, also on an early return)
         HIP_TRY(hipEventRecord(e0, stream));
         HIP_TRY(launch_interp(T, p.divider, waves_per_workgroup(p.divider, (nb + T - 1) / T), p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
-        HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream));
+        HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream, montgomery));
         HIP_TRY(hipEventRecord(e2, stream));
-        g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});
         g->last_call_launches++;
         g->timing.n_launches++;
     }
     g->timing_pending = true;
+    HIP_TRY(hipEventRecord(g->last_done, stream));
+    if (done_event) HIP_TRY(hipEventRecord(done_event, stream));
+    g->last_stream = stream;
+    g->has_last = true;
     return "";
 }
 
@@ -546,11 +582,12 @@ std::string set_status_text(uint32_t bits) {
 // ---- compiled-graph cache for the single-shot entry point (the reference re-parses per call, lib.rs:129) ----
 struct CacheEntry {
     uint64_t hash;
-    size_t len;
+    std::vector<uint8_t> bytes;  // the graph image itself: a hit is a byte-for-byte match, never a hash alone
     std::shared_ptr<gwb_graph> g;
 };
 std::mutex g_cache_mu;
-std::vector<CacheEntry> g_cache;
+// (never destroyed: the handles own HIP objects and static destructors run after the HIP runtime may be gone)
+std::vector<CacheEntry>& g_cache = *new std::vector<CacheEntry>();
 
 uint64_t fnv1a(const uint8_t* p, size_t n) {
     uint64_t h = 1469598103934665603ull;
@@ -597,6 +634,7 @@ void gwb_free_status(gw_status_t* status) {
 }
 
 int gwb_graph_load(const void* graph_data, size_t len, gwb_graph_t** out, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!graph_data) return fail(status, "graph_data is null");
     if (len == 0) return fail(status, "graph_data_len is 0");
     if (!out) return fail(status, "out is null");
@@ -604,6 +642,7 @@ int gwb_graph_load(const void* graph_data, size_t len, gwb_graph_t** out, gw_sta
     if (load_graph(graph_data, len, out, err)) return fail(status, "Failed to load graph: " + err);
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 void gwb_graph_free(gwb_graph_t* g) { delete g; }
@@ -622,6 +661,7 @@ int gwb_graph_info(const gwb_graph_t* g, gwb_graph_info_t* info) {
 }
 
 int gwb_graph_serialize(const gwb_graph_t* g, void** out, size_t* out_len, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!g || !out || !out_len) return fail(status, "null argument");
     if (!g->has_graph) return fail(status, "imported handle holds no graph to serialize");
     std::vector<uint8_t> b = serialize_witnesscalc_graph(g->graph);
@@ -631,9 +671,11 @@ int gwb_graph_serialize(const gwb_graph_t* g, void** out, size_t* out_len, gw_st
     *out_len = b.size();
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 int gwb_inputs_from_json(const gwb_graph_t* g, const char* json, void* row, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!g || !json || !row) return fail(status, "null argument");
     InputList list;
     std::string err;
@@ -649,10 +691,12 @@ int gwb_inputs_from_json(const gwb_graph_t* g, const char* json, void* row, gw_s
         }
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 int gwb_inputs_from_json_batch(const gwb_graph_t* g, const char* text, size_t text_len, void* rows, size_t max_rows,
                                size_t* n_rows, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!g || !text || !n_rows || (!rows && max_rows)) return fail(status, "null argument");
     std::vector<std::pair<size_t, size_t>> spans;
     std::string err;
@@ -662,17 +706,48 @@ int gwb_inputs_from_json_batch(const gwb_graph_t* g, const char* text, size_t te
     Graph meta;
     meta.inputs = g->inputs;
     meta.input_index = g->input_index;
-    InputList list;
-    for (size_t i = 0; i < spans.size(); ++i) {
-        if (!deserialize_inputs(text + spans[i].first, spans[i].second - spans[i].first, list, err) ||
-            !populate_inputs(list, meta, (uint8_t*)rows + i * (size_t)g->n_inputs * 32, g->n_inputs, err))
-            return fail(status, "Failed to calculate witness: input set " + std::to_string(i) + ": " + err);
+    // the input sets are independent: parsed on CWC_PARSE_THREADS host threads (default min(cores, 16)), contiguous
+    // ranges each; the error of the lowest failing set is reported, as a sequential loop would
+    unsigned n_threads = copy_threads();
+    if (const char* e = getenv("CWC_PARSE_THREADS")) {
+        const long v = atol(e);
+        if (v >= 1) n_threads = (unsigned)v;
     }
+    if (spans.size() < 64) n_threads = 1;
+    if (n_threads > spans.size()) n_threads = (unsigned)spans.size();
+    std::vector<std::string> errs(n_threads ? n_threads : 1);
+    std::vector<size_t> bad(n_threads ? n_threads : 1, (size_t)-1);
+    auto work = [&](unsigned w) {
+        const size_t lo = spans.size() * w / n_threads, hi = spans.size() * (w + 1) / n_threads;
+        InputList list;
+        for (size_t i = lo; i < hi; ++i) {
+            std::string e;
+            if (!deserialize_inputs(text + spans[i].first, spans[i].second - spans[i].first, list, e) ||
+                !populate_inputs(list, meta, (uint8_t*)rows + i * (size_t)g->n_inputs * 32, g->n_inputs, e)) {
+                errs[w] = e;
+                bad[w] = i;
+                return;
+            }
+        }
+    };
+    if (n_threads <= 1) {
+        n_threads = 1;
+        if (!spans.empty()) work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned w = 1; w < n_threads; ++w) th.emplace_back(work, w);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (unsigned w = 0; w < n_threads; ++w)
+        if (bad[w] != (size_t)-1) return fail(status, "Failed to calculate witness: input set " + std::to_string(bad[w]) + ": " + errs[w]);
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, const char* path_pattern, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     // one `.wtns` file per input set; path_pattern must contain one %zu / %lu-style conversion for the set index
     if ((!witness && batch) || !path_pattern) return fail(status, "null argument");
     std::vector<uint8_t> hdr(76);
@@ -689,6 +764,7 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
     }
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
@@ -701,6 +777,7 @@ int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
 
 int gwb_calc_witness_batch_device(gwb_graph_t* g, const void* d_inputs, size_t batch, void* d_witness,
                                   uint32_t* d_set_status, void* hip_stream, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!g || (batch && (!d_inputs || !d_witness || !d_set_status))) return fail(status, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
     std::string err = check_device();
@@ -708,10 +785,57 @@ int gwb_calc_witness_batch_device(gwb_graph_t* g, const void* d_inputs, size_t b
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");
     return 0;
+    });
+}
+
+int gwb_calc_witness_batch_handoff(gwb_graph_t* g, const void* d_inputs, size_t batch, void* d_witness, uint32_t* d_set_status,
+                                   const gwb_handoff_t* h, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
+    if (!g || !h || (batch && (!d_inputs || !d_witness || !d_set_status))) return fail(status, "null argument");
+    if (h->struct_size != sizeof(gwb_handoff_t)) return fail(status, "gwb_handoff_t: struct_size does not match this library");
+    if (h->form != GWB_FORM_CANONICAL && h->form != GWB_FORM_MONTGOMERY) return fail(status, "gwb_handoff_t: unknown form");
+    std::lock_guard<std::mutex> lk(g->mu);
+    std::string err = check_device();
+    if (err.empty()) err = run_device(g, d_inputs, batch, d_witness, d_set_status, (hipStream_t)h->hip_stream, h->form == GWB_FORM_MONTGOMERY, (hipEvent_t)h->done_event);
+    if (err.empty() && batch == 0 && h->done_event && hipEventRecord((hipEvent_t)h->done_event, (hipStream_t)h->hip_stream) != hipSuccess) err = "hipEventRecord failed";
+    if (!err.empty()) return fail(status, err);
+    set_status(status, OK, "");
+    return 0;
+    });
+}
+
+double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters) {
+    // chip-wide one-lane Montgomery products per second with `waves_per_simd` waves on every SIMD (bench.py's compute
+    // ceiling, measured in the same run); 0 on failure
+    try {
+        if (!check_device().empty() || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return 0.0;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0.0;
+        uint32_t* sink = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        double rate = 0.0;
+        if (hipMalloc(&sink, 64) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+            bool ok = launch_modmul_ubench(cus, waves_per_simd, iters, sink, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // warm-up
+            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess && launch_modmul_ubench(cus, waves_per_simd, iters, sink, nullptr) == hipSuccess &&
+                 hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+            float ms = 0.f;
+            if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
+                rate = 2.0 * iters * (double)cus * 256.0 * waves_per_simd / (ms * 1e-3);
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (sink) (void)hipFree(sink);
+        return rate;
+    } catch (...) {
+        return 0.0;
+    }
 }
 
 int gwb_calc_witness_batch_host(gwb_graph_t* g, const void* inputs, size_t batch, void* witness, uint32_t* set_status_out,
                                 gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!g || (batch && (!inputs || !witness || !set_status_out))) return fail(status, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
     std::string err = check_device();
@@ -719,6 +843,7 @@ int gwb_calc_witness_batch_host(gwb_graph_t* g, const void* inputs, size_t batch
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 void* gwb_host_alloc(size_t bytes) {
@@ -772,6 +897,7 @@ int gwb_timing_history(gwb_graph_t* g, size_t max_launches, float* interp_ms, fl
 
 int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void* d_witness, uint32_t* d_set_status,
                         uint64_t* out36, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     // Diagnostic: one batch through the stamped interpreter build; out36[class*4 + {load, compute, store, count}]
     // in shader cycles, summed over the sampled waves (lane 0 of every 64th tile).
     if (!g || !out36) return fail(status, "null argument");
@@ -789,6 +915,7 @@ int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 size_t gwb_wtns_size(size_t n_witness) { return wtns_size(n_witness); }
@@ -800,6 +927,7 @@ int gwb_wtns_from_witness(const void* row, size_t n_witness, void* out) {
 }
 
 int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
     if (!g || !blob || !blob_len) return fail(status, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
     Program tmp;
@@ -817,6 +945,7 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
     std::vector<uint8_t> b = program_to_blob(*p);
     // trailer: input map
     auto put32 = [&](uint32_t v) { b.insert(b.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
+    const size_t exact_len = b.size();
     while (b.size() % 8) b.push_back(0);
     const size_t prog_len = b.size();
     put32((uint32_t)g->inputs.size());
@@ -826,32 +955,37 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
         put32((uint32_t)s.name.size());
         b.insert(b.end(), s.name.begin(), s.name.end());
     }
-    uint64_t pl = prog_len;
-    b.insert(b.end(), (uint8_t*)&pl, (uint8_t*)&pl + 8);
+    // trailer: exact program length, padded program length (= where the input map starts), FNV-1a of everything before
+    uint64_t tr[3] = {(uint64_t)exact_len, (uint64_t)prog_len, 0};
+    tr[2] = fnv1a(b.data(), b.size());
+    b.insert(b.end(), (uint8_t*)tr, (uint8_t*)tr + sizeof tr);
     *blob = malloc(b.size());
     if (!*blob) return fail(status, "out of memory");
     memcpy(*blob, b.data(), b.size());
     *blob_len = b.size();
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_t* status) {
-    if (!blob || !out || len < 16) return fail(status, "bad blob");
+    return guarded(status, [&]() -> int {
+    if (!blob || !out) return fail(status, "null argument");
+    if (len < 24 + 8) return fail(status, "bad blob: too short");
     const uint8_t* b = (const uint8_t*)blob;
-    uint64_t prog_len;
-    memcpy(&prog_len, b + len - 8, 8);
-    if (prog_len > len - 8) return fail(status, "bad blob trailer");
+    uint64_t tr[3];  // exact program length, padded program length, checksum of everything before the trailer
+    memcpy(tr, b + len - 24, 24);
+    const size_t body = len - 24;
+    if (tr[2] != fnv1a(b, body)) return fail(status, "bad blob: checksum mismatch (truncated or corrupted)");
+    if (tr[0] > tr[1] || tr[1] - tr[0] >= 8 || tr[1] > body || (tr[1] % 8) != 0) return fail(status, "bad blob trailer");
     std::unique_ptr<gwb_graph> g(new gwb_graph());
     std::unique_ptr<DeviceProgram> dp(new DeviceProgram());
     std::string err;
-    // program_from_blob checks an exact size: find the unpadded length by trying the padded one minus 0..7
-    bool ok = false;
-    for (size_t pad = 0; pad < 8 && !ok; ++pad) ok = program_from_blob(b, (size_t)prog_len - pad, dp->host, err);
-    if (!ok) return fail(status, "bad program blob: " + err);
-    size_t pos = (size_t)prog_len;
+    if (!program_from_blob(b, (size_t)tr[0], dp->host, err)) return fail(status, "bad program blob: " + err);
+    if (!validate_program(dp->host, err)) return fail(status, "bad program blob: " + err);
+    size_t pos = (size_t)tr[1];
     auto get32 = [&](uint32_t& v) {
-        if (pos + 4 > len - 8) return false;
+        if (pos + 4 > body) return false;
         memcpy(&v, b + pos, 4);
         pos += 4;
         return true;
@@ -861,7 +995,8 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     for (uint32_t i = 0; i < n; ++i) {
         InputSignal s;
         uint32_t nl;
-        if (!get32(s.offset) || !get32(s.len) || !get32(nl) || pos + nl > len - 8) return fail(status, "bad blob trailer");
+        if (!get32(s.offset) || !get32(s.len) || !get32(nl) || nl > body - pos) return fail(status, "bad blob trailer");
+        if ((uint64_t)s.offset + s.len > dp->host.n_inputs) return fail(status, "bad blob: input signal beyond the inputs buffer");
         s.name.assign((const char*)b + pos, nl);
         pos += nl;
         g->input_index[s.name] = (uint32_t)g->inputs.size();
@@ -878,11 +1013,13 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     *out = g.release();
     set_status(status, OK, "");
     return 0;
+    });
 }
 
 // ---- the reference's symbol (src/lib.rs:44-111) ----------------------------------------------------
 int gw_calc_witness(const char* inputs, const void* graph_data, const size_t graph_data_len, void** wtns_data,
                     size_t* wtns_len, const gw_status_t* status_c) {
+    return guarded(const_cast<gw_status_t*>(status_c), [&]() -> int {
     gw_status_t* status = const_cast<gw_status_t*>(status_c);  // the reference writes through it too
     if (!inputs) return fail(status, "inputs is null");                    // lib.rs:51-54
     if (!graph_data) return fail(status, "graph_data is null");            // lib.rs:56-59
@@ -914,7 +1051,7 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (auto& e : g_cache)
-            if (e.hash == h && e.len == graph_data_len) g = e.g;
+            if (e.hash == h && e.bytes.size() == graph_data_len && memcmp(e.bytes.data(), graph_data, graph_data_len) == 0) g = e.g;
     }
     if (!g) {
         gwb_graph* raw = nullptr;
@@ -922,7 +1059,7 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         g.reset(raw);
         std::lock_guard<std::mutex> lk(g_cache_mu);
         if (g_cache.size() >= 4) g_cache.erase(g_cache.begin());
-        g_cache.push_back(CacheEntry{h, graph_data_len, g});
+        g_cache.push_back(CacheEntry{h, std::vector<uint8_t>((const uint8_t*)graph_data, (const uint8_t*)graph_data + graph_data_len), g});
     }
     std::vector<uint8_t> row((size_t)g->n_inputs * 32), wit((size_t)g->n_witness * 32);
     if (!populate_inputs(list, g->graph, row.data(), g->n_inputs, err)) return fail(status, "Failed to calculate witness: " + err);
@@ -952,6 +1089,7 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         set_status(status, OK, "");
     }
     return 0;
+    });
 }
 
 }  // extern "C"

@@ -57,7 +57,8 @@ int gwb_graph_serialize(const gwb_graph_t *g, void **out, size_t *out_len, gw_st
 int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *row, gw_status_t *status);
 
 /* Batched front-end: `text` is a JSON array of input objects or NDJSON (one object per line); fills up to max_rows
- * rows of n_inputs x 32 bytes, *n_rows = number of input sets found (also set when the buffer is too small). */
+ * rows of n_inputs x 32 bytes, *n_rows = number of input sets found (also set when the buffer is too small).  The input
+ * sets are parsed on CWC_PARSE_THREADS host threads (default min(cores, 16)). */
 int gwb_inputs_from_json_batch(const gwb_graph_t *g, const char *text, size_t text_len, void *rows, size_t max_rows,
                                size_t *n_rows, gw_status_t *status);
 /* Write one `.wtns` file per input set (76-byte header + row, src/lib.rs:114-123); path_pattern takes the set index
@@ -86,6 +87,28 @@ uint32_t gwb_pick_tile_width(size_t batch);
  *   hip_stream: hipStream_t or NULL.  Asynchronous: returns after enqueueing. */
 int gwb_calc_witness_batch_device(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                                   uint32_t *d_set_status, void *hip_stream, gw_status_t *status);
+/* Ordering: the calls on one handle share its value workspace, so they execute in the order they were enqueued, whatever
+ * streams they name -- a call on a different stream than the previous one first waits (hipStreamWaitEvent) for that
+ * call's last kernel.  Calls on DIFFERENT handles are independent.  Reading d_witness / d_set_status from another stream
+ * or from the host needs the usual synchronization with `hip_stream` (or the hand-off event below).
+ *
+ * Device hand-off to a prover (the consumer of `.wtns` is an MSM/NTT pipeline, reference test_circuits.sh:98): the witness
+ * rows stay in HBM as [batch][n_witness][32 B] little-endian, one contiguous row of n_witness scalars per input set (what a
+ * multi-scalar multiplication takes).  gwb_handoff_t adds the two things a GPU consumer needs: the scalars in Montgomery
+ * form (x * 2^256 mod r, 8 x u32 / 4 x u64 little-endian limbs -- ark-ff's and most GPU provers' internal form) instead
+ * of canonical integers, and an event recorded behind the last kernel of the call, for hipStreamWaitEvent on the
+ * consumer's stream without a host round trip. */
+#define GWB_FORM_CANONICAL 0u
+#define GWB_FORM_MONTGOMERY 1u
+typedef struct {
+  uint32_t struct_size;      /* sizeof(gwb_handoff_t): lets the struct grow */
+  uint32_t form;             /* GWB_FORM_CANONICAL (the .wtns body) or GWB_FORM_MONTGOMERY */
+  void *hip_stream;          /* hipStream_t the work is enqueued on, or NULL */
+  void *done_event;          /* hipEvent_t created by the caller, recorded after the last kernel; or NULL */
+} gwb_handoff_t;
+int gwb_calc_witness_batch_handoff(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
+                                   uint32_t *d_set_status, const gwb_handoff_t *handoff, gw_status_t *status);
+
 /* Same with host buffers (copies in/out, synchronous).  The witness rows come back in slices through pinned staging
  * while worker threads (CWC_COPY_THREADS, default min(cores, 16)) fill `witness`; a `witness` buffer from
  * gwb_host_alloc (or any pinned allocation) is the destination of the device copy itself. */
@@ -108,6 +131,11 @@ int gwb_timing_history(gwb_graph_t *g, size_t max_launches, float *interp_ms, fl
  * out64[63] = waves.  out64 must hold 64 words. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out64, gw_status_t *status);
+
+/* Diagnostic: chip-wide one-lane Montgomery products per second with waves_per_simd (1..4) wavefronts on every SIMD, each
+ * lane running a dependent chain of 2 * iters products (the compute ceiling bench.py reports beside the HBM model);
+ * 0.0 on failure. */
+double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters);
 
 /* `.wtns` framing of one witness row (wtns_from_witness, src/lib.rs:114-123): out holds gwb_wtns_size bytes. */
 size_t gwb_wtns_size(size_t n_witness);

@@ -66,3 +66,67 @@ def test_hostile_json_never_crashes(pkg):
             g.inputs_from_json(txt.encode("latin-1", "replace").replace(b"\x00", b" "))
         except pkg.WitnessCalcError:
             pass
+
+
+def test_corrupted_program_blobs_are_rejected(pkg):
+    """gwb_graph_import is what the ranks of a node feed with the broadcast program: a truncated, padded, bit-flipped or
+    internally inconsistent blob must be refused before anything is uploaded or launched (checksum + structural
+    validation of every offset / index / LDS address, validate_program in compile.cc).  On this CPU-only machine a
+    VALID blob gets as far as the device check and fails there; everything else must fail earlier with its own message."""
+    import struct
+    rnd = random.Random(5)
+    g = pkg.Graph(C.build_gadgets().to_bin())
+    for key in (1, 4, 64, 2 | 0x100):
+        blob = g.export_blob(key)
+        with pytest.raises(pkg.WitnessCalcError, match="no HIP device"):
+            pkg.Graph.from_blob(blob)
+        # the advisor's crash: a 16-byte blob whose trailer says "program length 0"
+        for tiny in (b"\0" * 16, b"\0" * 24, b"\0" * 32, blob[:7], blob[-24:]):
+            with pytest.raises(pkg.WitnessCalcError, match="bad blob|bad program blob"):
+                pkg.Graph.from_blob(tiny)
+        # transport damage: caught by the checksum
+        for _ in range(150):
+            d = bytearray(blob)
+            kind = rnd.randrange(3)
+            if kind == 0:
+                d[rnd.randrange(len(d))] ^= 1 << rnd.randrange(8)
+            elif kind == 1:
+                d = d[:rnd.randrange(len(d))]
+            else:
+                d += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 64)))
+            with pytest.raises(pkg.WitnessCalcError, match="bad blob|bad program blob"):
+                pkg.Graph.from_blob(bytes(d))
+        # a hostile sender: consistent checksum, damaged contents -> the structural validation has to catch it
+        def refnv(body):
+            h = 1469598103934665603
+            for byte in body:
+                h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            return h
+        body, (exact, padded, _) = bytearray(blob[:-24]), struct.unpack("<3Q", blob[-24:])
+        hits = 0
+        for _ in range(120):
+            d = bytearray(body)
+            pos = rnd.randrange(0, exact - 4) & ~3
+            d[pos:pos + 4] = struct.pack("<I", rnd.choice([0xFFFFFFFF, 0x7FFFFFF0, 1 << 20, rnd.getrandbits(32)]))
+            evil = bytes(d) + struct.pack("<3Q", exact, padded, refnv(d))
+            try:
+                pkg.Graph.from_blob(evil)
+            except pkg.WitnessCalcError as e:
+                hits += "no HIP device" not in str(e)   # (a change in a statistics field or a constant is harmless and passes)
+        assert hits >= 30, hits  # (the rest landed in constants, statistics or on other valid offsets: memory-safe)
+
+
+def test_oversized_input_map_is_refused(pkg):
+    """An input-map entry far beyond the Input nodes (offset 0xFFFFFFFF, the advisor's case) used to wrap the 32-bit
+    input count, after which the kernel would have read beyond the caller's rows; such a graph is refused at load."""
+    from tools.graphgen.builder import Builder, serialize_graph
+    b = Builder()
+    a = b.input("a", 1)[0]
+    b.signal(b.mul(a, a))
+    nodes, wit, inputs = b.finalize()
+    assert pkg.Graph(serialize_graph(nodes, wit, inputs)).n_inputs == 2
+    for off, n in ((0xFFFFFFFF, 2), (1 << 27, 1), (0xFFFFFFF0, 0x20)):
+        with pytest.raises(pkg.WitnessCalcError, match="too large"):
+            pkg.Graph(serialize_graph(nodes, wit, {"a": (off, n)}))
+    # a sane entry beyond the Input run only grows the buffer (reference: panic at lib.rs:158-161; here: reported size)
+    assert pkg.Graph(serialize_graph(nodes, wit, {"a": (1, 1), "pad": (5, 3)})).n_inputs == 8

@@ -218,6 +218,20 @@ def test_batched_json_front_end_and_wtns_writer(pkg, tmp_path):
     for bad in ('[{"x": 1}, {"x": -1}]', '[{"x": 1},]', '{"x": 1} {"x": ', '[{"nope": 1}]'):
         with pytest.raises(pkg.WitnessCalcError):
             g.inputs_from_json_batch(bad)
+    # many sets: parsed on several host threads (contiguous ranges); same rows, and the LOWEST failing set is reported
+    many = ['{"x": "%d", "y": %d, "arr": ["%d", 2, 3, "%d"]}' % (3 ** (k % 150), k, k * k, 2 ** (k % 250)) for k in range(700)]
+    want = np.stack([g.inputs_from_json(o) for o in many])
+    for threads in ("1", "3", "16"):
+        os.environ["CWC_PARSE_THREADS"] = threads
+        try:
+            assert np.array_equal(g.inputs_from_json_batch("\n".join(many)), want)
+            broken = list(many)
+            broken[611] = '{"x": -5}'
+            broken[305] = '{"x": "12", "y": [1, [2]]}'
+            with pytest.raises(pkg.WitnessCalcError, match="input set 305"):
+                g.inputs_from_json_batch("[" + ",".join(broken) + "]")
+        finally:
+            del os.environ["CWC_PARSE_THREADS"]
     rnd = random.Random(3)
     wit = np.frombuffer(bytes(rnd.getrandbits(8) for _ in range(3 * 4 * 32)), dtype=np.uint8).reshape(3, 4, 32)
     pkg.wtns_save_batch(wit, str(tmp_path / "w_%03lu.wtns"))
