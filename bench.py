@@ -4,12 +4,27 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path (interpreter + witness pack kernels) over one batch of synthetic input
-sets already resident in HBM: BASELINE config 2 -- authV2-class graph, 1024 input sets per GPU (weak scaling:
-every rank evaluates its own 1024 sets; the compiled graph program is broadcast once from rank 0 over RCCL,
-there is no data-path collective).  Prints ONE JSON line on rank 0.
+A step = one pass of the hot path (interpreter + witness pack kernels) over one batch of synthetic input sets already
+resident in HBM.  `value` is BASELINE config 2 -- authV2-class graph, 1024 input sets per GPU, weak scaling: every rank
+evaluates its own shard of a global batch of 1024 x N counter-generated sets; rank 0 compiles, asks the cost model for
+the program of a 1024-set shard and broadcasts that program once over RCCL (no data-path collective).  Prints ONE JSON
+line on rank 0.  Outside `value`, the same line carries (N = 1 unless said otherwise):
+
+  roofline.compute   the ceiling that binds (instruction issue): modmul-equivalents/s against the chip's one-lane
+                     Montgomery product rate measured in this run (gwb_ubench_modmul)
+  cpu_baseline       the oracle's C port of the reference evaluate() on one host core, same input sets, byte-compared
+  config3            BASELINE config 3: sha256_512 graph, 4096 sets, every digest checked against hashlib
+  config4_per_gpu    BASELINE config 4's per-GPU share: 8192 authV2-class sets, sampled sets against the oracle
+  config4            (every N) the config-4 job itself: a global batch of 8192 x N sets, contiguous shards, per-set checksums
+                     of all ranks hashed and compared with the same job recomputed on rank 0 alone
+  json_front_end     sets/s of the batched NDJSON -> rows front-end
+  pcie_inclusive     the host-buffer entry point (never `value`)
+
+`--config 3` / `--config 4` make one of those the timed `value` instead; CWC_GRAPH_BIN=<file.bin> runs a real graph
+(synthetic inputs by its input count) in place of the generated authV2-class one.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,23 +38,82 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 0xC1C00000      # + config number
+# One-lane Montgomery products a node costs: Mul and Fr::new 1; a conversion out of Montgomery form is the
+# reduction half alone (0.5); Div = safegcd inversion (73.5 k lone-wave cycles against 1.44 k for a product) + 2 products.
+MODMUL_EQ = {"Mul": 1.0, "Input": 1.0, "Div": 53.0, "Lt": 1.0, "Gt": 1.0, "Leq": 1.0, "Geq": 1.0, "Shl": 2.0, "Shr": 2.0,
+             "Band": 2.0, "Bor": 2.0, "Bxor": 2.0, "Idiv": 6.0, "Mod": 6.0}
 
 
-def synth_inputs(graph_kind, n_inputs, batch, seed, first_row=None):
-    """Synthetic input sets, canonical 32-byte LE rows: uniform values below 2^253 (< r) for authV2-class,
-    uniform bits for sha256; slot 0 = 1.  Counter-based: depends only on (seed, batch)."""
-    rng = np.random.default_rng(seed)
-    rows = np.frombuffer(rng.bytes(batch * n_inputs * 32), dtype=np.uint8).reshape(batch, n_inputs, 32).copy()
-    if graph_kind == "sha256":
-        rows[:, :, 1:] = 0
-        rows[:, :, 0] &= 1
-    else:
-        rows[:, :, 31] &= 0x1F
-    rows[:, 0, :] = 0
-    rows[:, 0, 0] = 1
-    if first_row is not None:
-        rows[0] = first_row
-    return rows
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def modmul_equivalents(hist, n_witness):
+    return sum(MODMUL_EQ.get(k, 0.0) * v for k, v in hist.items()) + 0.5 * n_witness
+
+
+class Workload:
+    """graph bytes + what is needed to make inputs for it and to check its witnesses"""
+
+    def __init__(self, kind):
+        from tools.graphgen import circuits as C
+        from tools.graphgen.builder import graph_stats
+        self.kind = kind
+        path = os.environ.get("CWC_GRAPH_BIN") if kind == "authv2" else None
+        if path:
+            from oracle import model
+            self.data = open(path, "rb").read()
+            nodes, wit, self.inputs = model.deserialize_witnesscalc_graph(self.data)
+            self.stats = graph_stats(nodes, wit)
+            self.name = "graph file %s" % os.path.basename(path)
+            self.source = "CWC_GRAPH_BIN"
+        else:
+            builder = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512)
+            nodes, wit, self.inputs = builder.finalize()
+            self.stats = graph_stats(nodes, wit)
+            self.data = builder.to_bin()
+            self.name = "authV2-class graph" if kind == "authv2" else "sha256_512 graph"
+            self.source = "generated (tools/graphgen): real circom graphs cannot be built offline"
+        self.input_kind = "bits" if kind == "sha256" else "field"
+
+    def first_row(self, g):
+        if self.kind == "authv2" and self.source != "CWC_GRAPH_BIN":  # global set 0 = the reference's own input file through the JSON path
+            return g.inputs_from_json(open(os.path.join(ROOT, "tests", "golden", "circuit9_authV2_inputs.json")).read())
+        return None
+
+
+def make_inputs(wl, g, batch, config, first_set=0):
+    from tools.synth import synth_inputs
+    return synth_inputs(wl.input_kind, g.n_inputs, batch, SEED + config, first_set, wl.first_row(g) if first_set == 0 else None)
+
+
+def run_steps(g, d_in, d_out, d_st, steps, warmup, distributed):
+    for _ in range(warmup):
+        g.calc_witness_batch_device(d_in, d_out, d_st)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.calc_witness_batch_device(d_in, d_out, d_st)
+        if os.environ.get("BENCH_SYNC_EACH_STEP"):  # diagnostic: the host waits for every step (exposes launch latency)
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def kernel_times(g, steps):
+    """HIP events the library recorded on the launch stream around each kernel of the timed steps (read after the run:
+    no synchronization inside the timed region) -> per-step interpreter / pack milliseconds"""
+    tm = g.last_timing()
+    interp_ms, pack_ms = g.timing_history(steps * tm["n_launches"])
+    assert len(interp_ms) == min(steps * tm["n_launches"], 256)
+    return tm, interp_ms * tm["n_launches"], pack_ms * tm["n_launches"]
 
 
 def main():
@@ -51,15 +125,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=1024)
-    ap.add_argument("--graph", choices=["authv2", "sha256"], default="authv2")
-    ap.add_argument("--tile-width", type=int, default=0, help="0 = library heuristic")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=2, help="BASELINE config timed as `value`")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="0 = the config's own (1024 / 4096 / 8192)")
+    ap.add_argument("--graph", choices=["authv2", "sha256"], default=None, help="(old spelling of --config 2 / 3)")
+    ap.add_argument("--tile-width", type=int, default=0, help="0 = the library's cost model")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="input sets timed on one host core (0 = skip)")
-    ap.add_argument("--extra-batch", type=int, default=8192,
-                    help="also report (outside `value`) the throughput at this per-GPU batch, N=1 only; 0 = skip")
-    ap.add_argument("--host-path", type=int, default=1,
-                    help="also report (outside `value`) the PCIe-inclusive rate of the host-buffer entry point, N=1 only")
+    ap.add_argument("--extras", type=int, default=1, help="0 = only the timed metric (no sub-records)")
+    ap.add_argument("--extra-batch", type=int, default=None, help=argparse.SUPPRESS)   # (round-1 flags, still accepted)
+    ap.add_argument("--host-path", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.graph == "sha256" and args.config == 2:
+        args.config = 3
+    if args.extra_batch == 0 and args.host_path == 0:
+        args.extras = 0
+    cfg = args.config
+    kind = "sha256" if cfg == 3 else "authv2"
+    B = args.batch_per_gpu or {2: 1024, 3: 4096, 4: 8192}[cfg]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,102 +162,108 @@ def main():
         if distributed:
             dist.barrier()
     from circom_witnesscalc_amd import dist as cdist
-    from tools.graphgen import circuits as C
-    from tools.graphgen.builder import graph_stats
 
-    B = args.batch_per_gpu
-    # ---- graph: generated on rank 0, compiled there, program broadcast over RCCL (xGMI) ----
-    data = None
-    stats = None
-    if rank == 0:
-        builder = C.build_authv2_class() if args.graph == "authv2" else C.build_sha256(512)
-        nodes, wit, _ = builder.finalize()
-        stats = graph_stats(nodes, wit)
-        data = builder.to_bin()
+    # ---- graph: built on rank 0, compiled there, the cost model's program for a B-set shard broadcast over RCCL (xGMI) ----
+    wl = Workload(kind) if rank == 0 else None
     if distributed:
-        tile = args.tile_width or pkg.pick_tile_width(B)  # same on every rank
-        g = cdist.broadcast_graph(pkg, data, tile, src=0, device=dev)
+        g = cdist.broadcast_graph(pkg, wl.data if rank == 0 else None, args.tile_width, src=0, device=dev, batch_per_rank=B)
     else:
-        g = pkg.Graph(data)
+        g = pkg.Graph(wl.data)
         g.set_tile_width(args.tile_width)
 
-    first_row = None
-    if rank == 0 and args.graph == "authv2":  # set 0 = the reference's own input file through the JSON path
-        first_row = g.inputs_from_json(open(os.path.join(ROOT, "tests", "golden", "circuit9_authV2_inputs.json")).read())
-    rows = synth_inputs(args.graph, g.n_inputs, B, 0xC1C00002 + rank, first_row)
+    # ---- inputs: this rank's contiguous shard of ONE global batch of B x world counter-generated sets ----
+    from tools.synth import synth_inputs
+    lo, hi = cdist.shard_range(B * world, rank, world)
+    first_row = wl.first_row(g) if rank == 0 else None
+    rows = synth_inputs("bits" if kind == "sha256" else "field", g.n_inputs, hi - lo, SEED + cfg, lo, first_row)
     d_in = torch.from_numpy(rows).to(dev)
-    d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device=dev)
-    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_out = torch.empty((hi - lo, g.n_witness, 32), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
 
-    def step():
-        g.calc_witness_batch_device(d_in, d_out, d_st)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if os.environ.get("BENCH_SYNC_EACH_STEP"):  # diagnostic: the host waits for every step (exposes launch latency)
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = run_steps(g, d_in, d_out, d_st, args.steps, args.warmup, distributed)
     if distributed:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     bad_sets = int((d_st != 0).sum().item())
-    # HIP events the library recorded on the launch stream around each kernel of the timed steps (read after the run:
-    # no synchronization inside the timed region)
-    tm = g.last_timing()
-    interp_ms, pack_ms = g.timing_history(args.steps * tm["n_launches"])
-    assert len(interp_ms) == min(args.steps * tm["n_launches"], 256)
-    interp_ms, pack_ms = interp_ms * tm["n_launches"], pack_ms * tm["n_launches"]  # per step
+    tm, interp_ms, pack_ms = kernel_times(g, args.steps)
 
+    out = None
     if rank == 0:
-        total_sets = world * B * args.steps
-        value = total_sets / elapsed
+        value = world * B * args.steps / elapsed
         avg_interp_s = float(np.mean(interp_ms)) * 1e-3
         alg_bytes = g.algorithmic_bytes_per_set * B  # per launch
         achieved = alg_bytes / avg_interp_s / 1e9
+        traffic, traffic_source = committed_traffic(kind, B, tm["tile_width"])
+        eq_per_set = modmul_equivalents(wl.stats["hist"], g.n_witness)
+        peak4, peak1 = pkg.ubench_modmul(4, 1000), pkg.ubench_modmul(1, 1000)
         out = {
             "metric": "witnesses/sec", "value": value, "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "authV2-class graph, %d input sets per GPU (BASELINE config 2)" % B if args.graph == "authv2"
-                       else "sha256_512 graph, %d input sets per GPU (BASELINE config 3)" % B,
-                       "graph": "generated (tools/graphgen): real circom graphs cannot be built offline",
+            "config": {"workload": "%s, %d input sets per GPU (BASELINE config %d)" % (wl.name, B, cfg),
+                       "graph": wl.source, "inputs": "uniform in [0, r) by rejection (bits for sha256), SplitMix64 of seed 0xC1C0000%d and element id = "
+                       "global set index * n_inputs + k; set 0 = the reference's input file" % cfg,
                        "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth,
-                       "op_histogram": stats["hist"], "batch_per_gpu": B, "tile_width": tm["tile_width"],
+                       "op_histogram": wl.stats["hist"], "batch_per_gpu": B, "tile_width": tm["tile_width"],
                        "interpreter_waves_per_divider_wave": tm["divider"],
                        "bundles": tm["n_bundles"], "slots": tm["n_slots"], "sets_with_error_status": bad_sets,
-                       "parallelism": "batch shards x%d, program broadcast over RCCL" % world if distributed
+                       "parallelism": "contiguous shards of one global batch x%d, cost-model program broadcast over RCCL" % world if distributed
                        else "single process, 1 GPU"},
             "field_ops_per_sec": value * g.n_op,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": committed_traffic(args.graph, B, tm["tile_width"]), "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_interp_s * 1e3,
-                         "pack_kernel_avg_ms": float(np.mean(pack_ms))},
+                         "pack_kernel_avg_ms": float(np.mean(pack_ms)),
+                         "binding_resource": "valu_issue",
+                         "note": "`bound` names the model SURVEY 8(d) prescribes (algorithmic bytes against HBM peak); the counters say the "
+                                 "kernel is bound by instruction issue along the graph's dependency chain, see `compute`",
+                         "compute": {"unit": "modmul-equivalents/s", "achieved": eq_per_set * B / avg_interp_s,
+                                     "peak": peak4 or None, "frac": (eq_per_set * B / avg_interp_s / peak4) if peak4 else None,
+                                     "peak_source": "gwb_ubench_modmul in this run: one-lane Montgomery products/s chip-wide, 4 waves per SIMD",
+                                     "peak_one_wave_per_simd": peak1 or None, "modmul_equivalents_per_set": eq_per_set}},
         }
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(data, rows, d_out, min(args.cpu_sample, B))
-        if world == 1 and args.host_path:
-            out["pcie_inclusive"] = host_path_point(pkg, g, rows, d_out)
-        if world == 1 and args.extra_batch > B:
-            out["large_batch"] = large_batch_point(pkg, g, args.graph, args.extra_batch, dev)
+            t0 = time.perf_counter()
+            out["cpu_baseline"] = cpu_baseline(wl.data, rows, d_out, min(args.cpu_sample, B))
+            log("cpu_baseline: %.1f s" % (time.perf_counter() - t0))
+    if args.extras:
+        extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, out)
+    if rank == 0:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, out):
+    """sub-records outside `value` (every rank takes part in config4, the rest is rank 0 of a single-GPU run)"""
+    t_all = time.perf_counter()
+    if world == 1 and rank == 0:
+        if cfg == 2:
+            out["pcie_inclusive"] = host_path_point(pkg, g, rows, d_out)
+            out["json_front_end"] = json_front_end_point(wl, g)
+        del d_out
+        torch.cuda.empty_cache()
+        if cfg != 3:
+            t0 = time.perf_counter()
+            out["config3"] = config3_point(pkg, dev)
+            log("config3: %.1f s" % (time.perf_counter() - t0))
+        if cfg != 4 and wl.kind == "authv2":
+            t0 = time.perf_counter()
+            out["config4_per_gpu"] = config4_per_gpu_point(pkg, wl, dev)
+            log("config4_per_gpu: %.1f s" % (time.perf_counter() - t0))
+    if wl is None or wl.kind == "authv2" or world > 1:
+        t0 = time.perf_counter()
+        rec = config4_job(pkg, cdist, wl, dev, rank, world, distributed)
+        if rank == 0:
+            out["config4"] = rec
+            log("config4 job: %.1f s" % (time.perf_counter() - t0))
+    if rank == 0:
+        out["extras_seconds"] = time.perf_counter() - t_all
 
 
 def host_path_point(pkg, g, rows, d_out):
@@ -195,34 +282,162 @@ def host_path_point(pkg, g, rows, d_out):
     return res
 
 
-def large_batch_point(pkg, g, graph_kind, batch, dev):
-    """Informational only (never part of `value`): the same kernel at the per-GPU batch of BASELINE config 4
-    (65536 sets over 8 GPUs = 8192 per GPU), device-resident, library-chosen tile width."""
-    rows = synth_inputs(graph_kind, g.n_inputs, batch, 0xC1C00004)
-    d_in = torch.from_numpy(rows).to(dev)
-    d_out = torch.empty((batch, g.n_witness, 32), dtype=torch.uint8, device=dev)
-    d_st = torch.zeros(batch, dtype=torch.int32, device=dev)
+def rows_to_ndjson(g_inputs, rows):
+    """input rows -> NDJSON text with the graph's own signal names (decimal strings, as the reference's input files)"""
+    lines = []
+    for r in rows:
+        vals = [int.from_bytes(r[k].tobytes(), "little") for k in range(r.shape[0])]
+        obj = {name: [str(v) for v in vals[off:off + n]] for name, (off, n) in g_inputs.items()}
+        lines.append(json.dumps(obj))
+    return "\n".join(lines)
+
+
+def json_front_end_point(wl, g, n=4096):
+    """NDJSON of n input objects -> packed rows (gwb_inputs_from_json_batch, host threads)."""
+    from tools.synth import synth_inputs
+    src = synth_inputs("field", g.n_inputs, n, SEED + 8)
+    text = rows_to_ndjson(wl.inputs, src).encode()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = g.inputs_from_json_batch(text)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return {"value": n / best, "unit": "input sets/s", "sets": n, "text_bytes": len(text), "seconds": best,
+            "threads": os.environ.get("CWC_PARSE_THREADS") or "min(cores, 16)", "matches_source_rows": bool(np.array_equal(got, src))}
+
+
+def timed_batch(g, d_in, d_out, d_st, steps=3):
     g.set_tile_width(0)
     g.calc_witness_batch_device(d_in, d_out, d_st)
     torch.cuda.synchronize()
-    steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
         g.calc_witness_batch_device(d_in, d_out, d_st)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    tm = g.last_timing()
-    achieved = g.algorithmic_bytes_per_set * batch / (tm["interp_ms"] * 1e-3) / 1e9
-    return {"batch_per_gpu": batch, "value": batch / dt, "unit": "witnesses/s", "ms_per_step": dt * 1e3,
+    tm, interp_ms, pack_ms = kernel_times(g, steps)
+    return dt, tm, float(np.mean(interp_ms)), float(np.mean(pack_ms))
+
+
+def config3_point(pkg, dev, batch=4096):
+    """BASELINE config 3: sha256_512, 4096 sets on one GPU; EVERY set's 256 output bits against hashlib (an anchor outside
+    this repository's arithmetic), 8 sets against the oracle as whole witnesses."""
+    from oracle import cbind
+    wl = Workload("sha256")
+    g = pkg.Graph(wl.data)
+    rows = make_inputs(wl, g, batch, 3)
+    d_in = torch.from_numpy(rows).to(dev)
+    d_out = torch.empty((batch, g.n_witness, 32), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(batch, dtype=torch.int32, device=dev)
+    dt, tm, interp_ms, pack_ms = timed_batch(g, d_in, d_out, d_st)
+    # witness layout of the generated graph: [1, out[256], in[512], ...]; bits are MSB first per byte as circomlib's Sha256
+    wit_bits = d_out[:, 1:257, 0].cpu().numpy()
+    clean = int(d_out[:, 1:257, 1:].max().item()) == 0
+    msgs = np.packbits(rows[:, 1:513, 0], axis=1)
+    want_bits = np.unpackbits(np.frombuffer(b"".join(hashlib.sha256(m.tobytes()).digest() for m in msgs), dtype=np.uint8).reshape(batch, 32), axis=1)
+    ok = int((wit_bits == want_bits).all(axis=1).sum()) if clean else 0
+    og = cbind.Graph(wl.data)
+    want, st = og.evaluate_batch(rows[:8])
+    return {"workload": "sha256_512 graph, %d input sets, 1 GPU (BASELINE config 3)" % batch, "value": batch / dt, "unit": "witnesses/s",
+            "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms, "tile_width": tm["tile_width"],
+            "n_op": g.n_op, "n_witness": g.n_witness, "bundles": tm["n_bundles"],
+            "sets_with_error_status": int((d_st != 0).sum().item()),
+            "matches_hashlib": bool(ok == batch), "sets_checked_against_hashlib": batch,
+            "matches_oracle": bool(np.array_equal(d_out[:8].cpu().numpy(), want) and not st.any()), "sets_checked_against_oracle": 8}
+
+
+def config4_per_gpu_point(pkg, wl, dev, batch=8192):
+    """BASELINE config 4's per-GPU share (65536 sets over 8 GPUs): 8192 authV2-class sets on this GPU, library-chosen
+    program; 8 sampled sets against the oracle as whole witnesses, error status of every set."""
+    from oracle import cbind
+    g = pkg.Graph(wl.data)
+    rows = make_inputs(wl, g, batch, 4)
+    d_in = torch.from_numpy(rows).to(dev)
+    d_out = torch.empty((batch, g.n_witness, 32), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(batch, dtype=torch.int32, device=dev)
+    dt, tm, interp_ms, pack_ms = timed_batch(g, d_in, d_out, d_st)
+    sample = [0, 1, batch // 3, batch // 2, batch - 2049, batch - 2048, batch - 2, batch - 1]
+    og = cbind.Graph(wl.data)
+    want, st = og.evaluate_batch(rows[sample])
+    got = d_out[torch.tensor(sample, device=dev)].cpu().numpy()
+    achieved = g.algorithmic_bytes_per_set * batch / (interp_ms * 1e-3) / 1e9
+    return {"workload": "%s, %d input sets on one GPU (per-GPU share of BASELINE config 4)" % (wl.name, batch), "value": batch / dt,
+            "unit": "witnesses/s", "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms,
             "tile_width": tm["tile_width"], "interpreter_waves_per_divider_wave": tm["divider"], "launches": tm["n_launches"],
-            "roofline_frac": achieved / HBM_PEAK_GBS, "sets_with_error_status": int((d_st != 0).sum().item())}
+            "roofline_frac": achieved / HBM_PEAK_GBS, "sets_with_error_status": int((d_st != 0).sum().item()),
+            "matches_oracle": bool(np.array_equal(got, want) and not st.any()), "sets_checked_against_oracle": len(sample)}
+
+
+def config4_job(pkg, cdist, wl, dev, rank, world, distributed, per_gpu=8192):
+    """BASELINE config 4 as a job: ONE global batch of per_gpu x N counter-generated authV2-class sets, contiguous shards
+    (shard_range), rank 0 asks the cost model for the program of a shard and broadcasts it, every rank evaluates its
+    shard and returns the 64-bit checksums of its witness rows; rank 0 hashes the list in set order and compares it with
+    the same job recomputed on rank 0 alone, shard by shard (the N = 1 digest).  No data-path collective."""
+    total = per_gpu * world
+    if distributed:
+        if rank == 0 and wl.kind != "authv2":
+            wl = Workload("authv2")
+        g = cdist.broadcast_graph(pkg, wl.data if rank == 0 else None, 0, src=0, device=dev, batch_per_rank=per_gpu)
+    else:
+        if wl.kind != "authv2":
+            wl = Workload("authv2")
+        g = pkg.Graph(wl.data)
+        g.set_tile_width(g.pick_tile_width(per_gpu))
+    from tools.synth import synth_inputs
+    first_row = wl.first_row(g) if rank == 0 else None
+
+    def shard(lo, hi, steps):
+        rows = synth_inputs("field", g.n_inputs, hi - lo, SEED + 4, lo, first_row if lo == 0 else None)
+        d_in = torch.from_numpy(rows).to(dev)
+        d_out = torch.empty((hi - lo, g.n_witness, 32), dtype=torch.uint8, device=dev)
+        d_st = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
+        dt = run_steps(g, d_in, d_out, d_st, steps, 1, distributed and steps > 0) if steps else None
+        if not steps:
+            g.calc_witness_batch_device(d_in, d_out, d_st)
+            torch.cuda.synchronize()
+        cs = cdist.set_checksums(d_out)
+        return dt, cs, int((d_st != 0).sum().item()), g.last_timing()
+
+    lo, hi = cdist.shard_range(total, rank, world)
+    steps = 3
+    dt, cs, bad, tm = shard(lo, hi, steps)
+    if distributed:
+        te = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dt = float(te.item())
+        parts = [torch.empty(cdist.shard_range(total, r, world)[1] - cdist.shard_range(total, r, world)[0], dtype=torch.int64, device=dev)
+                 for r in range(world)]
+        dist.all_gather(parts, cs)   # (64 KiB per rank: bookkeeping of the check, not a data-path exchange)
+        cs_all = torch.cat(parts)
+        tb = torch.tensor([bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb)
+        bad = int(tb.item())
+    else:
+        cs_all = cs
+    if rank != 0:
+        return None
+    digest = hashlib.sha256(cs_all.cpu().numpy().tobytes()).hexdigest()
+    rec = {"workload": "authV2-class graph, one global batch of %d sets = %d per GPU x %d GPU(s) (BASELINE config 4)" % (total, per_gpu, world),
+           "value": total * steps / dt, "unit": "witnesses/s", "n_gpus": world, "ms_per_step": dt / steps * 1e3, "scaling": "weak",
+           "tile_width": tm["tile_width"], "interpreter_waves_per_divider_wave": tm["divider"], "sets_with_error_status": bad,
+           "digest_of_set_checksums": digest}
+    if world > 1:  # the N = 1 reference of the same job, on this GPU alone
+        ref = []
+        for r in range(world):
+            a, b = cdist.shard_range(total, r, world)
+            ref.append(shard(a, b, 0)[1])
+        rec["single_gpu_digest"] = hashlib.sha256(torch.cat(ref).cpu().numpy().tobytes()).hexdigest()
+        rec["matches_single_gpu_digest"] = rec["single_gpu_digest"] == digest
+    return rec
 
 
 def committed_traffic(graph_kind, batch, tile_width):
-    """HBM bytes per interpreter launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json,
-    collected on this same command line), or None when no committed profile matches this configuration."""
+    """HBM bytes per interpreter launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json, collected
+    on this same command line by tools/collect_evidence.sh) -- a cross-reference, not measured in this run -- or None when
+    no committed profile matches this configuration."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
         try:
             j = json.load(open(f))
@@ -231,7 +446,8 @@ def committed_traffic(graph_kind, batch, tile_width):
         c = j.get("config", {})
         if c.get("graph") == graph_kind and c.get("batch_per_gpu") == batch and c.get("tile_width") == tile_width:
             best = j["kernels"]["interp"]["hbm_bytes_per_launch_corrected"]
-    return best
+            src = "committed rocprofv3 --pmc passes of this command line (%s), FETCH_SIZE x2 gfx950 correction; not re-measured in this run" % os.path.relpath(f, ROOT)
+    return best, src or "none: no committed PMC profile matches this graph / batch / tile width"
 
 
 def cpu_baseline(graph_data, rows, d_out, n):
@@ -243,7 +459,9 @@ def cpu_baseline(graph_data, rows, d_out, n):
     t, want, st = og.time_batch(rows[:n])
     got = d_out[:n].cpu().numpy()
     ok = st == 0
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
     out = {"value": n / t, "unit": "witnesses/s", "cores": 1, "kind": "port",
+           "affinity": "one thread, not pinned: scheduled by the OS on the process's %d allowed CPUs" % len(aff) if aff else "one thread",
            "sample": "first %d input sets of rank 0's batch, graph parsed once outside the timed window (B1 of BASELINE.md)" % n,
            "seconds": t, "matches_gpu": bool(np.array_equal(got[ok], want[ok]))}
     # reported beside it: the reference really re-parses the .bin per call (lib.rs:129) ...
@@ -253,7 +471,7 @@ def cpu_baseline(graph_data, rows, d_out, n):
     t_parse = (time.perf_counter() - t0) / 3
     out["including_parse_per_call"] = {"value": 1.0 / (t / n + t_parse), "unit": "witnesses/s", "parse_seconds": t_parse}
     # ... and a courtesy upper bound: the same loop on every host core (the reference is single-threaded)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = len(aff) if aff else (os.cpu_count() or 1)
     if cores > 1:
         tt, want_mt, st_mt = cbind.time_batch_threads(og, rows[:n], cores)
         out["all_cores"] = {"value": n / tt, "unit": "witnesses/s", "cores": cores, "seconds": tt,

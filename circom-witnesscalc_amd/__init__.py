@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "gwb_inputs_from_json", "gwb_set_tile_width", "gwb_calc_witness_batch_device", "gwb_calc_witness_batch_host",
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
     "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width", "gwb_inputs_from_json_batch", "gwb_wtns_save_batch",
-    "gwb_host_alloc", "gwb_host_free", "gwb_timing_history", "gwb_calc_witness_batch_handoff", "gwb_ubench_modmul",
+    "gwb_host_alloc", "gwb_host_free", "gwb_timing_history", "gwb_calc_witness_batch_handoff", "gwb_ubench_modmul", "gwb_graph_pick_tile_width",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
         L.gwb_calc_witness_batch_handoff.argtypes = [vp, vp, sz, vp, vp, ctypes.POINTER(Handoff), stp]
         L.gwb_ubench_modmul.restype = ctypes.c_double
         L.gwb_ubench_modmul.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.gwb_graph_pick_tile_width.restype = ctypes.c_uint32
+        L.gwb_graph_pick_tile_width.argtypes = [vp, sz]
         L.gwb_pick_tile_width.restype = ctypes.c_uint32
         L.gwb_pick_tile_width.argtypes = [sz]
         _lib = L
@@ -243,6 +245,13 @@ class Graph:
         data = ctypes.string_at(out.value, n.value)
         _libc.free(out)
         return data
+
+    def pick_tile_width(self, batch):
+        """Program key the cost model chooses for this graph at this batch size (gwb_graph_pick_tile_width)."""
+        key = int(lib().gwb_graph_pick_tile_width(self._h, batch))
+        if key == 0:
+            raise WitnessCalcError("gwb_graph_pick_tile_width failed")
+        return key
 
     def set_tile_width(self, t):
         if lib().gwb_set_tile_width(self._h, t) != 0:

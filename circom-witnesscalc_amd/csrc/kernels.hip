@@ -654,14 +654,13 @@ hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void
 // Diagnostic (bench.py's compute ceiling): every lane of `waves_per_simd` waves on every SIMD runs a dependent chain of
 // one-lane Montgomery products; returns nothing, the caller times the launch.
 __global__ __launch_bounds__(1024) void modmul_ubench_kernel(uint32_t* sink, uint32_t iters) {
+    // (fr_mul: the per-column multiplier, 380 issue slots, no fixed registers -- four waves per SIMD need <= 128 VGPRs;
+    // the interpreter's one-block fr_mul_wave, 322 slots, pins v160-v167)
     Fr a = fr_r2(), b = fr_one();
     a.v[0] ^= threadIdx.x + blockIdx.x * 977u;
-    Fr pv = fr_p();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pv.v[i]));
     for (uint32_t it = 0; it < iters; ++it) {
-        a = fr_mul_wave(a, b, pv);
-        b = fr_mul_wave(b, a, pv);
+        a = fr_mul(a, b);
+        b = fr_mul(b, a);
     }
     if (a.v[0] == 0x1234567u && b.v[3] == 7u) sink[0] = a.v[1];
 }

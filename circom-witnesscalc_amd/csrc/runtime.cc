@@ -235,8 +235,11 @@ std::string check_device() {
 // (x1.33 measured at 1024 pairs); one divider per four interpreters means five-wave workgroups, one per CU (LDS): x1.23
 // at 1024 tiles, rounds of 1024 tiles beyond.  (profiles/r01_sweep_batch_tile.txt)
 double estimate_cycles(const Program& p, size_t batch) {
-    const double per_wave = program_wave_cycles(p);
-    const double heavy = program_wave_cycles_mul_div(p);
+    // (tiles of 8 sets and more: their bundles measure ~10 % above the per-class table, which was taken at T = 2 --
+    // round 2, authV2-class: 8192 sets T = 4 41.2 ms, T = 8 44.2 ms, T = 8 + group divider 45.0 ms; 16384 sets T = 8 69.2 ms)
+    const double wide = p.T >= 8 ? 1.10 : 1.0;
+    const double per_wave = program_wave_cycles(p) * wide;
+    const double heavy = program_wave_cycles_mul_div(p) * wide;
     const double waves = (double)((batch + p.T - 1) / p.T);
     const double two_per_simd = (1.3 * heavy + 1.9 * (per_wave - heavy)) / per_wave;
     if (p.divider == 4) return per_wave * 1.23 * (waves <= 1024 ? 1.0 : waves / 1024);
@@ -773,6 +776,18 @@ int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
     if (!g || T > 64 || (T & (T - 1)) || (mode && T == 0) || (mode & (mode - 1))) return 1;  // (at most one divider mode)
     g->forced_T = key;
     return 0;
+}
+
+uint32_t gwb_graph_pick_tile_width(gwb_graph_t* g, size_t batch) {
+    // the program key the cost model chooses for this graph and batch size (compiles the candidates on the host; no device
+    // needed): what rank 0 exports and broadcasts to the other GPUs of a node
+    if (!g) return 0;
+    try {
+        std::lock_guard<std::mutex> lk(g->mu);
+        return pick_tile_width(g, batch);
+    } catch (...) {
+        return 0;
+    }
 }
 
 int gwb_calc_witness_batch_device(gwb_graph_t* g, const void* d_inputs, size_t batch, void* d_witness,

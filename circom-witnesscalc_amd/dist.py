@@ -31,18 +31,38 @@ def broadcast_blob(blob, src=0, device=None):
     return buf.cpu().numpy().tobytes()
 
 
-def broadcast_graph(pkg, graph_data, tile_width, src=0, device=None):
-    """Rank `src` parses + compiles `graph_data` (`.bin` bytes) for `tile_width` and broadcasts the compiled
-    program; the other ranks import it (gwb_graph_import) instead of re-parsing.  Returns a pkg.Graph."""
+def broadcast_graph(pkg, graph_data, tile_width=0, src=0, device=None, batch_per_rank=None):
+    """Rank `src` parses + compiles `graph_data` (`.bin` bytes) and broadcasts the compiled program; the other ranks
+    import it (gwb_graph_import: checksummed + validated) instead of re-parsing.  tile_width = 0: rank `src` asks the
+    library's cost model for the program of a `batch_per_rank`-set shard (every rank gets the same shard size up to one
+    set), so the replicas run what a single-GPU call of that size would run.  Returns a pkg.Graph."""
     import torch.distributed as dist
     rank = dist.get_rank()
     g = None
     blob = b""
     if rank == src:
         g = pkg.Graph(graph_data)
+        if not tile_width:
+            assert batch_per_rank, "tile_width = 0 needs the shard size"
+            tile_width = g.pick_tile_width(batch_per_rank)
         g.set_tile_width(tile_width)
         blob = g.export_blob(tile_width)
     blob = broadcast_blob(blob, src=src, device=device)
     if rank != src:
         g = pkg.Graph.from_blob(blob)
     return g
+
+
+def set_checksums(d_witness, chunk=256):
+    """64-bit checksum per input set of device witness rows [B, W, 32] (torch uint8 cuda/cpu tensor): the row's int64
+    words times fixed odd weights, summed with wrap-around.  Independent of how the batch was sharded, so the list of
+    checksums of a job is the same on 1 GPU and on 8 (bench.py hashes that list)."""
+    import torch
+    b, w = d_witness.shape[0], d_witness.shape[1]
+    words = d_witness.view(torch.int64).reshape(b, w * 4)
+    k = torch.arange(1, w * 4 + 1, dtype=torch.int64, device=d_witness.device)
+    weights = (k * -7046029254386353131) | 1   # (0x9E3779B97F4A7C15 as int64; odd multipliers)
+    out = torch.empty(b, dtype=torch.int64, device=d_witness.device)
+    for lo in range(0, b, chunk):
+        out[lo:lo + chunk] = (words[lo:lo + chunk] * weights).sum(dim=1)
+    return out

@@ -77,8 +77,11 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
 #define GWB_TILE_TRIPLE_DIVIDER 0x400u
 /* 0 = choose from the batch size (default); else a program key */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
-/* the program key the library chooses for a batch of this size */
+/* the program key the static rule names for a batch of this size (no graph needed) */
 uint32_t gwb_pick_tile_width(size_t batch);
+/* the program key the cost model chooses for THIS graph and batch size (what a call with tile width 0 will use); 0 on
+ * failure.  Host-only work: rank 0 of a multi-GPU job asks once, exports that program and broadcasts it. */
+uint32_t gwb_graph_pick_tile_width(gwb_graph_t *g, size_t batch);
 
 /* Evaluate `batch` input sets resident in device memory (graph::evaluate per set, src/graph.rs:367-391).
  *   d_inputs  : [batch][n_inputs][32 B] canonical LE

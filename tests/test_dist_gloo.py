@@ -81,3 +81,64 @@ def test_broadcast_program_blob_world2():
     assert res[0][1] == res[1][1] > 0 and res[0][2] == res[1][2] == 4
     assert (res[0][3], res[0][4], res[1][3], res[1][4]) == (0, 5, 5, 10)
     assert res[0][5] and res[1][5]
+
+
+def _worker_config4(rank, world, port, q):
+    """BASELINE config 4's flow at toy size on the emulator: one global batch of counter-generated sets, contiguous
+    shards, rank 0 asks the cost model for the program of a shard and broadcasts it (checksummed blob), every rank
+    evaluates its shard and contributes per-set checksums; the hash of the gathered list must equal the single-process one."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cwc_import
+    pkg = cwc_import.load()
+    from circom_witnesscalc_amd import dist as cdist
+    from tools.graphgen import circuits as C
+    from tools.synth import synth_inputs
+    import program_emulator as pe
+    data = C.build_gadgets().to_bin()
+    total, per = 14, 7
+    key, blob = 0, b""
+    if rank == 0:
+        g = pkg.Graph(data)
+        key = g.pick_tile_width(per)          # host-only: the cost model needs no device
+        blob = g.export_blob(key)
+    got = cdist.broadcast_blob(blob, src=0, device="cpu")
+    prog = pe.Blob(got)
+
+    def evaluate(lo, hi):
+        rows = synth_inputs("field", prog.n_inputs, hi - lo, 0xC1C00004, lo)
+        wit = np.zeros((hi - lo, prog.n_witness, 32), dtype=np.uint8)
+        for s in range(hi - lo):
+            vals, status = pe.run(prog, [int.from_bytes(rows[s, k].tobytes(), "little") for k in range(prog.n_inputs)])
+            if status == 0:
+                wit[s] = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32)
+        return cdist.set_checksums(torch.from_numpy(wit))
+    lo, hi = cdist.shard_range(total, rank, world)
+    cs = evaluate(lo, hi)
+    parts = [torch.empty(cdist.shard_range(total, r, world)[1] - cdist.shard_range(total, r, world)[0], dtype=torch.int64) for r in range(world)]
+    dist.all_gather(parts, cs)
+    digest = hashlib.sha256(torch.cat(parts).numpy().tobytes()).hexdigest()
+    single = hashlib.sha256(evaluate(0, total).numpy().tobytes()).hexdigest() if rank == 0 else None
+    dist.barrier()
+    q.put((rank, digest, single, prog.T, lo, hi))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_config4_flow_world2_digest_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config4, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == res[0][2]                      # both ranks see the same digest = the single-process digest
+    assert (res[0][4], res[0][5], res[1][4], res[1][5]) == (0, 7, 7, 14) and res[0][3] == res[1][3]

@@ -413,3 +413,285 @@ def test_timing_history_covers_asynchronous_calls(pkg):
     assert tm["n_launches"] == 1 and abs(tm["interp_ms"] - float(interp[-1])) < 1e-6
     want, _ = cbind.Graph(data).evaluate_batch(rows)
     assert np.array_equal(d_out.cpu().numpy(), want) and not d_st.any().item()
+
+
+# ---- round 2: the BASELINE configurations at their named sizes, an outside anchor for the division-heavy block, and the
+# ---- callers either side of the path end to end on the GPU -------------------------------------------------
+def _synth(kind, n_inputs, batch, seed, first_set=0):
+    from tools.synth import synth_inputs
+    return synth_inputs(kind, n_inputs, batch, seed, first_set)
+
+
+def test_config4_share_authv2_class_8192_sets(pkg):
+    """BASELINE config 4's per-GPU share (65536 sets over 8 GPUs = 8192 per GPU) at its named size, with the program the
+    library chooses for that batch and with T = 4 + group divider: sampled sets against the oracle byte for byte, all
+    sets through properties (witness[0] == 1, no error status, the same per-set checksums under both programs, a
+    duplicated input set gives a duplicated witness and nothing else does, the first 1024 sets equal to a separate
+    1024-set call)."""
+    import torch
+    from circom_witnesscalc_amd.dist import set_checksums
+    b = C.build_authv2_class()
+    data = b.to_bin()
+    g = pkg.Graph(data)
+    og = cbind.Graph(data)
+    B = 8192
+    inp = _synth("field", g.n_inputs, B, 0xC1C00004)
+    inp[B - 1] = inp[17]
+    d_in = torch.from_numpy(inp).cuda()
+    d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    sums = []
+    for tw in (0, 4 | GROUP):
+        g.set_tile_width(tw)
+        d_out.zero_()
+        g.calc_witness_batch_device(d_in, d_out, d_st)
+        torch.cuda.synchronize()
+        assert int((d_st != 0).sum()) == 0
+        sums.append(set_checksums(d_out).cpu().numpy())
+        assert bool((d_out[:, 0, 0] == 1).all()) and not bool(d_out[:, 0, 1:].any())
+    assert np.array_equal(sums[0], sums[1])
+    assert g.last_timing()["tile_width"] == 4 and g.last_timing()["divider"] == 4
+    assert sums[0][B - 1] == sums[0][17] and len(set(sums[0].tolist())) == B - 1   # the duplicate set, and only it, repeats
+    sample = [0, 1, 4095, 4096, 6143, 6144, 8190, 8191]
+    want, wst = og.evaluate_batch(inp[sample])
+    assert not wst.any() and np.array_equal(d_out[torch.tensor(sample, device="cuda")].cpu().numpy(), want)
+    g.set_tile_width(0)
+    d_small = torch.empty((1024, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+    g.calc_witness_batch_device(d_in[:1024], d_small, d_st[:1024])
+    torch.cuda.synchronize()
+    assert np.array_equal(set_checksums(d_small).cpu().numpy(), sums[0][:1024])
+
+
+def test_config3_sha256_512_4096_sets_every_digest_against_hashlib(pkg):
+    """BASELINE config 3 at its named size: 4096 uniform 512-bit messages, EVERY set's 256 output bits against hashlib."""
+    import torch
+    data = C.build_sha256(512).to_bin()
+    g = pkg.Graph(data)
+    B = 4096
+    inp = _synth("bits", g.n_inputs, B, 0xC1C00003)
+    ref_in = json.load(open(os.path.join(GOLD, "circuit8_sha256_512_inputs.json")))["in"]
+    inp[0, 1:, 0] = ref_in                                  # set 0 = the reference's own input file
+    d_in = torch.from_numpy(inp).cuda()
+    d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    g.calc_witness_batch_device(d_in, d_out, d_st)
+    torch.cuda.synchronize()
+    assert int((d_st != 0).sum()) == 0 and not bool(d_out[:, 1:257, 1:].any())
+    msgs = np.packbits(inp[:, 1:513, 0], axis=1)
+    want = np.unpackbits(np.frombuffer(b"".join(hashlib.sha256(m.tobytes()).digest() for m in msgs), dtype=np.uint8).reshape(B, 32), axis=1)
+    assert np.array_equal(d_out[:, 1:257, 0].cpu().numpy(), want)
+    wfull, _ = cbind.Graph(data).evaluate_batch(inp[:8])
+    assert np.array_equal(d_out[:8].cpu().numpy(), wfull)
+
+
+def test_config5_class_bigint_graph_one_million_nodes(pkg):
+    """BASELINE config 5's class at over a million nodes (the 10.5 M-node size runs as a tool, tools/gpu_bigint.py): 32
+    input sets (the per-GPU share of 256 over 8 GPUs) against the oracle, whole witnesses."""
+    b = C.build_bigint_class(k=32, rounds=400)
+    data = b.to_bin()
+    g = pkg.Graph(data)
+    assert g.n_nodes >= 1000000
+    rnd = random.Random(55)
+    rows = cbind.ints_to_array([[1] + [rnd.randrange(1 << 64) for _ in range(g.n_inputs - 1)] for _ in range(32)])
+    want, wst = cbind.Graph(data).evaluate_batch(rows)
+    got, st = g.calc_witness_batch(rows)
+    assert np.array_equal(st != 0, wst != 0) and np.array_equal(got[wst == 0], want[wst == 0])
+
+
+# BabyJubjub in twisted Edwards form a x^2 + y^2 = 1 + d x^2 y^2 (a = 168700, d = 168696), independent of the generator's
+# Montgomery-form gadgets: the unified addition law and double-and-add on Python integers.
+_BJ_A, _BJ_D = 168700, 168696
+_BJ_BASE8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553,
+             16950150798460657717958625567821834550301663161624707787222815936182638968203)
+_BJ_ORDER = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+
+
+def _ed_add(p, q):
+    (x1, y1), (x2, y2) = p, q
+    t = _BJ_D * x1 * x2 * y1 * y2 % M
+    return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, M) % M, (y1 * y2 - _BJ_A * x1 * x2) * pow(1 - t, -1, M) % M)
+
+
+def _ed_mul(k, p):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = _ed_add(acc, p)
+        p = _ed_add(p, p)
+        k >>= 1
+    return acc
+
+
+def _ed_to_mont(p):   # (x, y) -> (u, v) = ((1 + y) / (1 - y), u / x)
+    x, y = p
+    u = (1 + y) * pow(1 - y, -1, M) % M
+    return u, u * pow(x, -1, M) % M
+
+
+def test_division_heavy_block_against_the_babyjubjub_group_law(pkg):
+    """The outside anchor for the Div / inversion-heavy block (what hashlib is for the SHA-256 block): the generator's
+    circomlib-shaped curve gadgets -- MontgomeryDouble / MontgomeryAdd ladders (two dependent field divisions per bit) and
+    BabyAdd (two divisions) -- evaluated on the GPU must agree with the group law of the curve computed independently in
+    Edwards coordinates on Python integers: scalar_mul_any(bits, [r]B) = [(2k+1) r mod l]B and [r1]B + [r2]B = [r1+r2]B,
+    for 64 random sets.  (reference semantics: Operation::Div, src/graph.rs:109, vectors :787-800)"""
+    assert (_BJ_A * _BJ_BASE8[0] ** 2 + _BJ_BASE8[1] ** 2 - 1 - _BJ_D * _BJ_BASE8[0] ** 2 * _BJ_BASE8[1] ** 2) % M == 0
+    assert _ed_mul(_BJ_ORDER, _BJ_BASE8) == (0, 1)
+    nbits = 24
+    b = Builder()
+    bits = b.input("bits", nbits)
+    pu, pv = b.input("p", 2)
+    q1 = b.input("q1", 2)
+    q2 = b.input("q2", 2)
+    su, sv = C.scalar_mul_any(b, bits, (pu, pv))
+    b.signal(su)
+    b.signal(sv)
+    ax, ay = C.baby_add(b, tuple(q1), tuple(q2))
+    data = b.to_bin()
+    g = pkg.Graph(data)
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    rnd = random.Random(2024)
+    rows, want = [], []
+    for _ in range(64):
+        r, r1, r2 = (rnd.randrange(1, _BJ_ORDER) for _ in range(3))
+        k = rnd.getrandbits(nbits)
+        p_ed, q1_ed, q2_ed = _ed_mul(r, _BJ_BASE8), _ed_mul(r1, _BJ_BASE8), _ed_mul(r2, _BJ_BASE8)
+        rows.append([1] + [(k >> i) & 1 for i in range(nbits)] + list(_ed_to_mont(p_ed)) + list(q1_ed) + list(q2_ed))
+        want.append(_ed_to_mont(_ed_mul((2 * k + 1) * r % _BJ_ORDER, _BJ_BASE8)) + _ed_mul((r1 + r2) % _BJ_ORDER, _BJ_BASE8))
+    inp = cbind.ints_to_array(rows)
+    # positions of the four result nodes in the witness: the last two signals of the ladder, the last two of BabyAdd
+    w_all, wst = cbind.Graph(data).evaluate_batch(inp)
+    assert not wst.any()
+    for tw in (0, 1, 2 | DIVIDER, 4 | GROUP, 64):
+        g.set_tile_width(tw)
+        got, st = g.calc_witness_batch(inp)
+        assert not st.any() and np.array_equal(got, w_all), tw
+    n_w = got.shape[1]
+    # the ladder's (su, sv) were signalled just before BabyAdd's six signals (beta, gamma, delta, tau, xo, yo)
+    idx = [n_w - 8, n_w - 7, n_w - 2, n_w - 1]
+    for s in range(64):
+        vals = cbind.array_to_ints(got[s][idx])
+        assert tuple(vals) == tuple(want[s]), s
+
+
+def test_json_to_wtns_end_to_end_on_the_gpu(pkg, tmp_path):
+    """SURVEY 8(f) f3 end to end: NDJSON of 4096 authV2-class input objects -> gwb_inputs_from_json_batch (host threads) ->
+    device -> rows back -> gwb_wtns_save_batch; every set's rows against a per-set checksum of a direct run, 32 of the
+    files byte-compared with the oracle's `.wtns` (wtns_from_witness of the big-int model's framing)."""
+    import torch
+    from circom_witnesscalc_amd.dist import set_checksums
+    bld = C.build_authv2_class()
+    nodes, wit, inputs = bld.finalize()
+    data = bld.to_bin()
+    g = pkg.Graph(data)
+    B = 4096
+    src = _synth("field", g.n_inputs, B, 0xC1C00008)
+    lines = []
+    for r in src:
+        vals = [int.from_bytes(r[k].tobytes(), "little") for k in range(g.n_inputs)]
+        lines.append(json.dumps({name: [str(v) for v in vals[off:off + n]] for name, (off, n) in inputs.items()}))
+    rows = g.inputs_from_json_batch("\n".join(lines))
+    assert np.array_equal(rows, src)
+    d_in = torch.from_numpy(rows).cuda()
+    d_out = torch.empty((B, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    g.calc_witness_batch_device(d_in, d_out, d_st)
+    torch.cuda.synchronize()
+    assert int((d_st != 0).sum()) == 0
+    first = d_out[:32].cpu().numpy()
+    pkg.wtns_save_batch(first, str(tmp_path / "w_%04lu.wtns"))
+    og = cbind.Graph(data)
+    want, _ = og.evaluate_batch(src[:32])
+    for i in range(32):
+        vals = cbind.array_to_ints(want[i])
+        assert (tmp_path / ("w_%04d.wtns" % i)).read_bytes() == model.wtns_from_witness(vals), i
+    # every set: the same rows as the host-buffer entry point produces from the same JSON (another route through the library)
+    got2, st2 = g.calc_witness_batch(rows[1000:1256])
+    assert not st2.any() and np.array_equal(set_checksums(torch.from_numpy(got2)).numpy(), set_checksums(d_out[1000:1256]).cpu().numpy())
+
+
+def test_bin_writer_round_trip_on_the_gpu(pkg):
+    """serialize_witnesscalc_graph (storage.rs:137-183) -> reload -> the reloaded graph computes the same
+    witnesses on the GPU as the original, and re-serializes to the same bytes."""
+    rnd = random.Random(77)
+    for builder in (C.build_gadgets(), C.build_random_dag(5, n_ops=500), C.build_poseidon(3)):
+        data = builder.to_bin()
+        g = pkg.Graph(data)
+        again = g.serialize()
+        g2 = pkg.Graph(again)
+        assert g2.serialize() == again and (g2.n_nodes, g2.n_witness, g2.n_inputs) == (g.n_nodes, g.n_witness, g.n_inputs)
+        rows = cbind.ints_to_array([_rand_row(rnd, g.n_inputs) for _ in range(40)])
+        a, sa = g.calc_witness_batch(rows)
+        b2, sb = g2.calc_witness_batch(rows)
+        assert np.array_equal(a, b2) and np.array_equal(sa, sb)
+
+
+def test_prover_handoff_montgomery_rows_and_event(pkg):
+    """gwb_calc_witness_batch_handoff leaves the rows in HBM in Montgomery form (x * 2^256 mod r) and
+    records the caller's event behind its last kernel; a consumer stream that waits on the event (no host
+    synchronization) reads complete rows, and they are the canonical witnesses times 2^256."""
+    import torch
+    data = C.build_poseidon(2).to_bin()
+    g = pkg.Graph(data)
+    rnd = random.Random(4)
+    rows = cbind.ints_to_array([_rand_row(rnd, 3, 0) for _ in range(200)])
+    want, _ = cbind.Graph(data).evaluate_batch(rows)
+    d_in = torch.from_numpy(rows).cuda()
+    d_out = torch.zeros((200, g.n_witness, 32), dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(200, dtype=torch.int32, device="cuda")
+    producer, consumer = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    torch.cuda.synchronize()
+    g.calc_witness_batch_device(d_in, d_out, d_st, stream=producer, montgomery=True, done_event=ev)
+    with torch.cuda.stream(consumer):
+        consumer.wait_event(ev)
+        copy = d_out.clone()
+    consumer.synchronize()
+    got = copy.cpu().numpy()
+    rinv = pow(1 << 256, -1, M)
+    for s in (0, 57, 199):
+        assert [v * rinv % M for v in cbind.array_to_ints(got[s])] == cbind.array_to_ints(want[s])
+    # canonical form through the same entry point is the plain device call
+    g.calc_witness_batch_device(d_in, d_out, d_st, stream=producer, done_event=ev)
+    ev.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), want)
+
+
+def test_calls_on_different_streams_execute_in_enqueue_order(pkg):
+    """One handle, one value workspace: calls enqueued on different streams must not overlap (the advisor's finding: the
+    second call's tiles / constant refill used to race the first).  Alternating batch sizes forces workspace refills."""
+    import torch
+    data = C.build_gadgets().to_bin()
+    g = pkg.Graph(data)
+    og = cbind.Graph(data)
+    rnd = random.Random(9)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    jobs = []
+    for i in range(12):
+        n = (700, 64, 333)[i % 3]
+        rows = cbind.ints_to_array([_rand_row(rnd, 7) for _ in range(n)])
+        d_in = torch.from_numpy(rows).cuda()
+        jobs.append((rows, d_in, torch.zeros((n, g.n_witness, 32), dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")))
+    torch.cuda.synchronize()
+    for i, (rows, d_in, d_out, d_st) in enumerate(jobs):
+        g.set_tile_width((1, 4, 2 | DIVIDER)[i % 3])
+        g.calc_witness_batch_device(d_in, d_out, d_st, stream=streams[i % 3])
+    torch.cuda.synchronize()
+    for rows, d_in, d_out, d_st in jobs:
+        want, wst = og.evaluate_batch(rows)
+        ok = wst == 0
+        assert np.array_equal(d_st.cpu().numpy() != 0, wst != 0) and np.array_equal(d_out.cpu().numpy()[ok], want[ok])
+
+
+def test_single_shot_cache_distinguishes_graphs_of_equal_length(pkg):
+    """gw_calc_witness keeps compiled graphs keyed by the graph bytes themselves: two `.bin` images of the same length
+    that differ in one constant give their own witnesses, in either order."""
+    def build(c):
+        b = Builder()
+        (x,) = b.input("x")
+        b.signal(b.add(b.mul(x, x), b.const(c)))
+        return b.to_bin()
+    d1, d2 = build(1000), build(2000)
+    assert len(d1) == len(d2) and d1 != d2
+    for _ in range(2):
+        assert pkg.calc_witness('{"x": "7"}', d1)[1] == 1049
+        assert pkg.calc_witness('{"x": "7"}', d2)[1] == 2049

@@ -7,7 +7,11 @@ import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
-from bench import synth_inputs
+from tools.synth import synth_inputs as _synth_inputs
+
+
+def synth_inputs(kind, n_inputs, batch, seed):
+    return _synth_inputs("bits" if kind == "sha256" else "field", n_inputs, batch, seed)
 
 for kind, builder in (("authv2", C.build_authv2_class()), ("sha256", C.build_sha256(512))):
     g = pkg.Graph(builder.to_bin())

@@ -8,7 +8,11 @@ import numpy as np
 import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
-from bench import synth_inputs
+from tools.synth import synth_inputs as _synth_inputs
+
+
+def synth_inputs(kind, n_inputs, batch, seed):
+    return _synth_inputs("bits" if kind == "sha256" else "field", n_inputs, batch, seed)
 g = pkg.Graph(C.build_authv2_class().to_bin())
 print("host cores:", os.cpu_count(), "copy threads:", os.environ.get("CWC_COPY_THREADS", "default"), flush=True)
 for B in (1024, 4096):

@@ -6,7 +6,11 @@ import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
-from bench import synth_inputs
+from tools.synth import synth_inputs as _synth_inputs
+
+
+def synth_inputs(kind, n_inputs, batch, seed):
+    return _synth_inputs("bits" if kind == "sha256" else "field", n_inputs, batch, seed)
 for kind, builder, cases in (("authv2", C.build_authv2_class, [(512, 0x101), (512, 0x102), (1024, 0x101), (1024, 0x102), (1024, 0x104), (2048, 0x102), (2048, 0x104), (1024, 2), (1536, 2), (2048, 2), (3072, 4), (4096, 4), (6144, 8), (8192, 8)]),
                              ("sha256", lambda: C.build_sha256(512), [(512, 1), (768, 1), (1024, 1), (2048, 2), (4096, 4)])):
     g = pkg.Graph(builder().to_bin())

@@ -8,7 +8,11 @@ pkg = cwc_import.load()
 from oracle import cbind
 from tools.graphgen import circuits as C
 sys.path.insert(0, ROOT)
-from bench import synth_inputs
+from tools.synth import synth_inputs as _synth_inputs
+
+
+def synth_inputs(kind, n_inputs, batch, seed):
+    return _synth_inputs("bits" if kind == "sha256" else "field", n_inputs, batch, seed)
 
 def run(kind, builder, cases):
     data = builder.to_bin()

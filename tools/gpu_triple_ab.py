@@ -7,7 +7,11 @@ import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
-from bench import synth_inputs
+from tools.synth import synth_inputs as _synth_inputs
+
+
+def synth_inputs(kind, n_inputs, batch, seed):
+    return _synth_inputs("bits" if kind == "sha256" else "field", n_inputs, batch, seed)
 g = pkg.Graph(C.build_authv2_class().to_bin())
 D, G, T3 = 0x100, 0x200, 0x400
 for B, keys in ((768, (1 | T3, 2 | D, 1 | D, 1 | G)), (1024, (2 | D, 2 | T3)), (1536, (2 | T3, 4 | D, 2 | G, 2 | D)), (3072, (4 | T3, 4 | G, 4 | D, 8 | D)),
