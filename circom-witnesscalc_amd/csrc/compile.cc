@@ -459,7 +459,17 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     st.depth = depth;
 
     phase("levels");
-    // ---- exact depth-reducing rewrite (the statistics above describe the graph as loaded) ----
+    // ---- load-time re-optimiser (the statistics above describe the graph as loaded) ----
+    if (!getenv("CWC_NO_LOAD_OPTIMIZE")) {
+        OptimizeStats os;
+        optimize_loaded_graph(g, &os);
+        N = g.nodes.size();
+        st.n_folded = os.folded;
+        st.n_numbered = os.numbered + os.constants_merged;
+        st.n_shaken = os.shaken;
+        phase("load-time optimiser");
+    }
+    // ---- exact depth-reducing rewrite ----
     if (bit_fusion && !getenv("CWC_NO_BIT_FUSION")) {
         fuse_bit_extract(g);
         N = g.nodes.size();

@@ -45,6 +45,14 @@ bool deserialize_witnesscalc_graph(const uint8_t* data, size_t len, Graph& g, st
 // storage.rs:137-183
 std::vector<uint8_t> serialize_witnesscalc_graph(const Graph& g);
 
+// Load-time re-optimiser (optimize.cc; the reference's build-time passes src/graph.rs:358-619 as exact rewrites): constant
+// propagation with eval_fr semantics, structural value numbering of all pure operations, removal of unused nodes (Input
+// nodes and operations that can fail are kept).  Rewrites g in place; witness values are unchanged.
+struct OptimizeStats {
+    uint64_t nodes_before = 0, nodes_after = 0, folded = 0, numbered = 0, constants_merged = 0, shaken = 0;
+};
+void optimize_loaded_graph(Graph& g, OptimizeStats* stats);
+
 // lib.rs:138-152
 size_t get_inputs_size(const Graph& g);
 // Size actually allocated for the inputs buffer: max(get_inputs_size, max(offset+len) over the input map,

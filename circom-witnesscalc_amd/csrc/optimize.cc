@@ -1,0 +1,290 @@
+// Load-time re-optimiser of a loaded graph: the reference's build-time passes (src/graph.rs:358-619:
+// tree_shake, propagate, value_numbering, constants) restated as EXACT rewrites that a `.bin` from any producer goes
+// through before scheduling.  Nothing here is probabilistic (the reference's value_numbering / constants evaluate the
+// graph on random field elements, :499-600), and every witness value stays bit-identical:
+//
+//   propagate        an operation whose operands are all constants becomes a constant, evaluated with the semantics of
+//                    Operation::eval_fr / UnoOperation::eval_fr / TresOperation::eval_fr (src/graph.rs:102-144, 188-197,
+//                    221-225) -- what evaluate() would have computed at run time; the reference's own pass uses
+//                    Operation::eval on U256 (:394-428), whose results differ from eval_fr for Shl and the bit operations,
+//                    so it is deliberately NOT followed.  A constant operation that would panic in the reference (Shl
+//                    result >= r, bit-op result == r) is left in place: the failure still surfaces at evaluation.
+//                    Same-operand comparisons (:404-413: Eq/Leq/Geq -> 1, Neq/Lt/Gt -> 0) and the field identities
+//                    x*0, x*1, x+0, x-0, x-x, 0/x are folded too.
+//   value numbering  two pure operations with the same operator and the same (already numbered) operands are one node;
+//                    Add / Mul / Eq / Neq / Land / Lor / Bor / Band / Bxor commute.  Structural, hence exact.
+//   tree shake       nodes nothing depends on are dropped (:431-498) -- except Input nodes (they size the inputs buffer,
+//                    src/lib.rs:138-152) and every operation that can fail, with what feeds it: the reference evaluates
+//                    the whole graph, so an unused Shl that overflows still aborts there and still reports here.
+#include <string.h>
+
+#include <unordered_map>
+
+#include "graph.hpp"
+
+namespace cwc {
+
+namespace {
+
+bool is_zero(const Fr& x) { return u256_is_zero(x); }
+Fr one_canon() {
+    Fr o = fr_zero();
+    o.v[0] = 1;
+    return o;
+}
+Fr bool_val(bool b) { return b ? one_canon() : fr_zero(); }
+
+// signed comparison of canonical values, src/graph.rs:720-769 (neg(x) := x > halfM)
+void cmp_signed(const Fr& a, const Fr& b, bool& lt, bool& gt) {
+    const bool an = u256_lt(fr_half(), a), bn = u256_lt(fr_half(), b);
+    if (an == bn) {
+        lt = u256_lt(a, b);
+        gt = u256_lt(b, a);
+    } else {
+        lt = an;
+        gt = bn;
+    }
+}
+
+// eval_fr on canonical operands -> canonical result; false = the reference would panic (leave the node alone)
+bool fold_duo(uint8_t op, const Fr& a, const Fr& b, Fr& out) {
+    switch (op) {
+        case OP_MUL: out = fr_from_mont(fr_mul(fr_to_mont(a), fr_to_mont(b))); return true;
+        case OP_DIV:
+            if (is_zero(b)) out = fr_zero();
+            else out = fr_from_mont(fr_mul(fr_to_mont(a), fr_inv(fr_to_mont(b))));
+            return true;
+        case OP_ADD: out = fr_add(a, b); return true;
+        case OP_SUB: out = fr_sub(a, b); return true;
+        case OP_IDIV:
+        case OP_MOD: {
+            if (is_zero(b)) {
+                out = fr_zero();
+                return true;
+            }
+            Fr q, rem;
+            u256_divrem(q, rem, a, b, 256);
+            out = op == OP_IDIV ? q : rem;
+            return true;
+        }
+        case OP_EQ: out = bool_val(u256_eq(a, b)); return true;
+        case OP_NEQ: out = bool_val(!u256_eq(a, b)); return true;
+        case OP_LT: case OP_GT: case OP_LEQ: case OP_GEQ: {
+            bool lt, gt;
+            cmp_signed(a, b, lt, gt);
+            out = bool_val(op == OP_LT ? lt : op == OP_GT ? gt : op == OP_LEQ ? !gt : !lt);
+            return true;
+        }
+        case OP_LAND: out = bool_val(!is_zero(a) && !is_zero(b)); return true;
+        case OP_LOR: out = bool_val(!is_zero(a) || !is_zero(b)); return true;
+        case OP_SHL:
+        case OP_SHR: {  // src/graph.rs:621-672
+            if (is_zero(b)) {
+                out = a;
+                return true;
+            }
+            uint32_t hi = 0;
+            for (int i = 1; i < 8; ++i) hi |= b.v[i];
+            if (hi != 0 || b.v[0] >= 254u) {
+                out = fr_zero();
+                return true;
+            }
+            out = op == OP_SHL ? u256_shl(a, b.v[0]) : u256_shr(a, b.v[0]);
+            return op == OP_SHR || u256_lt(out, fr_p());  // Shl: from_bigint().unwrap() panics on >= r (:634)
+        }
+        case OP_BOR: case OP_BAND: case OP_BXOR: {  // :674-717
+            Fr d;
+            for (int i = 0; i < 8; ++i) d.v[i] = op == OP_BAND ? (a.v[i] & b.v[i]) : op == OP_BOR ? (a.v[i] | b.v[i]) : (a.v[i] ^ b.v[i]);
+            Fr t;
+            if (u256_sub(t, d, fr_p()) == 0) {  // d >= r
+                if (is_zero(t)) return false;    // d == r: the reference panics
+                d = t;
+            }
+            out = d;
+            return true;
+        }
+        default: return false;  // Pow: not evaluable (graph.rs:141-142), rejected later
+    }
+}
+
+bool can_fail(const Node& n) { return n.kind == N_DUO && (n.op == OP_SHL || n.op == OP_BOR || n.op == OP_BXOR || n.op == OP_BAND); }
+bool commutes(uint8_t op) {
+    return op == OP_MUL || op == OP_ADD || op == OP_EQ || op == OP_NEQ || op == OP_LAND || op == OP_LOR || op == OP_BOR || op == OP_BAND || op == OP_BXOR;
+}
+
+struct KeyHash {
+    size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
+        return (size_t)((k.first * 0x9E3779B97F4A7C15ull) ^ (k.second * 0xC2B2AE3D27D4EB4Full) ^ (k.first >> 29));
+    }
+};
+struct FrHash {
+    size_t operator()(const Fr& x) const {
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < 8; ++i) h = (h ^ x.v[i]) * 1099511628211ull;
+        return (size_t)h;
+    }
+};
+struct FrEq {
+    bool operator()(const Fr& a, const Fr& b) const { return memcmp(a.v, b.v, sizeof a.v) == 0; }
+};
+
+}  // namespace
+
+// Rewrites g in place (nodes, constants, witness references); the input map is untouched.  References must be backward
+// (validated by the caller).  Returns counts for the statistics line.
+void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
+    const size_t N = g.nodes.size();
+    std::vector<Node> out;
+    out.reserve(N);
+    std::vector<uint32_t> m(N, 0xffffffffu);  // old node -> new node
+    std::unordered_map<Fr, uint32_t, FrHash, FrEq> const_node;  // canonical value -> new constant node
+    std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> vn;
+    OptimizeStats st;
+    st.nodes_before = N;
+    auto make_const = [&](const Fr& v) -> uint32_t {
+        auto it = const_node.find(v);
+        if (it != const_node.end()) return it->second;
+        const uint32_t idx = (uint32_t)out.size();
+        out.push_back(Node{N_CONST, 0, (uint32_t)g.const_values.size(), 0, 0});
+        g.const_values.push_back(v);
+        const_node.emplace(v, idx);
+        return idx;
+    };
+    auto const_of = [&](uint32_t idx, Fr& v) -> bool {
+        if (out[idx].kind != N_CONST) return false;
+        v = g.const_values[out[idx].a];
+        return true;
+    };
+    // Constants of the file sit in front of their users or (appended by earlier rewrites) behind them: number them first.
+    for (size_t i = 0; i < N; ++i)
+        if (g.nodes[i].kind == N_CONST) {
+            const Fr v = g.const_values[g.nodes[i].a];
+            auto it = const_node.find(v);
+            if (it != const_node.end()) {
+                m[i] = it->second;
+                st.constants_merged++;
+            } else {
+                m[i] = (uint32_t)out.size();
+                out.push_back(g.nodes[i]);
+                const_node.emplace(v, m[i]);
+            }
+        }
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        if (n.kind == N_INPUT) {
+            m[i] = (uint32_t)out.size();
+            out.push_back(n);
+            continue;
+        }
+        Node c = n;
+        const int ar = n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : 3;
+        c.a = m[n.a];
+        if (ar >= 2) c.b = m[n.b];
+        if (ar >= 3) c.c = m[n.c];
+        Fr va, vb, vc, r;
+        const bool ca = const_of(c.a, va), cb = ar >= 2 && const_of(c.b, vb), cc = ar >= 3 && const_of(c.c, vc);
+        uint32_t repl = 0xffffffffu;
+        if (n.kind == N_UNO) {
+            if (n.op == UOP_NEG && ca) {  // graph.rs:188-194
+                repl = make_const(is_zero(va) ? va : fr_sub(fr_zero(), va));
+                st.folded++;
+            }
+        } else if (n.kind == N_TRES) {
+            if (ca) {  // TernCond with a constant condition selects one arm (graph.rs:221-225); both arms stay evaluated elsewhere if used
+                repl = is_zero(va) ? c.c : c.b;
+                st.folded++;
+            } else if (c.b == c.c) {
+                repl = c.b;
+                st.folded++;
+            }
+            (void)cb; (void)cc; (void)vc;
+        } else {
+            const uint8_t op = n.op;
+            if (ca && cb) {
+                if (fold_duo(op, va, vb, r)) {
+                    repl = make_const(r);
+                    st.folded++;
+                }
+            } else if (c.a == c.b && (op == OP_EQ || op == OP_LEQ || op == OP_GEQ)) {
+                repl = make_const(one_canon());
+                st.folded++;
+            } else if (c.a == c.b && (op == OP_NEQ || op == OP_LT || op == OP_GT || op == OP_SUB)) {
+                repl = make_const(fr_zero());
+                st.folded++;
+            } else if (op == OP_MUL && ((ca && is_zero(va)) || (cb && is_zero(vb)))) {
+                repl = make_const(fr_zero());
+                st.folded++;
+            } else if (op == OP_MUL && ca && u256_eq(va, one_canon())) {
+                repl = c.b;
+                st.folded++;
+            } else if (op == OP_MUL && cb && u256_eq(vb, one_canon())) {
+                repl = c.a;
+                st.folded++;
+            } else if (op == OP_ADD && ca && is_zero(va)) {
+                repl = c.b;
+                st.folded++;
+            } else if ((op == OP_ADD || op == OP_SUB) && cb && is_zero(vb)) {
+                repl = c.a;
+                st.folded++;
+            } else if (op == OP_DIV && ((ca && is_zero(va)) || (cb && is_zero(vb)))) {  // 0 / x = 0, x / 0 = 0 (graph.rs:109)
+                repl = make_const(fr_zero());
+                st.folded++;
+            } else if (op == OP_DIV && cb && u256_eq(vb, one_canon())) {
+                repl = c.a;
+                st.folded++;
+            }
+        }
+        if (repl == 0xffffffffu) {
+            if (n.kind == N_DUO && commutes(n.op) && c.a > c.b) std::swap(c.a, c.b);
+            const std::pair<uint64_t, uint64_t> key(((uint64_t)c.kind << 56) | ((uint64_t)c.op << 48) | c.a, ((uint64_t)(ar >= 2 ? c.b : 0u) << 32) | (ar >= 3 ? c.c : 0u));
+            auto it = vn.find(key);
+            if (it != vn.end()) {
+                repl = it->second;
+                st.numbered++;
+            } else {
+                repl = (uint32_t)out.size();
+                out.push_back(c);
+                vn.emplace(key, repl);
+            }
+        }
+        m[i] = repl;
+    }
+    // ---- tree shake ------------------------------------------------------------------------------------------------
+    const size_t M = out.size();
+    std::vector<uint8_t> live(M, 0);
+    for (uint32_t w : g.witness_signals) live[m[w]] = 1;
+    for (size_t i = 0; i < M; ++i)
+        if (out[i].kind == N_INPUT || can_fail(out[i])) live[i] = 1;
+    for (size_t i = M; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& n = out[i];
+        if (n.kind == N_UNO || n.kind == N_DUO || n.kind == N_TRES) live[n.a] = 1;
+        if (n.kind == N_DUO || n.kind == N_TRES) live[n.b] = 1;
+        if (n.kind == N_TRES) live[n.c] = 1;
+    }
+    std::vector<uint32_t> pos(M, 0xffffffffu);
+    std::vector<Node> kept;
+    kept.reserve(M);
+    for (size_t i = 0; i < M; ++i)  // constants may sit behind their users (make_const appends): numbered in a first sweep
+        if (live[i] && out[i].kind == N_CONST) {
+            pos[i] = (uint32_t)kept.size();
+            kept.push_back(out[i]);
+        }
+    for (size_t i = 0; i < M; ++i) {
+        if (!live[i] || out[i].kind == N_CONST) continue;
+        Node n = out[i];
+        if (n.kind == N_UNO || n.kind == N_DUO || n.kind == N_TRES) n.a = pos[n.a];
+        if (n.kind == N_DUO || n.kind == N_TRES) n.b = pos[n.b];
+        if (n.kind == N_TRES) n.c = pos[n.c];
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[m[w]];
+    st.nodes_after = kept.size();
+    st.shaken = M - kept.size();
+    g.nodes.swap(kept);
+    if (stats) *stats = st;
+}
+
+}  // namespace cwc

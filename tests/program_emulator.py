@@ -19,7 +19,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I35Q"
+HDR_FMT = "<12I38Q"
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
 COOP_LANES, COOP_MAX_T = 4, 4
@@ -32,7 +32,7 @@ class Blob:
          self.n_witness, self.divider, self.n_div_requests, _res) = h[:12]
         st = h[12:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34])
+                          class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34], n_folded=st[35], n_numbered=st[36], n_shaken=st[37])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 

@@ -171,10 +171,11 @@ def test_graph_compiler_emulated(pkg, tile):
         blob = pe.Blob(g.export_blob(key))
         assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 4 if key & GROUP else 3 if key & TRIPLE else 0)
         n_div = sum(1 for n in nodes if n[0] == "Duo" and n[1] == "Div")
+        gone = blob.stats["n_folded"] + blob.stats["n_numbered"] + blob.stats["n_shaken"]  # (the load-time optimiser may remove divisions)
         if key & (DIVIDER | GROUP | TRIPLE):
-            assert blob.stats["class_nodes"][9] == blob.stats["class_nodes"][10] == n_div and blob.stats["class_nodes"][3] == 0
+            assert n_div - gone <= blob.stats["class_nodes"][9] == blob.stats["class_nodes"][10] <= n_div and blob.stats["class_nodes"][3] == 0
         else:
-            assert blob.stats["class_nodes"][3] == n_div and blob.n_div_requests == 0
+            assert n_div - gone <= blob.stats["class_nodes"][3] <= n_div and blob.n_div_requests == 0
         assert blob.stats["algorithmic_bytes_per_set"] == g.algorithmic_bytes_per_set
         arity = {"Uno": 1, "Duo": 2, "Tres": 3}
         want_bytes = 32 * (sum(arity[n[0]] + 1 for n in nodes if n[0] in arity) + 2 * sum(1 for n in nodes if n[0] == "Input") + 2 * len(wit))
@@ -197,7 +198,8 @@ def test_slot_reuse_keeps_workspace_small(pkg):
     blob = pe.Blob(g.export_blob(64))
     n_values = sum(1 for n in nodes if n[0] != "Const")
     assert blob.n_slots < n_values  # liveness reuse
-    assert blob.n_slots >= len(set(wit))  # witness values stay resident
+    # witness values stay resident (minus the ones the load-time optimiser merged or turned into constants)
+    assert blob.n_slots >= len(set(wit)) - blob.stats["n_folded"] - blob.stats["n_numbered"]
 
 
 def test_cli_usage(pkg):
@@ -280,7 +282,7 @@ def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
 
 
 def test_loader_and_compiler_under_sanitizers(tmp_path):
-    """graph.cc + compile.cc (loader, exact rewrites, scheduler, encoder, blob) under ASan + UBSan on generated graphs,
+    """graph.cc + compile.cc + optimize.cc (loader, load-time optimiser, exact rewrites, scheduler, encoder, blob) under ASan + UBSan on generated graphs,
     a fuzzed DAG, the chain-heavy graphs and a few corrupted files (no GPU involved)."""
     import subprocess
     src = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc")
@@ -288,7 +290,7 @@ def test_loader_and_compiler_under_sanitizers(tmp_path):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-Wno-unknown-pragmas", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
                            os.path.join(ROOT, "tests", "native", "compile_sanitize.cc"),
-                           os.path.join(src, "graph.cc"), os.path.join(src, "compile.cc")])
+                           os.path.join(src, "graph.cc"), os.path.join(src, "compile.cc"), os.path.join(src, "optimize.cc")])
     files = []
     cases = {"gadgets": C.build_gadgets(), "poseidon3": C.build_poseidon(3), "dag": C.build_random_dag(5, n_ops=300),
              "chains": C.build_chain_heavy(3), "bigint": C.build_bigint_class(k=3, rounds=2)}
@@ -355,3 +357,73 @@ def test_schedule_quality_guard(pkg):
     g = pkg.Graph(C.build_sha256(512).to_bin())
     h = struct.unpack_from(pe.HDR_FMT, g.export_blob(1), 0)
     assert h[4] <= 5600
+
+
+def test_load_time_optimiser_is_exact(pkg):
+    """SURVEY 8(f) f2 (optimize.cc; the reference's build-time passes src/graph.rs:358-619 as exact load-time rewrites):
+    every operator applied to CONSTANT operands over a grid of edge values -- folded with eval_fr semantics unless the
+    reference would panic, in which case the node must survive and still report --, same-operand comparisons, the field
+    identities, duplicated subexpressions and dead code.  The optimised program (emulated) against the big-int model on
+    the graph as written, with and without the pass."""
+    from tools.graphgen.builder import Builder
+    M = model.M
+    edge = [0, 1, 2, 5, 253, 254, 255, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
+    duo = ["Mul", "Div", "Add", "Sub", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land", "Lor", "Shl", "Shr", "Bor", "Band", "Bxor"]
+    rnd = random.Random(12)
+    for variant in range(4):
+        b = Builder(dedup_consts=(variant % 2 == 0))
+        x, y = b.input("x")[0], b.input("y")[0]
+        outs = []
+        pairs = [(rnd.choice(edge), rnd.choice(edge)) for _ in range(40)]
+        for op in duo:
+            for va, vb in pairs[:12 if variant else 40]:
+                if variant:  # variants 1..3: only constant operations the reference can evaluate (their VALUES are compared);
+                    try:     # variant 0 keeps the ones that panic there: they must survive the pass and report on every row
+                        model.eval_duo(op, va, vb)
+                    except model.ReferencePanic:
+                        continue
+                outs.append(b.op(op, b.const(va), b.const(vb)))
+            outs.append(b.op(op, x, x))                                     # same operand
+            outs.append(b.op(op, x, b.const(0)))
+            outs.append(b.op(op, b.const(0), x))
+            outs.append(b.op(op, x, b.const(1)))
+            outs.append(b.op(op, b.const(1), y))
+            outs.append(b.op(op, b.op(op, x, y), b.op(op, x, y)))         # duplicated subexpression
+            outs.append(b.op(op, b.op("Add", x, y), b.op("Add", y, x)))     # ... up to commutation
+        for v in edge[:6]:
+            outs.append(b.neg(b.const(v)))
+            outs.append(b.tern(b.const(v), x, y))
+            outs.append(b.tern(x, b.const(v), b.const(v)))
+        dead = b.mul(b.add(x, y), b.const(77))                              # unused: shaken
+        dead_fallible = b.op("Shl", x, y)                                   # unused but can fail: kept, still reports
+        assert dead and dead_fallible
+        for o in outs[::2] if variant == 3 else outs:
+            b.signal(o)
+        data = b.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        compared = 0
+        for env in ({}, {"CWC_NO_LOAD_OPTIMIZE": "1"}):
+            os.environ.update(env)
+            try:
+                g = pkg.Graph(data)
+                blobs = [pe.Blob(g.export_blob(k)) for k in (1, 4, 64)]
+            finally:
+                for k in env:
+                    del os.environ[k]
+            if not env:
+                assert blobs[0].stats["n_folded"] > 100 and blobs[0].stats["n_numbered"] > 10 and blobs[0].stats["n_shaken"] >= 1
+            else:
+                assert blobs[0].stats["n_folded"] == 0
+            for row in ([1, 0, 0], [1, 5, 5], [1, M - 1, 3], [1, rnd.randrange(M), rnd.randrange(M)], [1, 1 << 200, 2], [1, 3, 200]):
+                try:
+                    want = model.evaluate(nodes, row, wit)
+                    panic = False
+                except model.ReferencePanic:
+                    panic = True
+                compared += not panic
+                for blob in blobs:
+                    got, st = pe.run(blob, row)
+                    assert (st != 0) == panic, (variant, row)
+                    if not panic:
+                        assert got == want, (variant, row)
+        assert (compared == 0) if variant == 0 else (compared >= 6), (variant, compared)
