@@ -15,6 +15,7 @@
 // buffer loads two bundles ahead, recent results through a ring (program_dev.h, format v4).  No MFMA: this is
 // 256-bit modular integer arithmetic on v_mad_u64_u32.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "fr_gfx950.hpp"
 #include "program_dev.h"
@@ -571,17 +572,61 @@ __global__ __launch_bounds__(256) void fill_consts_kernel(ProgramDev p, WsTable 
     }
 }
 
-// Block = 64 witness indices x min(T, 4) sets of ONE tile: the waves of a block read the same 128-byte lines of the
-// tile's slots ([slot][half][T][16 B]) at the same time, so each line comes from HBM once instead of once per set.
+// One thread = one witness index of ONE tile, all T sets of it: the thread reads its slot whole ([half][T][16 B] = 32 T
+// contiguous bytes, every 64- or 128-byte line of the tile fetched by exactly one wave instruction stream) and writes T
+// rows; a wave's 64 consecutive indices make 2 KiB runs in every output row.  (Round 1 split the sets of a slot over
+// the waves of a block: twice / four times the read requests for the same lines, 4.6 TB/s; CWC_PACK_V1=1 keeps it for A/B.)
 // MONT: the rows keep the interpreter's Montgomery form (x * 2^256 mod r) for a consumer that computes in it.
-template <bool MONT>
-__global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
-    const uint32_t w = blockIdx.x * 64u + threadIdx.x;
+template <bool MONT, int TT>
+__global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T_) {
+    const uint32_t T = TT ? (uint32_t)TT : T_;
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= p.n_witness) return;
     const uint32_t ref = p.witness_refs[w];
     const uint32_t n_tiles = (batch + T - 1) / T;
     const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
     const uint32_t slot = (ref & REF_CONST) ? (ref & ~REF_CONST) : p.n_const + ref;  // every tile holds the constants too
+    for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+        const char* tb = reinterpret_cast<const char*>(wst.base[tile / wst.tiles_per_chunk]) + (uint64_t)(tile % wst.tiles_per_chunk) * tile_bytes;
+        const uint4* q = reinterpret_cast<const uint4*>(tb) + (size_t)slot * (2 * T);
+        if (TT != 0 && TT <= 4) {  // small tiles: all loads of the slot in flight before the first conversion
+            uint4 lo[TT ? TT : 1], hi[TT ? TT : 1];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                lo[t] = q[t];
+                hi[t] = q[TT + t];
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const uint32_t set = tile * TT + t;
+                if (set >= batch) break;
+                const Fr c = MONT ? fr_from_u4(lo[t], hi[t]) : fr_from_mont(fr_from_u4(lo[t], hi[t]));
+                uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
+                o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+                o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
+            }
+        } else {
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint32_t set = tile * T + t;
+                if (set >= batch) break;
+                const Fr c = MONT ? fr_from_u4(q[t], q[T + t]) : fr_from_mont(fr_from_u4(q[t], q[T + t]));
+                uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
+                o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+                o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
+            }
+        }
+    }
+}
+
+// (round-1 shape, kept for A/B: block = 64 witness indices x min(T, 4) sets of one tile)
+template <bool MONT>
+__global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
+    const uint32_t w = blockIdx.x * 64u + threadIdx.x;
+    if (w >= p.n_witness) return;
+    const uint32_t ref = p.witness_refs[w];
+    const uint32_t n_tiles = (batch + T - 1) / T;
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
+    const uint32_t slot = (ref & REF_CONST) ? (ref & ~REF_CONST) : p.n_const + ref;
     for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
         const char* tb = reinterpret_cast<const char*>(wst.base[tile / wst.tiles_per_chunk]) + (uint64_t)(tile % wst.tiles_per_chunk) * tile_bytes;
         const uint4* q0 = reinterpret_cast<const uint4*>(tb) + (size_t)slot * (2 * T);
@@ -645,9 +690,21 @@ hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& ws
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream, bool montgomery) {
     if (p.n_witness == 0 || batch == 0) return hipSuccess;
     const uint32_t n_tiles = (batch + T - 1) / T;
-    dim3 grid((p.n_witness + 63) / 64, n_tiles < 32768u ? n_tiles : 32768u), block(64, T < 4 ? T : 4);
-    if (montgomery) pack_kernel<true><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
-    else pack_kernel<false><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
+    static const bool v1 = getenv("CWC_PACK_V1") != nullptr;
+    if (v1) {
+        dim3 grid((p.n_witness + 63) / 64, n_tiles < 32768u ? n_tiles : 32768u), block(64, T < 4 ? T : 4);
+        if (montgomery) pack_kernel_v1<true><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
+        else pack_kernel_v1<false><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
+        return hipGetLastError();
+    }
+    dim3 grid((p.n_witness + 255) / 256, n_tiles < 32768u ? n_tiles : 32768u), block(256);
+#define CWC_PACK(MM, TT) pack_kernel<MM, TT><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T)
+    if (montgomery) {
+        if (T == 1) CWC_PACK(true, 1); else if (T == 2) CWC_PACK(true, 2); else if (T == 4) CWC_PACK(true, 4); else CWC_PACK(true, 0);
+    } else {
+        if (T == 1) CWC_PACK(false, 1); else if (T == 2) CWC_PACK(false, 2); else if (T == 4) CWC_PACK(false, 4); else CWC_PACK(false, 0);
+    }
+#undef CWC_PACK
     return hipGetLastError();
 }
 
