@@ -143,6 +143,11 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 17
 // the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
 // first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
 // narrow linear steps in between) loses 3 % with it and keeps the measured ratio.
+// Tiles of one or two input sets run the critical chain's multiplications in narrow (four-lane) bundles: its steps cost
+// what a narrow bundle and a linear bundle cost (1 306 : 706 cycles in the product kernel = 26 : 14; measured best of
+// 26..40 : 14..24 on the authV2-class graph: 1024 sets 13.27 -> 12.19 ms, 256 sets 12.27 -> 10.52 ms; wider tiles, whose
+// multiplication bundles stay full-width, keep the table above: 8192 sets 32.6 ms with either, 33.4 ms with this one).
+static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 16, 1470, 25, 100, 110, 175, 38, 22, 22, 26};
 static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26};
 // What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
@@ -322,11 +327,11 @@ double program_wave_cycles_mul_div(const Program& p) {
 
 // When a multiplication step becomes a narrow (four lanes per product) bundle: `fill` or more ready multiplications make
 // a full-width bundle instead (it costs the same with 10 or 32 nodes); otherwise a narrow one if the multiplications
-// within `slack` (scheduler cost units, a multiplication level is 47) of the most urgent ready node fit it.  The rest
-// stays ready.  fill = 0: never narrow.
+// within `slack_levels` multiplication levels (in the scheduler's cost units) of the most urgent ready node fit it.  The
+// rest stays ready.  fill = 0: never narrow.
 struct CoopPolicy {
     uint32_t fill;
-    uint64_t slack;
+    uint32_t slack_levels;  // ~0u: everything ready counts as urgent
 };
 static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err);
 
@@ -336,9 +341,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
 // policies are not fitted to one graph, the cost model picks per graph and tile width.
 bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err) {
     const uint32_t G = T ? 64 / T : 1;
-    CoopPolicy base{G, ~0ull};  // narrow whenever everything ready fits
+    CoopPolicy base{G, ~0u};  // narrow whenever everything ready fits
     if (const char* e = getenv("CWC_COOP_FILL")) base.fill = (uint32_t)atol(e);
-    if (const char* e = getenv("CWC_COOP_SLACK")) base.slack = (uint64_t)atol(e);
+    if (const char* e = getenv("CWC_COOP_SLACK")) base.slack_levels = (uint32_t)atol(e);
     const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
     if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
     if (!compile_variant(g, T, divider, true, base, out, err)) return false;
@@ -355,7 +360,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
         }
     }
     if (base.fill == 0 || forced || g.nodes.size() > 2000000) return true;  // (huge graphs: one schedule, compile time counts)
-    const CoopPolicy more[] = {{0, 0}, {std::max(12u, G * 3 / 8), 0}, {G / 2, 94}, {G * 5 / 8, 94}};
+    const CoopPolicy more[] = {{0, 0}, {std::max(12u, G * 3 / 8), 0}, {G / 2, 2}, {G * 5 / 8, 2}};
     for (const CoopPolicy& pol : more) {
         Program alt;
         std::string err2;
@@ -477,7 +482,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         phase("bit-extract fusion");
     }
     // scheduling weights by class: linear-heavy graphs (more Add / Sub than Mul nodes) take the heavier linear weight
-    const uint32_t* class_cost = kClassCost;
+    const uint32_t* class_cost = policy.fill && T <= 2 ? kClassCostNarrow : kClassCost;
     {
         size_t n_lin = 0, n_mul = 0;
         for (const Node& n : g.nodes) {
@@ -485,6 +490,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             n_mul += n.kind == N_DUO && n.op == OP_MUL;
         }
         if (n_lin > n_mul && !getenv("CWC_NO_LIN_HEAVY_WEIGHTS")) class_cost = kClassCostLinHeavy;
+    }
+    uint32_t cost_override[C_COUNT];
+    if (getenv("CWC_SCHED_LIN_COST") || getenv("CWC_SCHED_MUL_COST")) {  // (A/B knobs for the priority weights)
+        for (int c = 0; c < (int)C_COUNT; ++c) cost_override[c] = class_cost[c];
+        if (const char* e = getenv("CWC_SCHED_LIN_COST")) cost_override[C_LIN] = (uint32_t)atoi(e);
+        if (const char* e = getenv("CWC_SCHED_MUL_COST")) cost_override[C_MUL] = (uint32_t)atoi(e);
+        class_cost = cost_override;
     }
     if (G > 1 && !getenv("CWC_NO_TREE_REDUCTION")) {
         // whole chains at T = 1 (small batches: depth is everything); at most 8 leaves per tree otherwise, where the
@@ -634,7 +646,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         // bundle is compiled for the lane-cooperative multiplier (about half the cycles of a full-width multiplication
         // bundle); linear nodes cannot ride in it.
         const size_t coop_cap = policy.fill ? coop_nodes(T) : 0;
-        const uint64_t coop_slack = policy.slack;
+        const uint64_t coop_slack = policy.slack_levels == ~0u ? ~0ull : (uint64_t)policy.slack_levels * class_cost[C_MUL];
         const size_t coop_fill = policy.fill;
         auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false) {
             const uint32_t b = (uint32_t)bundle_start.size();
