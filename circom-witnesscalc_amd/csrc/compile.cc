@@ -7,9 +7,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <unordered_map>
 
+#include "flat_map.hpp"
 #include "program.hpp"
 
 namespace cwc {
@@ -164,6 +166,7 @@ static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 17
 // node) needs them; common subexpressions are shared; nodes that end up unused are dropped.
 // Only Add/Mul nodes are touched, so every operation that can fail (graph.rs:634, :686-716) survives unchanged.
 static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost) {
+    // <functional> comparators below
     const size_t N = g.nodes.size();
     Graph h;
     h.const_values = g.const_values;
@@ -171,19 +174,12 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
     std::vector<uint64_t> rt;                 // earliest finish time of each new node (unbounded width)
     rt.reserve(N + N / 4);
     h.nodes.reserve(N + N / 4);
-    struct KeyHash {
-        size_t operator()(const uint64_t& k) const { return (size_t)(k * 0x9E3779B97F4A7C15ull >> 16); }
-    };
-    std::unordered_map<uint64_t, uint32_t, KeyHash> vn[2];  // value numbering of Add (0) / Mul (1) nodes by operand pair
-    {
-        size_t n_add = 0, n_mul = 0;
-        for (const Node& n : g.nodes) {
-            n_add += n.kind == N_DUO && n.op == OP_ADD;
-            n_mul += n.kind == N_DUO && n.op == OP_MUL;
-        }
-        vn[0].reserve(n_add + n_add / 4);
-        vn[1].reserve(n_mul + n_mul / 4);
+    size_t n_add = 0, n_mul = 0;
+    for (const Node& n : g.nodes) {
+        n_add += n.kind == N_DUO && n.op == OP_ADD;
+        n_mul += n.kind == N_DUO && n.op == OP_MUL;
     }
+    FlatMap128 vn[2] = {FlatMap128(n_add + n_add / 4), FlatMap128(n_mul + n_mul / 4)};  // value numbering of Add (0) / Mul (1) nodes by operand pair
     auto emit = [&](const Node& n, uint64_t t) -> uint32_t {
         h.nodes.push_back(n);
         rt.push_back(t);
@@ -196,13 +192,43 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
         if (x > y) std::swap(x, y);
         const uint64_t key = ((uint64_t)x << 32) | y;
         auto& table = vn[op == OP_MUL];
-        auto it = table.find(key);
-        if (it != table.end()) return it->second;
+        uint32_t idx;
+        if (table.find(key, 0, &idx)) return idx;
         const uint64_t cost = class_cost[op == OP_MUL ? C_MUL : C_LIN];
-        const uint32_t idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
-        table.emplace(key, idx);
+        idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
+        table.find_or_insert(key, 0, idx, nullptr);
         return idx;
     };
+    // A node inside a chain -- its one user is a node of the same operation and it is no witness element -- needs no tree
+    // of its own: the chain's end is rebuilt over the leaves and the inner node dies unless something else reads it.
+    // (Without this every node of a chain of length L flattened up to kMaxLeaves leaves: most of the compile time of
+    // multi-million-node graphs.)
+    std::vector<uint8_t> inner(N, 0);
+    {
+        std::vector<uint32_t> n_users(N, 0), same_op_users(N, 0);
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            const int ar = arity_of(n);
+            const uint32_t ops[3] = {n.a, n.b, n.c};
+            for (int q = 0; q < ar; ++q) {
+                n_users[ops[q]]++;
+                const Node& o = g.nodes[ops[q]];
+                if (n.kind == N_DUO && o.kind == N_DUO && o.op == n.op && (n.op == OP_ADD || n.op == OP_MUL)) same_op_users[ops[q]]++;
+            }
+        }
+        for (uint32_t w : g.witness_signals) n_users[w] += 2;
+        // (only where whole chains are flattened -- T = 1 -- : with the 8-leaf trees of wider tiles the inner nodes' own
+        // trees are what keeps a long chain balanced)
+        // Used for multi-million-node graphs only, where the compile time counts: the trees come out the same but are
+        // emitted in another order, and the list scheduler then packs the bigint-class graph into 12 % more linear bundles
+        // (1 M nodes: rewrites 1.17 -> 0.27 s; CWC_TREE_INNER_SKIP=1 / 0 forces either way).
+        const char* force = getenv("CWC_TREE_INNER_SKIP");
+        if (kMaxLeaves >= 64 && (force ? atoi(force) != 0 : N > 2000000)) {
+            for (size_t i = 0; i < N; ++i) inner[i] = n_users[i] == 1 && same_op_users[i] == 1;
+            kMaxLeaves = 1u << 16;
+        }
+    }
+    std::vector<uint8_t> inner_new;  // new-graph nodes that are such inner chain nodes
     std::vector<uint32_t> leaves;
     typedef std::pair<uint64_t, uint32_t> LeafKey;  // (ready time, ~position in `leaves`)
     std::vector<LeafKey> latest;
@@ -224,6 +250,12 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
             m[i] = emit(c, t + class_cost[class_of(n)]);
             continue;
         }
+        if (inner[i]) {
+            m[i] = combine(n.op, c.a, c.b);
+            if (inner_new.size() < h.nodes.size()) inner_new.resize(h.nodes.size() + h.nodes.size() / 2 + 16, 0);
+            inner_new[m[i]] = 1;
+            continue;
+        }
         const uint64_t cost = class_cost[n.op == OP_MUL ? C_MUL : C_LIN];
         const uint64_t direct = std::max(rt[c.a], rt[c.b]) + cost;
         // flatten: keep opening the latest-ready leaf while it is a node of the same operation
@@ -231,11 +263,22 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
         leaves.clear();
         leaves.push_back(c.a);
         leaves.push_back(c.b);
-        latest.clear();
-        latest.push_back(LeafKey(rt[c.a], ~0u));
-        latest.push_back(LeafKey(rt[c.b], ~1u));
-        std::make_heap(latest.begin(), latest.end());
         bool opened = false;
+        // the chain's own inner nodes (emitted unbalanced above) are opened whatever their ready time ...
+        for (size_t q = 0; q < leaves.size() && leaves.size() < kMaxLeaves;) {
+            const uint32_t L = leaves[q];
+            if (L < inner_new.size() && inner_new[L] && is_ac(L, n.op)) {
+                leaves[q] = h.nodes[L].a;
+                leaves.push_back(h.nodes[L].b);
+                opened = true;
+            } else {
+                ++q;
+            }
+        }
+        // ... then the latest-ready leaf while it is a node of the same operation
+        latest.clear();
+        for (size_t q = 0; q < leaves.size(); ++q) latest.push_back(LeafKey(rt[leaves[q]], ~(uint32_t)q));
+        std::make_heap(latest.begin(), latest.end());
         while (leaves.size() < kMaxLeaves) {
             const uint32_t worst = ~latest.front().second;
             const uint32_t L = leaves[worst];
@@ -253,22 +296,32 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
         uint32_t result = 0xffffffffu;
         if (opened) {
             // would the rebuilt tree finish earlier?  (computed on times only, nothing is emitted yet)
-            work.clear();
-            for (uint32_t L : leaves) work.emplace_back(rt[L], L);
-            std::sort(work.begin(), work.end());
+            // (min-heaps on (ready time, node): the two earliest are combined until one is left)
             times.clear();
-            for (auto& w : work) times.push_back(w.first);
-            while (times.size() > 1) {  // combine the two earliest
-                const uint64_t t = std::max(times[0], times[1]) + cost;
-                times.erase(times.begin(), times.begin() + 2);
-                times.insert(std::lower_bound(times.begin(), times.end(), t), t);
+            for (uint32_t L : leaves) times.push_back(rt[L]);
+            std::make_heap(times.begin(), times.end(), std::greater<uint64_t>());
+            while (times.size() > 1) {
+                std::pop_heap(times.begin(), times.end(), std::greater<uint64_t>());
+                const uint64_t t0 = times.back();
+                times.pop_back();
+                std::pop_heap(times.begin(), times.end(), std::greater<uint64_t>());
+                const uint64_t t1 = times.back();
+                times.back() = std::max(t0, t1) + cost;
+                std::push_heap(times.begin(), times.end(), std::greater<uint64_t>());
             }
             if (times[0] < direct) {
+                typedef std::pair<uint64_t, uint32_t> W;
+                work.clear();
+                for (uint32_t L : leaves) work.emplace_back(rt[L], L);
+                std::make_heap(work.begin(), work.end(), std::greater<W>());
                 while (work.size() > 1) {
-                    const uint32_t idx = combine(n.op, work[0].second, work[1].second);
-                    work.erase(work.begin(), work.begin() + 2);
-                    const std::pair<uint64_t, uint32_t> e(rt[idx], idx);
-                    work.insert(std::lower_bound(work.begin(), work.end(), e), e);
+                    std::pop_heap(work.begin(), work.end(), std::greater<W>());
+                    const uint32_t x = work.back().second;
+                    work.pop_back();
+                    std::pop_heap(work.begin(), work.end(), std::greater<W>());
+                    const uint32_t idx = combine(n.op, x, work.back().second);
+                    work.back() = W(rt[idx], idx);
+                    std::push_heap(work.begin(), work.end(), std::greater<W>());
                 }
                 result = work[0].second;
             }
@@ -333,7 +386,23 @@ struct CoopPolicy {
     uint32_t fill;
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
 };
-static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err);
+// The rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) depends on the fusion switch and on
+// the weight table only: the schedule variants of one compile_program call share it instead of redoing it.
+struct RewriteCache {
+    struct Entry {
+        bool bit_fusion;
+        const uint32_t* table;  // kClassCost / kClassCostNarrow (before the linear-heavy switch and the A/B overrides)
+        Graph g;
+        ProgramStats st;
+        const uint32_t* class_cost;
+    };
+    std::vector<Entry> entries;
+};
+static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err,
+                            RewriteCache* cache = nullptr, bool probe_only = false);
+
+// Validation and statistics of a loaded graph without compiling a program (what gwb_graph_load needs).
+bool probe_graph(const Graph& g, Program& out, std::string& err) { return compile_variant(g, 64, 0, false, CoopPolicy{0, 0}, out, err, nullptr, true); }
 
 // The list scheduler is a heuristic, and exact rewrites and the narrow-bundle policy shift how the chains of a graph line
 // up in bundles: the program is compiled with and without the bit-extract fusion, then under a few narrow-bundle
@@ -346,7 +415,8 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     if (const char* e = getenv("CWC_COOP_SLACK")) base.slack_levels = (uint32_t)atol(e);
     const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
     if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
-    if (!compile_variant(g, T, divider, true, base, out, err)) return false;
+    RewriteCache cache;
+    if (!compile_variant(g, T, divider, true, base, out, err, &cache)) return false;
     if (getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
     // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
     // authV2-class graph, and slower for multi-million-node graphs)
@@ -354,7 +424,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     if (out.stats.n_bitx_nodes != 0 && !getenv("CWC_NO_BIT_FUSION")) {
         Program alt;
         std::string err2;
-        if (compile_variant(g, T, divider, false, base, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) {
+        if (compile_variant(g, T, divider, false, base, alt, err2, &cache) && program_wave_cycles(alt) < program_wave_cycles(out)) {
             out = std::move(alt);
             fusion = false;
         }
@@ -364,18 +434,24 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     for (const CoopPolicy& pol : more) {
         Program alt;
         std::string err2;
-        if (compile_variant(g, T, divider, fusion, pol, alt, err2) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+        if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
     }
     return true;
 }
 
-static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err) {
+static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err,
+                            RewriteCache* cache, bool probe_only) {
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
     }
+    const uint32_t* weight_table = policy.fill && T <= 2 ? kClassCostNarrow : kClassCost;
+    const RewriteCache::Entry* hit = nullptr;
+    if (cache)
+        for (const auto& e : cache->entries)
+            if (e.bit_fusion == bit_fusion && e.table == weight_table) hit = &e;
     // validate operand order on the graph as loaded, then work on a rewritten copy
-    for (size_t i = 0; i < g_in.nodes.size(); ++i) {
+    for (size_t i = 0; !hit && i < g_in.nodes.size(); ++i) {
         const Node& n = g_in.nodes[i];
         const int ar = arity_of(n);
         if ((ar >= 1 && n.a >= i) || (ar >= 2 && n.b >= i) || (ar >= 3 && n.c >= i)) {
@@ -387,7 +463,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             return false;
         }
     }
-    Graph g = g_in;
+    Graph g = hit ? hit->g : g_in;
     // CWC_DEBUG_COMPILE_TIMES=1: seconds per phase on stderr
     const bool phase_times = getenv("CWC_DEBUG_COMPILE_TIMES") != nullptr;
     auto t_phase = std::chrono::steady_clock::now();
@@ -397,7 +473,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         fprintf(stderr, "compile T=%u: %-28s %.3f s\n", T, name, std::chrono::duration<double>(now - t_phase).count());
         t_phase = now;
     };
-    rewrite_pow2_divisions(g);
+    if (!hit) rewrite_pow2_divisions(g);
     size_t N = g.nodes.size();
     const uint32_t G = 64 / T;
     if (divider != 0 && divider != 1 && divider != 3 && divider != 4) {
@@ -414,13 +490,19 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     st.n_witness = g.witness_signals.size();
 
     // ---- validate (assert_valid, reference src/graph.rs:343-356; evaluate() itself does not check) ----
-    const size_t n_in_buf = inputs_buffer_size(g);
+    const size_t n_in_buf = inputs_buffer_size(g_in);
     // (the reference sizes the buffer from the leading Input nodes, lib.rs:138-152, and panics on anything beyond; here
     // the buffer covers every Input index and every signal of the input map -- within a sane bound: rows are n x 32 bytes)
     if (n_in_buf > (1u << 27)) {
         err = "inputs buffer of " + std::to_string(n_in_buf) + " elements is too large (an input map entry or Input index beyond 2^27)";
         return false;
     }
+    const uint32_t* class_cost = nullptr;
+    uint32_t cost_override[C_COUNT];
+    if (hit) {
+        st = hit->st;
+        class_cost = hit->class_cost;
+    } else {
     uint64_t arity_sum = 0;
     for (size_t i = 0; i < N; ++i) {
         const Node& n = g.nodes[i];
@@ -464,6 +546,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     st.depth = depth;
 
     phase("levels");
+    if (probe_only) {
+        out.n_inputs = (uint32_t)n_in_buf;
+        out.n_witness = (uint32_t)g.witness_signals.size();
+        return true;
+    }
     // ---- load-time re-optimiser (the statistics above describe the graph as loaded) ----
     if (!getenv("CWC_NO_LOAD_OPTIMIZE")) {
         OptimizeStats os;
@@ -482,7 +569,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         phase("bit-extract fusion");
     }
     // scheduling weights by class: linear-heavy graphs (more Add / Sub than Mul nodes) take the heavier linear weight
-    const uint32_t* class_cost = policy.fill && T <= 2 ? kClassCostNarrow : kClassCost;
+    class_cost = weight_table;
     {
         size_t n_lin = 0, n_mul = 0;
         for (const Node& n : g.nodes) {
@@ -491,7 +578,6 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         if (n_lin > n_mul && !getenv("CWC_NO_LIN_HEAVY_WEIGHTS")) class_cost = kClassCostLinHeavy;
     }
-    uint32_t cost_override[C_COUNT];
     if (getenv("CWC_SCHED_LIN_COST") || getenv("CWC_SCHED_MUL_COST")) {  // (A/B knobs for the priority weights)
         for (int c = 0; c < (int)C_COUNT; ++c) cost_override[c] = class_cost[c];
         if (const char* e = getenv("CWC_SCHED_LIN_COST")) cost_override[C_LIN] = (uint32_t)atoi(e);
@@ -507,6 +593,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         N = g.nodes.size();
     }
     for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
+    if (cache && class_cost != cost_override) cache->entries.push_back(RewriteCache::Entry{bit_fusion, weight_table, g, st, class_cost});
+    }  // (!hit)
 
     phase("rewrites");
     // ---- constants -> table (Montgomery form), node -> ref ----

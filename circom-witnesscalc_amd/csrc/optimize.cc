@@ -20,6 +20,7 @@
 
 #include <unordered_map>
 
+#include "flat_map.hpp"
 #include "graph.hpp"
 
 namespace cwc {
@@ -112,11 +113,6 @@ bool commutes(uint8_t op) {
     return op == OP_MUL || op == OP_ADD || op == OP_EQ || op == OP_NEQ || op == OP_LAND || op == OP_LOR || op == OP_BOR || op == OP_BAND || op == OP_BXOR;
 }
 
-struct KeyHash {
-    size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
-        return (size_t)((k.first * 0x9E3779B97F4A7C15ull) ^ (k.second * 0xC2B2AE3D27D4EB4Full) ^ (k.first >> 29));
-    }
-};
 struct FrHash {
     size_t operator()(const Fr& x) const {
         uint64_t h = 1469598103934665603ull;
@@ -138,7 +134,7 @@ void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
     out.reserve(N);
     std::vector<uint32_t> m(N, 0xffffffffu);  // old node -> new node
     std::unordered_map<Fr, uint32_t, FrHash, FrEq> const_node;  // canonical value -> new constant node
-    std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, KeyHash> vn;
+    FlatMap128 vn(g.n_op ? g.n_op : N);
     OptimizeStats st;
     st.nodes_before = N;
     auto make_const = [&](const Fr& v) -> uint32_t {
@@ -237,16 +233,11 @@ void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
         }
         if (repl == 0xffffffffu) {
             if (n.kind == N_DUO && commutes(n.op) && c.a > c.b) std::swap(c.a, c.b);
-            const std::pair<uint64_t, uint64_t> key(((uint64_t)c.kind << 56) | ((uint64_t)c.op << 48) | c.a, ((uint64_t)(ar >= 2 ? c.b : 0u) << 32) | (ar >= 3 ? c.c : 0u));
-            auto it = vn.find(key);
-            if (it != vn.end()) {
-                repl = it->second;
-                st.numbered++;
-            } else {
-                repl = (uint32_t)out.size();
-                out.push_back(c);
-                vn.emplace(key, repl);
-            }
+            bool fresh = false;
+            repl = vn.find_or_insert(((uint64_t)c.kind << 56) | ((uint64_t)c.op << 48) | c.a, ((uint64_t)(ar >= 2 ? c.b : 0u) << 32) | (ar >= 3 ? c.c : 0u),
+                                     (uint32_t)out.size(), &fresh);
+            if (fresh) out.push_back(c);
+            else st.numbered++;
         }
         m[i] = repl;
     }

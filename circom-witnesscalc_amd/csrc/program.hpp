@@ -47,6 +47,8 @@ struct Program {
 // (power of two, 1..64); divider = W > 0 compiles divisions for a divider wave shared by W interpreter waves (W = 1 or
 // 4, T < 64 only).
 bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err);
+// Validation and statistics of a loaded graph without compiling a program: out.stats, out.n_inputs, out.n_witness.
+bool probe_graph(const Graph& g, Program& out, std::string& err);
 // "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER | KEY_GROUP
 static const uint32_t KEY_DIVIDER = 0x100u;  // one divider wave per interpreter wave
 static const uint32_t KEY_GROUP = 0x200u;    // one divider wave per four interpreter waves

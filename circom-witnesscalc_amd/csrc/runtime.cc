@@ -605,9 +605,9 @@ int load_graph(const void* data, size_t len, gwb_graph** out, std::string& err) 
     std::unique_ptr<gwb_graph> g(new gwb_graph());
     if (!deserialize_witnesscalc_graph((const uint8_t*)data, len, g->graph, err)) return 1;
     g->has_graph = true;
-    // validate by compiling the widest program's metadata (cheap) -- catches bad indices / Pow / Id early
+    // validation + statistics (bad indices / Pow / Id are caught here); programs are compiled when a batch size is known
     Program probe;
-    if (!compile_program(g->graph, 64, 0, probe, err)) return 1;
+    if (!probe_graph(g->graph, probe, err)) return 1;
     g->stats = probe.stats;
     g->n_inputs = probe.n_inputs;
     g->n_witness = probe.n_witness;

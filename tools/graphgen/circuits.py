@@ -531,18 +531,22 @@ AUTHV2_INPUTS = [  # key schema of test_circuits/circuit9_authV2_inputs.json (21
     ("gistMtpAuxHv", 1), ("gistMtpNoAux", 1)]
 
 
-def build_authv2_class(scale=1.0):
+def build_authv2_class(scale=1.0, levels=None, ladder_bits=None):
     """authV2-class composite (BASELINE configs 2 and 4): the reference's authV2 input schema;
     three SMT verifiers (40/40/64 levels, one Poseidon(2) per level + leaf hashes), claim hashing,
     state check, and an EdDSA-Poseidon-shaped block (Num2Bits(254), CompConstant, Poseidon(5),
     three BabyDbl, EscalarMulAny over 254 bits = 508 chained Divs, EscalarMulFix over 253 bits).
-    `scale` < 1 shrinks level counts / scalar widths proportionally (for fast tests)."""
+    `scale` < 1 shrinks level counts / scalar widths proportionally (for fast tests); `levels` = (claims, rev, gist) tree
+    depths (at most 40, 40, 64: the input schema) and `ladder_bits` = width of the scalar in EscalarMulAny give structurally
+    different members of the class (tools/gpu_robustness.py)."""
     b = Builder()
     I = {name: b.input(name, n) for name, n in AUTHV2_INPUTS}
     g = lambda k: I[k][0]
     one, zero = b.const(1), b.const(0)
     lv = lambda n: max(3, int(round(n * scale)))
     nb = lambda n: max(9, int(round(n * scale)))
+    l_claims, l_rev, l_gist = levels if levels else (lv(40), lv(40), lv(64))
+    assert l_claims <= 40 and l_rev <= 40 and l_gist <= 64
     # claim hashes: hi = Poseidon(4)(slots 0..3), hv = Poseidon(4)(slots 4..7), hash = Poseidon(2)
     claim = I["authClaim"]
     hi = poseidon(b, claim[0:4])
@@ -552,17 +556,17 @@ def build_authv2_class(scale=1.0):
     c0bits = num2bits(b, claim[0], nb(254))
     b.signal(b.mul(c0bits[3 % len(c0bits)], c0bits[5 % len(c0bits)]))
     # auth claim inclusion in claims tree
-    smt_verifier(b, lv(40), one, g("claimsTreeRoot"), I["authClaimIncMtp"][:lv(40)], zero, zero, zero, hi, hv, zero)
+    smt_verifier(b, l_claims, one, g("claimsTreeRoot"), I["authClaimIncMtp"][:l_claims], zero, zero, zero, hi, hv, zero)
     # non-revocation (non-inclusion) in rev tree
     rev_nonce = bits2num(b, c0bits[:min(64, len(c0bits))])
-    smt_verifier(b, lv(40), one, g("revTreeRoot"), I["authClaimNonRevMtp"][:lv(40)], g("authClaimNonRevMtpAuxHi"),
+    smt_verifier(b, l_rev, one, g("revTreeRoot"), I["authClaimNonRevMtp"][:l_rev], g("authClaimNonRevMtpAuxHi"),
                  g("authClaimNonRevMtpAuxHv"), g("authClaimNonRevMtpNoAux"), rev_nonce, zero, one)
     # state = Poseidon(3)(claimsTreeRoot, revTreeRoot, rootsTreeRoot); compare with `state`
     st = poseidon(b, [g("claimsTreeRoot"), g("revTreeRoot"), g("rootsTreeRoot")])
     b.signal(is_equal(b, st, g("state")))
     # GIST inclusion / non-inclusion (64 levels), key = Poseidon(1)(genesisID)
     gkey = poseidon(b, [g("genesisID")])
-    smt_verifier(b, lv(64), one, g("gistRoot"), I["gistMtp"][:lv(64)], g("gistMtpAuxHi"), g("gistMtpAuxHv"),
+    smt_verifier(b, l_gist, one, g("gistRoot"), I["gistMtp"][:l_gist], g("gistMtpAuxHi"), g("gistMtpAuxHv"),
                  g("gistMtpNoAux"), gkey, g("state"), b.signal(is_zero(b, g("profileNonce"))))
     # profile id: Poseidon(2)(genesisID, nonce) selected by IsZero(nonce)
     prof = poseidon(b, [g("genesisID"), g("profileNonce")])
@@ -583,7 +587,7 @@ def build_authv2_class(scale=1.0):
     # Edwards -> Montgomery: u = (1+y)/(1-y), v = u/x
     u = b.signal(b.div(b.add(one, d3[1]), b.sub(one, d3[1])))
     v = b.signal(b.div(u, d3[0]))
-    right = scalar_mul_any(b, hbits, (u, v))
+    right = scalar_mul_any(b, hbits[:ladder_bits] if ladder_bits else hbits, (u, v))
     rx = b.signal(b.div(right[0], right[1]))
     ry = b.signal(b.div(b.sub(right[0], one), b.add(right[0], one)))
     right2 = baby_add(b, (g("challengeSignatureR8x"), g("challengeSignatureR8y")), (rx, ry))
