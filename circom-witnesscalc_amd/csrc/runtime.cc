@@ -1,6 +1,7 @@
 // C-ABI runtime: gw_calc_witness (drop-in for reference src/lib.rs:44-111) and the additive batch API
 // (include/graph_witness_batch.h).  Everything numeric runs in the HIP kernels of kernels.hip; this file
 // parses, compiles, moves buffers and launches.  There is deliberately no CPU evaluation path.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -9,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <algorithm>
 #include <atomic>
 #include <deque>
 #include <future>
@@ -262,7 +264,19 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
         const uint32_t key = (uint32_t)atoi(e), t = key & ~KEY_MODE_MASK;
         if (t >= 1 && t <= 64 && !(t & (t - 1))) return key;
     }
-    const uint32_t rule = gwb_pick_tile_width(batch);
+    uint32_t rule = gwb_pick_tile_width(batch);
+    // Deep graphs: a program is one header word, G records and G third-operand words per bundle, and a bundle per
+    // dependency level at least -- 1 KiB + 260 B per bundle at T = 1 (2 GB for the 10.5 M-node bigint-class graph of
+    // BASELINE config 5, depth 1.29 M).  Small batches fill the same number of SIMDs whatever the tile width (every tile
+    // is one wave), so the width is raised until the program stream fits CWC_PROGRAM_MB (default 768): 0.5 GB at T = 4.
+    uint32_t min_t = 1;
+    {
+        double budget = 768.0;
+        if (const char* e = getenv("CWC_PROGRAM_MB")) budget = atof(e);
+        const double per_bundle_t1 = 4.0 + 64.0 * 20.0;
+        while (min_t < 16 && (double)g->stats.depth * 1.25 * (4.0 + (per_bundle_t1 - 4.0) / min_t) > budget * 1048576.0) min_t *= 2;
+        if ((rule & ~KEY_MODE_MASK) < min_t) rule = min_t | ((rule & KEY_MODE_MASK) && min_t < 64 ? (rule & KEY_MODE_MASK) : 0u);
+    }
     // tiny batches (the single-shot entry point): one tile either way, not worth compiling candidates
     if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph || batch < 64) return rule;
     auto hit = g->chosen.find(batch);
@@ -275,7 +289,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     uint32_t best = rule;
     double best_cost = -1;
     std::vector<uint32_t> keys;
-    for (uint32_t t = t0 >= 4 ? t0 / 4 : 1; t <= t0 * 2 && t <= 32; t *= 2)
+    for (uint32_t t = std::max(min_t, t0 >= 4 ? t0 / 4 : 1u); t <= t0 * 2 && t <= 32; t *= 2)
         for (uint32_t mode : {0u, KEY_DIVIDER, KEY_TRIPLE, KEY_GROUP}) {
             const size_t tiles = (batch + t - 1) / t;
             if (tiles > 4 * 2048) continue;
@@ -1028,6 +1042,78 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     *out = g.release();
     set_status(status, OK, "");
     return 0;
+    });
+}
+
+// One collective in the whole path: the compiled program of rank `root` goes to every GPU of the communicator over RCCL
+// (xGMI inside a node).  RCCL's entry points are resolved in the running process (the host program that owns the
+// communicator has RCCL loaded; this library does not link it).
+int gwb_graph_broadcast(gwb_graph_t* g, uint32_t tile_width, size_t batch_per_rank, int root, int rank, void* nccl_comm, void* hip_stream,
+                        gwb_graph_t** out, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
+    if (!out || !nccl_comm) return fail(status, "null argument");
+    if (rank == root && !g) return fail(status, "the root rank needs a loaded graph");
+    typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*errstr_fn)(int);
+    bcast_fn bcast = (bcast_fn)dlsym(RTLD_DEFAULT, "ncclBroadcast");
+    if (!bcast) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) bcast = (bcast_fn)dlsym(h, "ncclBroadcast");
+    }
+    if (!bcast) return fail(status, "ncclBroadcast not found: RCCL is not loaded in this process");
+    errstr_fn errstr = (errstr_fn)dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+    std::string err = check_device();
+    if (!err.empty()) return fail(status, err);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    void* blob = nullptr;
+    size_t blob_len = 0;
+    if (rank == root) {
+        if (!tile_width) {
+            if (!batch_per_rank) return fail(status, "tile_width = 0 needs the shard size");
+            tile_width = gwb_graph_pick_tile_width(g, batch_per_rank);
+            if (!tile_width) return fail(status, "no program for that batch size");
+        }
+        gw_status_t st2{OK, nullptr};
+        if (gwb_graph_export(g, tile_width, &blob, &blob_len, &st2) != 0) {
+            std::string m = st2.error_msg ? st2.error_msg : "export failed";
+            gwb_free_status(&st2);
+            return fail(status, m);
+        }
+    }
+    struct Bufs {
+        void* d_len = nullptr;
+        void* d_blob = nullptr;
+        void* h_blob = nullptr;
+        ~Bufs() {
+            if (d_len) (void)hipFree(d_len);
+            if (d_blob) (void)hipFree(d_blob);
+            free(h_blob);
+        }
+    } bufs;
+    bufs.h_blob = blob;
+    auto nccl_fail = [&](int rc, const char* what) { return fail(status, std::string(what) + ": " + (errstr ? errstr(rc) : "RCCL error " + std::to_string(rc))); };
+    const int ncclUint8 = 1, ncclUint64 = 5;
+    unsigned long long len64 = blob_len;
+    if (hipMalloc(&bufs.d_len, 8) != hipSuccess || hipMemcpy(bufs.d_len, &len64, 8, hipMemcpyHostToDevice) != hipSuccess) return fail(status, "hipMalloc failed");
+    int rc = bcast(bufs.d_len, bufs.d_len, 1, ncclUint64, root, nccl_comm, stream);
+    if (rc != 0) return nccl_fail(rc, "ncclBroadcast (length)");
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(&len64, bufs.d_len, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(status, "hipMemcpy failed");
+    if (len64 == 0 || len64 > (1ull << 40)) return fail(status, "bad program length in broadcast");
+    if (hipMalloc(&bufs.d_blob, (size_t)len64) != hipSuccess) return fail(status, "hipMalloc failed");
+    if (rank == root && hipMemcpy(bufs.d_blob, blob, (size_t)len64, hipMemcpyHostToDevice) != hipSuccess) return fail(status, "hipMemcpy failed");
+    rc = bcast(bufs.d_blob, bufs.d_blob, (size_t)len64, ncclUint8, root, nccl_comm, stream);
+    if (rc != 0) return nccl_fail(rc, "ncclBroadcast (program)");
+    if (hipStreamSynchronize(stream) != hipSuccess) return fail(status, "hipStreamSynchronize failed");
+    if (rank == root) {
+        *out = g;  // the root keeps its handle (its own program for that key is compiled on first use, or already is)
+        set_status(status, OK, "");
+        return 0;
+    }
+    bufs.h_blob = malloc((size_t)len64);
+    if (!bufs.h_blob) return fail(status, "out of memory");
+    if (hipMemcpy(bufs.h_blob, bufs.d_blob, (size_t)len64, hipMemcpyDeviceToHost) != hipSuccess) return fail(status, "hipMemcpy failed");
+    return gwb_graph_import(bufs.h_blob, (size_t)len64, out, status);
     });
 }
 

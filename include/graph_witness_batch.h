@@ -149,6 +149,14 @@ int gwb_wtns_from_witness(const void *witness_row, size_t n_witness, void *out);
 int gwb_graph_export(gwb_graph_t *g, uint32_t tile_width, void **blob, size_t *blob_len, gw_status_t *status);
 int gwb_graph_import(const void *blob, size_t blob_len, gwb_graph_t **out, gw_status_t *status);
 
+/* The same exchange done by the library: rank `root` exports the program for `tile_width` (0 = what the cost model
+ * chooses for a shard of batch_per_rank input sets) and broadcasts it over the caller's RCCL communicator (ncclComm_t,
+ * xGMI inside a node) on hip_stream; every other rank imports it.  *out = g on the root, a new replica elsewhere.  This
+ * is the only collective of the path -- input sets are independent, shards need no exchange.  RCCL is resolved in the
+ * running process (dlsym), the library does not link it. */
+int gwb_graph_broadcast(gwb_graph_t *g, uint32_t tile_width, size_t batch_per_rank, int root, int rank, void *nccl_comm,
+                        void *hip_stream, gwb_graph_t **out, gw_status_t *status);
+
 /* exported twin of the header-inline gw_free_status, for FFI callers that cannot use the inline */
 void gwb_free_status(gw_status_t *status);
 

@@ -47,3 +47,28 @@ def test_conformance_client_end_to_end(pkg, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert out.read_bytes() == open(os.path.join(GOLD, "circuit1.wtns"), "rb").read()
+
+
+def _build_bcast_client(pkg, tmp_path):
+    exe = str(tmp_path / "bcast_client")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "bcast_client.c"), "-L", libdir, "-lcircom_witnesscalc_amd", "-ldl",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_native_broadcast_client_builds(pkg, tmp_path):
+    """The RCCL-owning C host of tests/native/bcast_client.c compiles against include/graph_witness_batch.h (CPU: usage only)."""
+    r = subprocess.run([_build_bcast_client(pkg, tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_broadcast_over_an_rccl_communicator(pkg, tmp_path):
+    """gwb_graph_broadcast from a C host that owns the communicator (one rank: the GPU boxes have one GPU): the root
+    gets its handle back and evaluates circuit1's reference inputs to the golden witness [1, 31817, 105, 303]."""
+    exe = _build_bcast_client(pkg, tmp_path)
+    r = subprocess.run([exe, os.path.join(GOLD, "circuit1.bin"), os.path.join(GOLD, "circuit1_inputs.json")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert [int(x, 16) for x in r.stdout.split()] == [1, 31817, 105, 303]
