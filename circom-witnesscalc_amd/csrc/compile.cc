@@ -547,6 +547,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
 
     phase("levels");
     if (probe_only) {
+        for (const Node& n : g.nodes)  // (nodes per class of the graph as loaded: the runtime asks whether there are divisions)
+            if (n.kind != N_CONST) st.class_nodes[class_of(n)]++;
         out.n_inputs = (uint32_t)n_in_buf;
         out.n_witness = (uint32_t)g.witness_signals.size();
         return true;

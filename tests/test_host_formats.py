@@ -427,3 +427,17 @@ def test_load_time_optimiser_is_exact(pkg):
                     if not panic:
                         assert got == want, (variant, row)
         assert (compared == 0) if variant == 0 else (compared >= 6), (variant, compared)
+
+
+def test_cost_model_program_choice_is_host_only_and_sane(pkg):
+    """gwb_graph_pick_tile_width needs no device (rank 0 of a multi-GPU job asks it before exporting the program), sees the
+    divisions of the graph as loaded (a divider-wave program while every pair is resident, none for a graph without
+    divisions) and widens the tile with the batch."""
+    g = pkg.Graph(C.build_authv2_class(scale=0.3).to_bin())
+    keys = {b: g.pick_tile_width(b) for b in (1, 256, 1024, 4096, 16384, 65536)}
+    assert keys[1024] & 0x700 and keys[256] & 0x700, keys          # divider programs at small batches
+    assert not keys[65536] & 0x700 and (keys[65536] & 0xff) >= 16, keys
+    widths = [keys[b] & 0xff for b in sorted(keys)]
+    assert widths == sorted(widths), keys
+    s = pkg.Graph(C.build_sha256(512).to_bin())
+    assert not s.pick_tile_width(1024) & 0x700 and not s.pick_tile_width(4096) & 0x700
