@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
     }
 }
 
-// (round-1 shape, kept for A/B: block = 64 witness indices x min(T, 4) sets of one tile)
+// (round-1 shape: block = 64 witness indices x min(T, 4) sets of one tile; what tiles wider than 4 sets use)
 template <bool MONT>
 __global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
     const uint32_t w = blockIdx.x * 64u + threadIdx.x;
@@ -691,7 +691,8 @@ hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void
     if (p.n_witness == 0 || batch == 0) return hipSuccess;
     const uint32_t n_tiles = (batch + T - 1) / T;
     static const bool v1 = getenv("CWC_PACK_V1") != nullptr;
-    if (v1) {
+    if (v1 || T > 4) {  // (tiles of 8 sets and more: a thread walking all sets of its slot serialises 8..64 conversions -- 22.6 ms
+                        // against 9.5 ms for the 8192-set pack at T = 8; the sets of a slot stay spread over the waves of a block)
         dim3 grid((p.n_witness + 63) / 64, n_tiles < 32768u ? n_tiles : 32768u), block(64, T < 4 ? T : 4);
         if (montgomery) pack_kernel_v1<true><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
         else pack_kernel_v1<false><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
@@ -700,9 +701,9 @@ hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void
     dim3 grid((p.n_witness + 255) / 256, n_tiles < 32768u ? n_tiles : 32768u), block(256);
 #define CWC_PACK(MM, TT) pack_kernel<MM, TT><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T)
     if (montgomery) {
-        if (T == 1) CWC_PACK(true, 1); else if (T == 2) CWC_PACK(true, 2); else if (T == 4) CWC_PACK(true, 4); else CWC_PACK(true, 0);
+        if (T == 1) CWC_PACK(true, 1); else if (T == 2) CWC_PACK(true, 2); else CWC_PACK(true, 4);
     } else {
-        if (T == 1) CWC_PACK(false, 1); else if (T == 2) CWC_PACK(false, 2); else if (T == 4) CWC_PACK(false, 4); else CWC_PACK(false, 0);
+        if (T == 1) CWC_PACK(false, 1); else if (T == 2) CWC_PACK(false, 2); else CWC_PACK(false, 4);
     }
 #undef CWC_PACK
     return hipGetLastError();

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Evidence of one code state on one MI355X box (run through gpurun from the repository root):
-#   gpurun --timeout 2400 -- 'bash tools/collect_evidence.sh r01'
-# then, back in the container:  python tools/profile_summary.py r01  and copy the logs named in profiles/README.md.
+#   gpurun --timeout 2400 -- 'bash tools/collect_evidence.sh r02'
+# then, back in the container:  python tools/profile_summary.py r02  and copy the logs named in profiles/README.md.
 # Each rocprofv3 pass is its own command with the program directly behind `--`; counter passes carry no trace domains.
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extra-batch 0 --host-path 0"
+BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0"
 python -m pytest tests -q -m gpu > $O/gputest_$R.log 2>&1; tail -1 $O/gputest_$R.log
 python bench.py > $O/bench_$R.json 2> $O/bench_$R.err
 rocprofv3 --kernel-trace --stats -d $O/prof_$R -o runc -- $BENCH > $O/prof_$R.log 2>&1
@@ -15,10 +15,21 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$R -o runc -- $BENCH > $O/pmc_fetch_$
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$R -o runc -- $BENCH > $O/pmc_write_$R.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
     -d $O/pmc_sq_$R -o runc -- $BENCH > $O/pmc_sq_$R.log 2>&1
-PROBE_T=2,258,4 python tools/gpu_classprof.py > $O/classprof_$R.log 2>&1
+PROBE_T=258,2,4 python tools/gpu_classprof.py > $O/classprof_$R.log 2>&1
+PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 PROBE_GRAPH=bigint PROBE_B=32 PROBE_T=1 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 python tools/gpu_sweep.py > $O/sweep_$R.log 2>&1
 python tools/gpu_autopick.py > $O/autopick_$R.log 2>&1
-python bench.py --graph sha256 --batch-per-gpu 4096 --cpu-sample 128 --extra-batch 0 > $O/bench_sha256_$R.json 2> $O/bench_sha256_$R.err
+python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
+(cd tools/ubench && ./coop_mul) > $O/coop_mul_$R.log 2>&1
+python bench.py --config 3 --cpu-sample 128 > $O/bench_config3_$R.json 2> $O/bench_config3_$R.err
+python bench.py --config 4 --cpu-sample 0 > $O/bench_config4_$R.json 2> $O/bench_config4_$R.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 1 --cpu-sample 0 \
+    > $O/bench_dist1_$R.json 2> $O/bench_dist1_$R.err
 python tools/gpu_host_path.py > $O/hostpath_$R.log 2>&1
+python tools/gpu_single_shot.py > $O/single_shot_$R.log 2>&1
+BIGINT_ROUNDS=4000 PROBE_T=0 python tools/gpu_bigint.py > $O/config5_$R.log 2>&1
+bash tools/gpu_policies.sh "X=0 --" "CWC_NO_COOP_MUL=1 --" "CWC_COOP_FILL=32 CWC_COOP_SLACK=4000000000 --" "CWC_COOP_FILL=16 CWC_COOP_SLACK=2 --" \
+    "CWC_SCHED_MUL_COST=47 CWC_SCHED_LIN_COST=12 --" "CWC_SCHED_MUL_COST=26 CWC_SCHED_LIN_COST=14 --" "CWC_SCHED_MUL_COST=30 CWC_SCHED_LIN_COST=24 --" \
+    "CWC_PACK_V1=1 --" "X=0 -- --batch-per-gpu 256" "CWC_NO_COOP_MUL=1 -- --batch-per-gpu 256" > $O/policies_$R.log 2>&1
 ls $O

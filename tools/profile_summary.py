@@ -52,7 +52,7 @@ def main():
     divider = int(interp[0][0].split("interp_kernel<")[1].split(">")[0].split(",")[2].strip())
     summary = {"config": {"graph": a.graph, "batch_per_gpu": a.batch, "tile_width": tile, "interpreter_waves_per_divider_wave": divider},
                "source": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* passes of "
-                         "`python3 bench.py --steps N --warmup 1 --cpu-sample 0 --extra-batch 0`, one pass per command",
+                         "`python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0`, one pass per command",
                "kernels": {"interp": {"name": interp[0][0].split("(")[0], "launches": len(interp),
                                       "avg_duration_ms": sum(d[4] for d in interp) / len(interp) / 1e6,
                                       "vgpr": interp[0][10], "sgpr": interp[0][12], "lds_bytes": interp[0][9],
