@@ -31,7 +31,7 @@ class GraphInfo(ctypes.Structure):
 class Timing(ctypes.Structure):
     _fields_ = [("tile_width", ctypes.c_uint32), ("n_launches", ctypes.c_uint32), ("n_bundles", ctypes.c_uint64),
                 ("n_slots", ctypes.c_uint64), ("interp_ms", ctypes.c_float), ("pack_ms", ctypes.c_float),
-                ("divider", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("divider", ctypes.c_uint32), ("streams", ctypes.c_uint32)]
 
 
 class Handoff(ctypes.Structure):

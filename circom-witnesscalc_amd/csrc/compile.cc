@@ -367,6 +367,11 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
 static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 2200, 8500, 1450, 1490, 3700, 1306};
 static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60;
 double program_wave_cycles(const Program& p) {
+    if (p.n_streams > 1) {  // the tile is done when its slowest stream is
+        double m = 0;
+        for (uint32_t s = 0; s < p.n_streams; ++s) m = std::max(m, std::max(p.stream_cycles[s], p.stream_chain_cycles[s]));
+        return m;
+    }
     double c = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)p.stats.class_bundles[k];
     return c - (kCycles[C_BIT] - kCyclesBitx) * (double)p.stats.n_bitx_bundles + kCyclesCoopRiders * (double)p.stats.n_coop_rider_bundles;
@@ -374,6 +379,12 @@ double program_wave_cycles(const Program& p) {
 
 // the multiplication and inversion bundles' part of it (bundles that are bound by instruction issue)
 double program_wave_cycles_mul_div(const Program& p) {
+    if (p.n_streams > 1) {
+        uint32_t m = 0;
+        for (uint32_t s = 1; s < p.n_streams; ++s)
+            if (p.stream_cycles[s] > p.stream_cycles[m]) m = s;
+        return p.stream_cycles_mul_div[m];
+    }
     return kCycles[C_MUL] * (double)p.stats.class_bundles[C_MUL] + kCycles[C_MULQ] * (double)p.stats.class_bundles[C_MULQ] +
            kCycles[C_DIV] * (double)p.stats.class_bundles[C_DIV];
 }
@@ -399,7 +410,7 @@ struct RewriteCache {
     std::vector<Entry> entries;
 };
 static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err,
-                            RewriteCache* cache = nullptr, bool probe_only = false);
+                            RewriteCache* cache = nullptr, bool probe_only = false, uint32_t streams = 1);
 
 // Validation and statistics of a loaded graph without compiling a program (what gwb_graph_load needs).
 bool probe_graph(const Graph& g, Program& out, std::string& err) { return compile_variant(g, 64, 0, false, CoopPolicy{0, 0}, out, err, nullptr, true); }
@@ -408,7 +419,7 @@ bool probe_graph(const Graph& g, Program& out, std::string& err) { return compil
 // up in bundles: the program is compiled with and without the bit-extract fusion, then under a few narrow-bundle
 // policies, and the cheapest schedule by the measured cycles per bundle class (program_wave_cycles) is kept -- the
 // policies are not fitted to one graph, the cost model picks per graph and tile width.
-bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err) {
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams) {
     const uint32_t G = T ? 64 / T : 1;
     CoopPolicy base{G, ~0u};  // narrow whenever everything ready fits
     if (const char* e = getenv("CWC_COOP_FILL")) base.fill = (uint32_t)atol(e);
@@ -416,7 +427,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
     if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
     RewriteCache cache;
-    if (!compile_variant(g, T, divider, true, base, out, err, &cache)) return false;
+    if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) return false;
     if (getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
     // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
     // authV2-class graph, and slower for multi-million-node graphs)
@@ -424,7 +435,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     if (out.stats.n_bitx_nodes != 0 && !getenv("CWC_NO_BIT_FUSION")) {
         Program alt;
         std::string err2;
-        if (compile_variant(g, T, divider, false, base, alt, err2, &cache) && program_wave_cycles(alt) < program_wave_cycles(out)) {
+        if (compile_variant(g, T, divider, false, base, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
             out = std::move(alt);
             fusion = false;
         }
@@ -434,13 +445,17 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     for (const CoopPolicy& pol : more) {
         Program alt;
         std::string err2;
-        if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+        if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
     }
     return true;
 }
 
 static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err,
-                            RewriteCache* cache, bool probe_only) {
+                            RewriteCache* cache, bool probe_only, uint32_t streams) {
+    if (streams != 1 && streams != 2 && streams != 4) {
+        err = "a tile is evaluated by 1, 2 or 4 streams";
+        return false;
+    }
     if (T == 0 || T > 64 || (T & (T - 1))) {
         err = "tile width must be a power of two in 1..64";
         return false;
@@ -637,18 +652,27 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                                                           // division handed to the divider wave: request vs. collect)
     std::vector<uint32_t> bundle_start;  // index into order
     std::vector<uint8_t> bundle_coop;    // the bundle is a narrow multiplication bundle (C_MULQ: four lanes per product)
+    std::vector<uint32_t> bundle_flags;  // HDR_POST / HDR_WAIT (programs of several streams)
     static const uint32_t REQ_FLAG = 0x80000000u;         // order[] entry: the request half of a division
+    // Streams: the graph's independent parts (components that share nothing but Input nodes and constants) can be
+    // evaluated by different wavefronts of one tile, each with its own bundle sequence.  Stream 0 also evaluates every
+    // Input node first (the prologue) and then posts; the other streams begin with a wait for that post.
+    std::vector<uint8_t> stream_of(N, 0);
+    uint32_t P = 1;
+    uint32_t s_first[MAX_STREAMS] = {0, 0, 0, 0}, s_count[MAX_STREAMS] = {0, 0, 0, 0}, s_div[MAX_STREAMS] = {0, 0, 0, 0};
+    double s_chain[MAX_STREAMS] = {0, 0, 0, 0};  // longest dependent chain of each stream, lone-wave cycles (divisions at the divider wave's latency)
     if (G == 1) {
         for (size_t i = 0; i < N; ++i)
             if (g.nodes[i].kind != N_CONST) {
                 bundle_of[i] = use_bundle_of[i] = (uint32_t)bundle_start.size();
                 bundle_start.push_back((uint32_t)order.size());
                 bundle_coop.push_back(0);
+                bundle_flags.push_back(0);
                 order.push_back((uint32_t)i);
             }
+        s_count[0] = (uint32_t)bundle_start.size();
     } else {
         std::vector<uint64_t> height(N, 0);
-        std::vector<uint32_t> indeg(N, 0);
         std::vector<std::vector<uint32_t>> users;  // adjacency (only non-const producers)
         users.resize(N);
         for (size_t i = 0; i < N; ++i) {
@@ -664,7 +688,6 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 if (dup) continue;
                 seen[ns++] = o;
                 users[o].push_back((uint32_t)i);
-                indeg[i]++;
             }
         }
         for (size_t i = N; i-- > 0;) {
@@ -712,154 +735,340 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             dist_to_div[i] = (uint16_t)std::min<uint32_t>(d, kFar);
         }
         const bool tie_reverse = getenv("CWC_SCHED_TIE_REVERSE") != nullptr;
-        // ready heaps per class, keyed by (height, -index)
-        typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
-        std::vector<std::vector<Key>> heap(C_COUNT);
-        auto push = [&](uint32_t i) {
-            auto& h = heap[class_of(g.nodes[i])];
-            h.push_back(Key(height[i], tie_reverse ? i : ~i));
-            std::push_heap(h.begin(), h.end());
-        };
-        for (size_t i = 0; i < N; ++i)
-            if (g.nodes[i].kind != N_CONST && indeg[i] == 0) push((uint32_t)i);
-        std::vector<uint32_t> picked;
-        size_t remaining = 0;
-        for (size_t i = 0; i < N; ++i) remaining += g.nodes[i].kind != N_CONST;
-        // Asynchronous divider: a division bundle is split into a request (operands to the divider wave) and, about
-        // one inversion later on the scheduler's clock, a collect bundle with the same nodes in the same node slots;
-        // the interpreter runs other ready work in between.  One request is in flight at a time.
         const bool ride_along = !getenv("CWC_NO_RIDE_ALONG");
-        uint64_t clock = 0;
-        std::vector<uint32_t> in_flight;  // nodes of the pending request
-        uint64_t in_flight_ready = 0;
         // Narrow multiplication bundles: when no more multiplications are ready than four-lane products fit a wave, the
         // bundle is compiled for the lane-cooperative multiplier (about half the cycles of a full-width multiplication
-        // bundle); linear nodes cannot ride in it.
+        // bundle).
         const size_t coop_cap = policy.fill ? coop_nodes(T) : 0;
         const uint64_t coop_slack = policy.slack_levels == ~0u ? ~0ull : (uint64_t)policy.slack_levels * class_cost[C_MUL];
         const size_t coop_fill = policy.fill;
-        auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false) {
-            const uint32_t b = (uint32_t)bundle_start.size();
-            bundle_start.push_back((uint32_t)order.size());
-            bundle_coop.push_back(coop ? 1 : 0);
-            for (uint32_t i : nodes) {
-                if (request) {
-                    use_bundle_of[i] = b;
-                    order.push_back(i | REQ_FLAG);
-                } else {
-                    bundle_of[i] = b;
-                    if (!collect) use_bundle_of[i] = b;
-                    order.push_back(i);
-                }
+
+        // Programs of several streams: the prologue -- Input nodes and the operations within a short chain of them, which
+        // the graph's parts tend to share (flags, key bits, common subexpressions) -- is evaluated by stream 0 before
+        // anything else; it posts behind it, the other streams begin with a wait for that post.
+        std::vector<uint8_t> prologue(N, 0);
+        static const uint64_t kPrologueBoost = 1ull << 60;
+        // One stream's bundle sequence (bundle indices relative to the stream's first bundle).
+        struct StreamSched {
+            std::vector<uint32_t> order, bundle_start, div_lanes;
+            std::vector<uint8_t> bundle_coop;
+            uint64_t class_bundles[C_COUNT] = {0};
+            uint32_t n_div_requests = 0, last_prologue_bundle = 0;
+            double cycles() const {
+                double c = 0;
+                for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)class_bundles[k];
+                return c;
             }
-            if (request) return;
-            remaining -= nodes.size();
-            for (uint32_t i : nodes)  // release users only now: a bundle never reads its own results
-                for (uint32_t u : users[i])
-                    if (--indeg[u] == 0) push(u);
         };
-        while (remaining) {
-            int best = -1;
-            for (int c = 0; c < (int)C_COUNT; ++c)
-                if (!heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
-            if (!in_flight.empty()) {
-                // collect when the quotients are due, or when nothing else can run (the interpreter then waits)
-                bool other_ready = false;
-                for (int c = 0; c < (int)C_COUNT; ++c) other_ready |= c != C_DIV && !heap[c].empty();
-                if (clock >= in_flight_ready || !other_ready) {
-                    emit_bundle(in_flight, false, true);
-                    out.div_lanes.push_back((uint32_t)in_flight.size() * T);
-                    in_flight.clear();
-                    out.n_div_requests++;
-                    clock += kClockCost[C_DIVGET];
-                    continue;
-                }
-                if (best == C_DIV) {  // a second request has to wait for the first one: run the best other class
-                    best = -1;
-                    for (int c = 0; c < (int)C_COUNT; ++c)
-                        if (c != C_DIV && !heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
-                }
+        // `so`: stream of every node; producers in another stream do not gate a node (the streams' phases do).  With
+        // record = false nothing outside `ss` is written (pricing a candidate partition).
+        auto schedule_stream = [&](uint32_t s, const std::vector<uint8_t>& so, StreamSched& ss, bool record) -> bool {
+            std::vector<uint32_t> indeg(N, 0);
+            size_t remaining = 0;
+            for (size_t i = 0; i < N; ++i) {
+                if (g.nodes[i].kind == N_CONST) continue;
+                for (uint32_t u : users[i])
+                    if (so[u] == s && so[i] == s) indeg[u]++;
+                remaining += so[i] == s;
             }
-            if (best < 0) {
-                err = "internal error: scheduler found no ready node";
-                return false;
-            }
-            // An inversion bundle costs about thirty multiplication bundles however few of its lanes are used, and a
-            // wave's time is the sum of its bundles: a ready division waits while another chain is within a few
-            // operations of its own division (its ready node goes first), so that sibling chains divide together.
-            if (best == C_DIV) {
-                int other = -1;
-                for (int c = 0; c < (int)C_COUNT; ++c) {
-                    if (c == C_DIV || heap[c].empty()) continue;
-                    // the heap top is the class's most urgent node; scan the ready nodes of the class for one that
-                    // is about to reach a division
-                    bool near = false;
-                    for (const Key& k : heap[c]) near |= dist_to_div[tie_reverse ? k.second : ~k.second] <= div_wait_ops;
-                    if (near && (other < 0 || heap[c].front() > heap[other].front())) other = c;
-                }
-                if (other >= 0) best = other;
-            }
-            // INPUT nodes first whenever any is ready (they have no producers and feed everything)
-            if (!heap[C_INPUT].empty()) best = C_INPUT;
-            picked.clear();
-            auto& h = heap[best];
-            // a request must fit the interpreter's mailbox (mbox_lanes active lanes = node slots x T)
-            const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : G;
-            bool coop = false;
-            if (best == C_MUL && coop_cap) {
-                // Narrow or full-width?  The ready multiplications in priority order; the ones within `coop_slack` of the
-                // most urgent node's height cannot wait.  If they fit a narrow bundle it is one (cheapest step for the
-                // critical chain; its free groups take the next most urgent multiplications, then linear riders) and the
-                // rest stays ready: work with slack piles up until it becomes urgent itself and then fills full-width
-                // bundles properly (a full-width bundle costs the same with 10 or 32 nodes).
-                std::vector<Key> cand;
-                while (!h.empty() && cand.size() < G) {
-                    std::pop_heap(h.begin(), h.end());
-                    cand.push_back(h.back());
-                    h.pop_back();
-                }
-                size_t n_urgent = 0;
-                while (n_urgent < cand.size() && (coop_slack >= cand[0].first || cand[n_urgent].first >= cand[0].first - coop_slack)) ++n_urgent;
-                coop = n_urgent <= coop_cap && (cand.size() <= coop_cap || cand.size() < coop_fill);
-                const size_t take = coop ? std::min(coop_cap, cand.size()) : cand.size();
-                for (size_t q = 0; q < cand.size(); ++q) {
-                    if (q < take) {
-                        picked.push_back(tie_reverse ? cand[q].second : ~cand[q].second);
+            // ready heaps per class, keyed by (height, -index)
+            typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
+            std::vector<std::vector<Key>> heap(C_COUNT);
+            auto push = [&](uint32_t i) {
+                auto& h = heap[class_of(g.nodes[i])];
+                h.push_back(Key(height[i] + (prologue[i] ? kPrologueBoost : 0ull), tie_reverse ? i : ~i));
+                std::push_heap(h.begin(), h.end());
+            };
+            for (size_t i = 0; i < N; ++i)
+                if (g.nodes[i].kind != N_CONST && so[i] == s && indeg[i] == 0) push((uint32_t)i);
+            std::vector<uint32_t> picked;
+            // Asynchronous divider: a division bundle is split into a request (operands to the divider wave) and, about
+            // one inversion later on the scheduler's clock, a collect bundle with the same nodes in the same node slots;
+            // the interpreter runs other ready work in between.  One request is in flight at a time.
+            uint64_t clock = 0;
+            std::vector<uint32_t> in_flight;  // nodes of the pending request
+            uint64_t in_flight_ready = 0;
+            auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false) {
+                const uint32_t b = (uint32_t)ss.bundle_start.size();
+                ss.bundle_start.push_back((uint32_t)ss.order.size());
+                ss.bundle_coop.push_back(coop ? 1 : 0);
+                const int cl = request ? (int)C_DIVREQ : collect && divider ? (int)C_DIVGET : coop ? (int)C_MULQ : nodes.empty() ? (int)C_LIN : class_of(g.nodes[nodes[0]]);
+                if ((unsigned)cl < (unsigned)C_COUNT) ss.class_bundles[cl]++;
+                for (uint32_t i : nodes) {
+                    if (prologue[i] && !request) ss.last_prologue_bundle = b;
+                    if (request) {
+                        if (record) use_bundle_of[i] = b;
+                        ss.order.push_back(i | REQ_FLAG);
                     } else {
-                        h.push_back(cand[q]);
-                        std::push_heap(h.begin(), h.end());
+                        if (record) {
+                            bundle_of[i] = b;
+                            if (!collect) use_bundle_of[i] = b;
+                        }
+                        ss.order.push_back(i);
                     }
                 }
+                if (request) return;
+                remaining -= nodes.size();
+                for (uint32_t i : nodes)  // release users only now: a bundle never reads its own results
+                    for (uint32_t u : users[i])
+                        if (so[u] == s && --indeg[u] == 0) push(u);
+            };
+            if (s != 0) {  // two idle bundles: the first one waits for stream 0's post (the values of the Input nodes), and
+                           // the staging loads of bundles 0 and 1 are issued before the loop, ahead of that wait
+                emit_bundle(picked, false, false);
+                emit_bundle(picked, false, false);
             }
-            while (!coop && !h.empty() && picked.size() < cap) {
-                std::pop_heap(h.begin(), h.end());
-                picked.push_back(tie_reverse ? h.back().second : ~h.back().second);
-                h.pop_back();
-            }
-            std::sort(picked.begin(), picked.end());
-            // A wave's time is the sum of its bundles and a multiplication bundle costs the same however few of its
-            // node slots are used: ready Add/Sub nodes ride in its free slots (the kernel then also runs the ~40-slot
-            // linear body, header bits) instead of asking for a bundle of their own later.
-            const size_t slots = coop ? coop_cap : G;  // (a narrow bundle takes riders too: groups of four lanes add / subtract)
-            if (best == C_MUL && picked.size() < slots && !heap[C_LIN].empty() && ride_along) {
-                auto& hl = heap[C_LIN];
-                std::vector<uint32_t> riders;
-                while (!hl.empty() && picked.size() + riders.size() < slots) {
-                    std::pop_heap(hl.begin(), hl.end());
-                    riders.push_back(tie_reverse ? hl.back().second : ~hl.back().second);
-                    hl.pop_back();
+            while (remaining) {
+                int best = -1;
+                for (int c = 0; c < (int)C_COUNT; ++c)
+                    if (!heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
+                if (!in_flight.empty()) {
+                    // collect when the quotients are due, or when nothing else can run (the interpreter then waits)
+                    bool other_ready = false;
+                    for (int c = 0; c < (int)C_COUNT; ++c) other_ready |= c != C_DIV && !heap[c].empty();
+                    if (clock >= in_flight_ready || !other_ready) {
+                        emit_bundle(in_flight, false, true);
+                        ss.div_lanes.push_back((uint32_t)in_flight.size() * T);
+                        in_flight.clear();
+                        ss.n_div_requests++;
+                        clock += kClockCost[C_DIVGET];
+                        continue;
+                    }
+                    if (best == C_DIV) {  // a second request has to wait for the first one: run the best other class
+                        best = -1;
+                        for (int c = 0; c < (int)C_COUNT; ++c)
+                            if (c != C_DIV && !heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
+                    }
                 }
-                std::sort(riders.begin(), riders.end());
-                picked.insert(picked.end(), riders.begin(), riders.end());  // multiplications first: they name the class
+                if (best < 0) {
+                    err = "internal error: scheduler found no ready node";
+                    return false;
+                }
+                // An inversion bundle costs about thirty multiplication bundles however few of its lanes are used, and a
+                // wave's time is the sum of its bundles: a ready division waits while another chain is within a few
+                // operations of its own division (its ready node goes first), so that sibling chains divide together.
+                if (best == C_DIV) {
+                    int other = -1;
+                    for (int c = 0; c < (int)C_COUNT; ++c) {
+                        if (c == C_DIV || heap[c].empty()) continue;
+                        // the heap top is the class's most urgent node; scan the ready nodes of the class for one that
+                        // is about to reach a division
+                        bool near = false;
+                        for (const Key& k : heap[c]) near |= dist_to_div[tie_reverse ? k.second : ~k.second] <= div_wait_ops;
+                        if (near && (other < 0 || heap[c].front() > heap[other].front())) other = c;
+                    }
+                    if (other >= 0) best = other;
+                }
+                // INPUT nodes first whenever any is ready (they have no producers and feed everything)
+                if (!heap[C_INPUT].empty()) best = C_INPUT;
+                picked.clear();
+                auto& h = heap[best];
+                // a request must fit the interpreter's mailbox (mbox_lanes active lanes = node slots x T)
+                const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : G;
+                bool coop = false;
+                if (best == C_MUL && coop_cap) {
+                    // Narrow or full-width?  The ready multiplications in priority order; the ones within `coop_slack` of the
+                    // most urgent node's height cannot wait.  If they fit a narrow bundle it is one (cheapest step for the
+                    // critical chain; its free groups take the next most urgent multiplications, then linear riders) and the
+                    // rest stays ready: work with slack piles up until it becomes urgent itself and then fills full-width
+                    // bundles properly (a full-width bundle costs the same with 10 or 32 nodes).
+                    std::vector<Key> cand;
+                    while (!h.empty() && cand.size() < G) {
+                        std::pop_heap(h.begin(), h.end());
+                        cand.push_back(h.back());
+                        h.pop_back();
+                    }
+                    size_t n_urgent = 0;
+                    while (n_urgent < cand.size() && (coop_slack >= cand[0].first || cand[n_urgent].first >= cand[0].first - coop_slack)) ++n_urgent;
+                    coop = n_urgent <= coop_cap && (cand.size() <= coop_cap || cand.size() < coop_fill);
+                    const size_t take = coop ? std::min(coop_cap, cand.size()) : cand.size();
+                    for (size_t q = 0; q < cand.size(); ++q) {
+                        if (q < take) {
+                            picked.push_back(tie_reverse ? cand[q].second : ~cand[q].second);
+                        } else {
+                            h.push_back(cand[q]);
+                            std::push_heap(h.begin(), h.end());
+                        }
+                    }
+                }
+                while (!coop && !h.empty() && picked.size() < cap) {
+                    std::pop_heap(h.begin(), h.end());
+                    picked.push_back(tie_reverse ? h.back().second : ~h.back().second);
+                    h.pop_back();
+                }
+                std::sort(picked.begin(), picked.end());
+                // A wave's time is the sum of its bundles and a multiplication bundle costs the same however few of its
+                // node slots are used: ready Add/Sub nodes ride in its free slots (the kernel then also runs the ~40-slot
+                // linear body, header bits) instead of asking for a bundle of their own later.
+                const size_t slots = coop ? coop_cap : G;  // (a narrow bundle takes riders too: groups of four lanes add / subtract)
+                if (best == C_MUL && picked.size() < slots && !heap[C_LIN].empty() && ride_along) {
+                    auto& hl = heap[C_LIN];
+                    std::vector<uint32_t> riders;
+                    while (!hl.empty() && picked.size() + riders.size() < slots) {
+                        std::pop_heap(hl.begin(), hl.end());
+                        riders.push_back(tie_reverse ? hl.back().second : ~hl.back().second);
+                        hl.pop_back();
+                    }
+                    std::sort(riders.begin(), riders.end());
+                    picked.insert(picked.end(), riders.begin(), riders.end());  // multiplications first: they name the class
+                }
+                if (best == C_DIV && divider) {
+                    emit_bundle(picked, true, false);
+                    in_flight = picked;
+                    clock += kClockCost[C_DIVREQ];
+                    in_flight_ready = clock + kClockCost[C_DIV];
+                } else {
+                    emit_bundle(picked, false, false, coop);
+                    clock += kClockCost[coop ? (int)C_MULQ : best];
+                }
             }
-            if (best == C_DIV && divider) {
-                emit_bundle(picked, true, false);
-                in_flight = picked;
-                clock += kClockCost[C_DIVREQ];
-                in_flight_ready = clock + kClockCost[C_DIV];
+            return true;
+        };
+
+        // ---- partition into streams ----
+        if (streams > 1 && (divider == 0 || divider == 1)) {
+            // components of the operation nodes (edges through Input nodes and constants do not connect)
+            std::vector<uint32_t> parent(N);
+            for (size_t i = 0; i < N; ++i) parent[i] = (uint32_t)i;
+            auto find = [&](uint32_t x) {
+                while (parent[x] != x) x = parent[x] = parent[parent[x]];
+                return x;
+            };
+            auto is_op = [&](uint32_t i) { return arity_of(g.nodes[i]) != 0; };
+            // per component: the longest dependent chain and the summed work, both in lone-wave cycles (a multiplication
+            // on a chain is a narrow bundle where the tile width has them; a division is its request, the inversion and
+            // its collect bundle)
+            const bool narrow = coop_cap != 0;
+            auto node_cycles = [&](int c) -> double {
+                if (c == C_MUL) return narrow ? kCycles[C_MULQ] : kCycles[C_MUL];
+                if (c == C_DIV && divider) return kCycles[C_DIV] + kCycles[C_DIVREQ] + kCycles[C_DIVGET];
+                return kCycles[c];
+            };
+            double theta = 30000;  // (cycles of dependent operations from the inputs that still count as prologue)
+            if (const char* e = getenv("CWC_STREAM_PROLOGUE")) theta = atof(e);
+            std::vector<double> cp(N, 0);
+            for (size_t i = 0; i < N; ++i) {
+                const Node& n = g.nodes[i];
+                if (n.kind == N_INPUT) prologue[i] = 1;
+                if (!is_op((uint32_t)i)) continue;
+                const uint32_t ops[3] = {n.a, n.b, n.c};
+                double m = 0;
+                for (int q = 0; q < arity_of(n); ++q) m = std::max(m, cp[ops[q]]);
+                cp[i] = m + node_cycles(class_of(n));
+                prologue[i] = cp[i] <= theta;
+            }
+            for (size_t i = 0; i < N; ++i) {
+                if (!is_op((uint32_t)i) || prologue[i]) continue;
+                const Node& n = g.nodes[i];
+                const uint32_t ops[3] = {n.a, n.b, n.c};
+                for (int q = 0; q < arity_of(n); ++q)
+                    if (is_op(ops[q]) && !prologue[ops[q]]) {
+                        const uint32_t ra = find((uint32_t)i), rb = find(ops[q]);
+                        if (ra != rb) parent[ra] = rb;
+                    }
+            }
+            struct Comp { uint32_t root; double cp = 0, work = 0, alone = 0; uint64_t nodes = 0; };
+            std::unordered_map<uint32_t, uint32_t> comp_index;
+            std::vector<Comp> comps;
+            for (size_t i = 0; i < N; ++i) {
+                if (!is_op((uint32_t)i) || prologue[i]) continue;
+                const Node& n = g.nodes[i];
+                const int c = class_of(n);
+                const uint32_t r = find((uint32_t)i);
+                auto it = comp_index.find(r);
+                if (it == comp_index.end()) {
+                    it = comp_index.emplace(r, (uint32_t)comps.size()).first;
+                    comps.push_back(Comp());
+                    comps.back().root = r;
+                }
+                Comp& co = comps[it->second];
+                co.cp = std::max(co.cp, cp[i]);
+                const double cap = c == C_MUL && narrow ? (double)coop_cap : c == C_DIV && divider ? std::max(1.0, (double)mbox_lanes(divider) / T) : (double)G;
+                co.work += node_cycles(c) / cap;
+                co.nodes++;
+            }
+            for (Comp& co : comps) co.alone = std::max(co.cp, co.work);
+            std::vector<uint32_t> by_size(comps.size());
+            for (size_t k = 0; k < comps.size(); ++k) by_size[k] = (uint32_t)k;
+            std::sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return comps[x].alone > comps[y].alone; });
+            // longest first, each to the stream with the least load so far
+            std::vector<uint8_t> comp_stream(comps.size(), 0);
+            double load[MAX_STREAMS] = {0, 0, 0, 0};
+            for (uint32_t k : by_size) {
+                uint32_t to = 0;
+                for (uint32_t s = 1; s < streams; ++s)
+                    if (load[s] < load[to]) to = s;
+                comp_stream[k] = (uint8_t)to;
+                load[to] += comps[k].alone;
+            }
+            uint32_t used = 0;
+            for (uint32_t s = 0; s < streams; ++s) used += load[s] > 0;
+            if (getenv("CWC_DEBUG_STREAMS")) {
+                fprintf(stderr, "streams T=%u: %zu components;", T, comps.size());
+                for (size_t q = 0; q < by_size.size() && q < 10; ++q) {
+                    const Comp& co = comps[by_size[q]];
+                    fprintf(stderr, " [%llu nodes, chain %.2f M, work %.2f M -> %u]", (unsigned long long)co.nodes, co.cp / 1e6, co.work / 1e6, comp_stream[by_size[q]]);
+                }
+                fprintf(stderr, "\n");
+            }
+            if (used > 1) {
+                P = streams;  // (a stream without a part stays empty: its wave ends at once)
+                for (size_t i = 0; i < N; ++i)
+                    if (is_op((uint32_t)i) && !prologue[i]) {
+                        stream_of[i] = comp_stream[comp_index[find((uint32_t)i)]];
+                        s_chain[stream_of[i]] = std::max(s_chain[stream_of[i]], cp[i]);
+                    }
             } else {
-                emit_bundle(picked, false, false, coop);
-                clock += kClockCost[coop ? (int)C_MULQ : best];
+                std::fill(prologue.begin(), prologue.end(), 0);
+            }
+        }
+
+        // ---- schedule every stream; a stream's first bundle index is a multiple of the pipeline depths ----
+        for (uint32_t s = 0; s < P; ++s) {
+            StreamSched ss;
+            bool any = s == 0;
+            for (size_t i = 0; i < N && !any; ++i) any = g.nodes[i].kind != N_CONST && stream_of[i] == s;
+            if (!any) {
+                s_first[s] = (uint32_t)bundle_start.size();
+                continue;
+            }
+            if (!schedule_stream(s, stream_of, ss, true)) return false;
+            uint32_t nb = (uint32_t)ss.bundle_start.size();
+            uint32_t post_at = 0xffffffffu;
+            if (P > 1 && s == 0) {  // the post behind the Input bundles: their stores are complete two bundles later
+                post_at = ss.last_prologue_bundle + 2;
+                while (nb <= post_at) {
+                    ss.bundle_start.push_back((uint32_t)ss.order.size());
+                    ss.bundle_coop.push_back(0);
+                    ++nb;
+                }
+            }
+            const uint32_t base = (uint32_t)bundle_start.size();
+            s_first[s] = base;
+            s_count[s] = nb;
+            s_div[s] = ss.n_div_requests;
+            const uint32_t obase = (uint32_t)order.size();
+            for (uint32_t b = 0; b < nb; ++b) {
+                bundle_start.push_back(obase + ss.bundle_start[b]);
+                bundle_coop.push_back(ss.bundle_coop[b]);
+                bundle_flags.push_back(b == post_at ? HDR_POST : (P > 1 && s != 0 && b == 0) ? HDR_WAIT : 0u);
+            }
+            for (uint32_t e : ss.order) {
+                const uint32_t i = e & ~REQ_FLAG;
+                if (e & REQ_FLAG) {
+                    use_bundle_of[i] += base;
+                } else {
+                    bundle_of[i] += base;
+                    if (!(divider && class_of(g.nodes[i]) == C_DIV)) use_bundle_of[i] += base;
+                }
+            }
+            order.insert(order.end(), ss.order.begin(), ss.order.end());
+            out.div_lanes.insert(out.div_lanes.end(), ss.div_lanes.begin(), ss.div_lanes.end());
+            out.n_div_requests += ss.n_div_requests;
+            while (s + 1 < P && bundle_start.size() % 4 != 0) {  // idle bundles up to the next stream's first one (never executed)
+                bundle_start.push_back((uint32_t)order.size());
+                bundle_coop.push_back(0);
+                bundle_flags.push_back(0);
             }
         }
     }
@@ -886,6 +1095,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     enum { SRC_MEM = 0, SRC_RING = 1 };
     auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
         if (q >= 2 || g.nodes[producer].kind == N_CONST) return SRC_MEM;
+        if (stream_of[producer] != stream_of[consumer]) return SRC_MEM;  // (another wave's ring)
         const uint32_t d = use_bundle_of[consumer] - bundle_of[producer];
         return (d >= 1 && d <= RING_BUNDLES) ? SRC_RING : SRC_MEM;
     };
@@ -906,6 +1116,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             const uint32_t o = ops[q];
             if (g.nodes[o].kind == N_CONST || route(o, i, q) != SRC_MEM) continue;
             if (!needs_slot[o]) needs_slot[o] = 1;
+            if (stream_of[o] != stream_of[i]) needs_slot[o] = 2;  // read by another stream: the slot is never reused
             last_mem_use[o] = std::max(last_mem_use[o], use_bundle_of[i]);
         }
     }
@@ -919,6 +1130,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     out.recs.assign((size_t)NB * G * 4, 0);
     out.crefs.assign((size_t)NB * G, 0);
     std::vector<uint32_t> free_slots;
+    uint64_t stream_class_bundles[MAX_STREAMS][C_COUNT];
+    memset(stream_class_bundles, 0, sizeof stream_class_bundles);
+    uint64_t stream_bitx[MAX_STREAMS] = {0, 0, 0, 0}, stream_riders[MAX_STREAMS] = {0, 0, 0, 0};
     std::vector<uint32_t> dying;  // nodes whose slot is released after the current bundle
     uint32_t n_slots = 0;
     const uint32_t zero_off = (uint32_t)((uint64_t)zero_const * slot_bytes);
@@ -941,12 +1155,19 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint8_t> ctrl_of((size_t)NB * G, 0);
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
-        const bool request = (order[k0] & REQ_FLAG) != 0, collect = is_collect(order[k0]);
+        const bool idle = cnt == 0;  // (programs of several streams: padding around the posts and waits; an Add of zeros into the trash slot)
+        const bool request = !idle && (order[k0] & REQ_FLAG) != 0, collect = !idle && is_collect(order[k0]);
         const bool coop = bundle_coop[b] != 0;
         const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ node's record is written COOP_LANES times (positions 4j .. 4j+3)
-        const int cl = request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
-        st.class_bundles[cl]++;
-        st.class_nodes[cl] += cnt;
+        const int cl = idle ? (int)C_LIN : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
+        uint32_t stream = 0;
+        while (stream + 1 < P && b >= s_first[stream + 1]) ++stream;
+        if (b == s_first[stream]) free_slots.clear();  // a slot is reused inside the stream that freed it only (the others run at their own pace)
+        if (b < s_first[stream] + s_count[stream]) {  // (not the never-executed padding in front of the next stream)
+            st.class_bundles[cl]++;
+            st.class_nodes[cl] += cnt;
+            stream_class_bundles[stream][cl]++;
+        }
         dying.clear();
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         bool b_canon = cl == C_BIT;  // every second operand that is read is a constant with a canonical copy
@@ -1039,11 +1260,15 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             if (all) {
                 lin_bits |= HDR_BITX_ALL;
                 st.n_bitx_bundles++;
+                stream_bitx[stream]++;
             }
             if (b_canon) lin_bits |= HDR_BIT_BCANON;
         }
-        if (cl == C_MULQ && lin_bits) st.n_coop_rider_bundles++;
-        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits;
+        if (cl == C_MULQ && lin_bits) {
+            st.n_coop_rider_bundles++;
+            stream_riders[stream]++;
+        }
+        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits | bundle_flags[b];
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);
@@ -1074,6 +1299,19 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
     }
     out.n_slots = n_slots;
+    out.n_streams = P;
+    for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
+        out.stream_first[s] = s_first[s];
+        out.stream_count[s] = s_count[s];
+        out.stream_div_requests[s] = s_div[s];
+        double c = 0, heavy = 0;
+        for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)stream_class_bundles[s][k];
+        c += kCyclesCoopRiders * (double)stream_riders[s] - (kCycles[C_BIT] - kCyclesBitx) * (double)stream_bitx[s];
+        for (int k : {(int)C_MUL, (int)C_MULQ, (int)C_DIV}) heavy += kCycles[k] * (double)stream_class_bundles[s][k];
+        out.stream_cycles[s] = c;
+        out.stream_chain_cycles[s] = s_chain[s];
+        out.stream_cycles_mul_div[s] = heavy;
+    }
     out.n_inputs = (uint32_t)n_in_buf;
     out.n_witness = (uint32_t)g.witness_signals.size();
     out.witness_refs.resize(out.n_witness);
@@ -1102,13 +1340,36 @@ bool validate_program(const Program& p, std::string& err) {
         return bad("array sizes");
     const uint32_t slot_bytes = 32u * T, HI = 16u * T;
     const uint64_t trash_off = ((uint64_t)p.n_const + p.n_slots) * slot_bytes;
-    uint32_t n_req = 0, n_get = 0;
+    // streams: consecutive bundle ranges, each starting at a multiple of the pipeline depths; one stream unless the
+    // divider mode is none or one divider wave per interpreter
+    const uint32_t NS = p.n_streams;
+    if (NS != 1 && NS != 2 && NS != 4) return bad("stream count");
+    if (NS > 1 && p.divider > 1) return bad("streams with a shared divider wave");
+    uint32_t next_first = 0, req_sum = 0;
+    for (uint32_t s = 0; s < NS; ++s) {
+        if (p.stream_first[s] < next_first || (p.stream_first[s] % 4) != 0 || (uint64_t)p.stream_first[s] + p.stream_count[s] > p.n_bundles) return bad("stream ranges");
+        next_first = p.stream_first[s] + p.stream_count[s];
+        req_sum += p.stream_div_requests[s];
+    }
+    if (p.stream_first[0] != 0 || (NS == 1 && p.stream_count[0] != p.n_bundles) || req_sum != p.n_div_requests) return bad("stream ranges");
+    uint32_t n_req = 0, n_get = 0, n_posts = 0;
     bool in_flight = false;
+    uint32_t stream = 0, stream_req = 0;
     for (uint32_t b = 0; b < p.n_bundles; ++b) {
+        while (stream + 1 < NS && b >= p.stream_first[stream + 1]) {
+            if (in_flight || stream_req != p.stream_div_requests[stream]) return bad("division requests of stream " + std::to_string(stream));
+            ++stream;
+            stream_req = 0;
+        }
+        const bool executed = b < p.stream_first[stream] + p.stream_count[stream];
         const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
-        if (cls >= C_COUNT || (h >> 15) != 0) return bad("bundle " + std::to_string(b) + ": header");
+        if (cls >= C_COUNT || (h >> 17) != 0) return bad("bundle " + std::to_string(b) + ": header");
+        // posts and waits: stream 0 posts once, every other stream waits in its first bundle (nothing else is compiled)
+        if ((h & HDR_POST) && !(NS > 1 && stream == 0 && executed && n_posts++ == 0)) return bad("bundle " + std::to_string(b) + ": post");
+        if (((h & HDR_WAIT) != 0) != (NS > 1 && stream != 0 && executed && b == p.stream_first[stream])) return bad("bundle " + std::to_string(b) + ": wait");
         const uint32_t rep = cls == C_MULQ ? COOP_LANES : 1u;
-        if (cnt == 0 || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
+        if ((cnt == 0 && cls != C_LIN) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
+        if (!executed && cnt != 0) return bad("bundle " + std::to_string(b) + ": outside every stream");
         if (cls == C_MULQ && T > COOP_MAX_T) return bad("bundle " + std::to_string(b) + ": narrow bundle at this tile width");
         if ((cls == C_DIVREQ || cls == C_DIVGET) && !p.divider) return bad("bundle " + std::to_string(b) + ": request / collect without a divider");
         if (cls == C_DIV && p.divider) return bad("bundle " + std::to_string(b) + ": inline division in a divider program");
@@ -1116,6 +1377,7 @@ bool validate_program(const Program& p, std::string& err) {
             if (in_flight || n_req >= p.n_div_requests || cnt * T > mbox_lanes(p.divider) || p.div_lanes[n_req] != cnt * T) return bad("bundle " + std::to_string(b) + ": division request");
             in_flight = true;
             ++n_req;
+            ++stream_req;
         }
         if (cls == C_DIVGET) {
             if (!in_flight) return bad("bundle " + std::to_string(b) + ": collect without a request");
@@ -1141,7 +1403,8 @@ bool validate_program(const Program& p, std::string& err) {
         }
         (void)HI;
     }
-    if (in_flight || n_req != p.n_div_requests || n_get != n_req) return bad("division requests");
+    if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
+    if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)
         if ((w & REF_CONST) ? (w & ~REF_CONST) >= p.n_const : w >= p.n_slots) return bad("witness reference");
     return true;
@@ -1150,7 +1413,9 @@ bool validate_program(const Program& p, std::string& err) {
 // ---- blob ----------------------------------------------------------------------------------------
 static const uint32_t kBlobMagic = 0x47505743u;  // "CWPG"
 struct BlobHeader {
-    uint32_t magic, version, T, G, n_bundles, n_slots, n_const, n_inputs, n_witness, divider, n_div_requests, reserved;
+    uint32_t magic, version, T, G, n_bundles, n_slots, n_const, n_inputs, n_witness, divider, n_div_requests, n_streams;
+    uint32_t stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS];
+    double stream_cycles[MAX_STREAMS], stream_cycles_mul_div[MAX_STREAMS], stream_chain_cycles[MAX_STREAMS];
     ProgramStats stats;
 };
 
@@ -1158,10 +1423,15 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 9;
+    h.version = 10;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
+    h.n_streams = p.n_streams;
+    for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
+        h.stream_first[s] = p.stream_first[s]; h.stream_count[s] = p.stream_count[s]; h.stream_div_requests[s] = p.stream_div_requests[s];
+        h.stream_cycles[s] = p.stream_cycles[s]; h.stream_cycles_mul_div[s] = p.stream_cycles_mul_div[s]; h.stream_chain_cycles[s] = p.stream_chain_cycles[s];
+    }
     h.stats = p.stats;
     std::vector<uint8_t> out((uint8_t*)&h, (uint8_t*)&h + sizeof h);
     auto put = [&](const std::vector<uint32_t>& v) { out.insert(out.end(), (const uint8_t*)v.data(), (const uint8_t*)(v.data() + v.size())); };
@@ -1173,11 +1443,16 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 9 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 10 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;
     p.divider = h.divider; p.n_div_requests = h.n_div_requests;
+    p.n_streams = h.n_streams;
+    for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
+        p.stream_first[s] = h.stream_first[s]; p.stream_count[s] = h.stream_count[s]; p.stream_div_requests[s] = h.stream_div_requests[s];
+        p.stream_cycles[s] = h.stream_cycles[s]; p.stream_cycles_mul_div[s] = h.stream_cycles_mul_div[s]; p.stream_chain_cycles[s] = h.stream_chain_cycles[s];
+    }
     const size_t n_hdr = p.n_bundles, n_recs = (size_t)p.n_bundles * p.G * 4, n_c = (size_t)p.n_bundles * p.G,
                  n_k = (size_t)p.n_const * 8, n_w = p.n_witness, n_d = p.n_div_requests;
     if (len != sizeof h + 4 * (n_hdr + n_recs + n_c + n_k + n_w + n_d)) { err = "program blob size mismatch"; return false; }

@@ -38,6 +38,9 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 struct InterpDims {
     uint32_t n_bundles, n_slots, n_inputs, batch, n_const, n_div_requests;
     const uint32_t* div_lanes;  // active lanes of each division request (divider programs)
+    // streams: interpreter wave w of a workgroup evaluates bundles [stream_first[s], stream_first[s] + stream_count[s]),
+    // s = w % n_streams, of tile w / n_streams (program.hpp); with divider waves, divider d serves interpreter wave d
+    uint32_t n_streams, stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS];
 };
 static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox wait gave up (never expected)
 
@@ -46,6 +49,14 @@ static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox 
 __device__ __forceinline__ bool mbox_wait(const volatile uint32_t* seq, uint32_t need) {
     for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
         if (*seq >= need) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+// Wait for another stream's post (a word in the tile's sync slot, read past the CU's vector cache).  Bounded like mbox_wait.
+__device__ __forceinline__ bool post_wait(uint32_t* word, uint32_t need) {
+    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+        if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
         __builtin_amdgcn_s_sleep(8);
     }
     return false;
@@ -88,7 +99,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const uint32_t n_tiles = (batch + T - 1) / T;
     const uint32_t t = lane % T;
     const uint32_t j = (G == 1) ? 0u : lane / T;
-    const uint32_t tile_raw = blockIdx.x * NW + wave;
+    const uint32_t NS = p.n_streams;  // (1, 2 or 4: NW is a multiple)
+    const uint32_t stream = wave < NW ? wave % NS : 0u;
+    const uint32_t tile_raw = blockIdx.x * (NW / NS) + (wave < NW ? wave : 0u) / NS;
     const uint32_t tile = tile_raw < n_tiles ? tile_raw : n_tiles - 1;  // (divider wave / absent interpreters: any valid tile)
     const uint32_t set = tile * T + t;
     const uint32_t set_c = set < batch ? set : batch - 1;  // padded lanes of the last tile re-evaluate a real set
@@ -98,6 +111,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     char* tile_base = reinterpret_cast<char*>(wst.base[chunk]) + (uint64_t)tile_in_chunk * tile_bytes;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, (int)(uint32_t)tile_bytes, 0x00020000);
     const i32x4 rsrc_rec = make_rsrc_words(recs, (p.n_bundles + REC_AHEAD) * (uint32_t)G * 16u);  // (incl. the zero padding behind the last bundle)
+    uint32_t* const sync_words = reinterpret_cast<uint32_t*>(tile_base + ws_sync_offset(p.n_const, p.n_slots, T));
     static_assert(NW + PACK <= 16, "sequence words: 64 bytes");
     __shared__ uint4 lds[(NW * AREA + (DIVIDER ? NW * MB + 64u : 0u)) / 16];  // the only LDS object: host-computed addresses are offsets into a wave's area
     const uint32_t area = wave * AREA;  // this interpreter wave's LDS area (0 for single-wave workgroups)
@@ -107,18 +121,30 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     char* const mbox_all = reinterpret_cast<char*>(lds) + NW * AREA;        // mailboxes, then the sequence words
     char* const mbox = mbox_all + (wave < NW ? wave : 0u) * MB;             // this interpreter's mailbox
     volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(mbox_all + NW * MB);  // [NW] posted, then [PACK] served
-    if (DIVIDER) {
-        if (threadIdx.x < NW + (uint32_t)PACK) seq[threadIdx.x] = 0;  // sequence words start at zero
+    if (DIVIDER || NW > 1) {
+        if (DIVIDER && threadIdx.x < NW + (uint32_t)PACK) seq[threadIdx.x] = 0;  // sequence words start at zero
+        // programs of several streams: the posts of each stream so far (HDR_POST / HDR_WAIT) live in the tile's sync slot
+        if (NS > 1 && wave < NW && stream == 0 && lane < MAX_STREAMS && tile_raw < n_tiles) {
+            __hip_atomic_store(sync_words + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        // this tile's status words (error bits are OR-ed in at the end, by every stream)
+        if (wave < NW && stream == 0 && j == 0 && tile_raw < n_tiles && set < batch) status[set] = 0;
         __syncthreads();
+    } else {
+        if (j == 0 && tile_raw < n_tiles && set < batch) status[set] = 0;
+    }
+    if (DIVIDER) {
         if (wave >= NW) {
             // ---- divider wave d: serves the division requests of interpreters [d * W, d * W + W) in order
             // (graph.rs:109: b == 0 -> 0).  Request k of every interpreter has the same div_lanes[k] active lanes;
             // they are packed into passes of 64 lanes.
-            const uint32_t first_w = (wave - NW) * WD, first_tile = blockIdx.x * NW + first_w;
+            const uint32_t first_w = (wave - NW) * WD, first_tile = blockIdx.x * (NW / NS) + first_w / NS;
             if (first_tile >= n_tiles) return;
-            const uint32_t n_active = n_tiles - first_tile < WD ? n_tiles - first_tile : WD;  // its interpreters with a tile
+            const uint32_t n_active = NS > 1 ? 1u : n_tiles - first_tile < WD ? n_tiles - first_tile : WD;  // its interpreters with a tile
             char* const mbox_d = mbox_all + first_w * MB;
-            for (uint32_t k = 0; k < p.n_div_requests; ++k) {
+            const uint32_t n_requests = NS > 1 ? p.stream_div_requests[first_w % NS] : p.n_div_requests;  // (streams: W = 1, its one interpreter's)
+            for (uint32_t k = 0; k < n_requests; ++k) {
                 bool ok = true;
                 for (uint32_t w = 0; w < n_active; ++w) ok = ok && mbox_wait(seq + first_w + w, k + 1);
                 if (!ok) {
@@ -153,7 +179,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     }
     if (tile_raw >= n_tiles) return;  // an interpreter wave without a tile (last workgroup)
     uint32_t div_seq = 0;  // requests posted / collected so far (interpreter wave)
-    if (j == 0 && set < batch) status[set] = 0;  // this tile's status words (error bits are OR-ed in at the end)
+    uint32_t n_posts = 0, n_waits = 0;
 
     auto ld = [&](uint32_t off) -> Fr {  // synchronous load of a slot (third operands only)
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
@@ -168,8 +194,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     auto ld_rec2 = [&](uint32_t bundle, uint32_t half) -> uint2 {  // one half of this lane's staged record
         return *reinterpret_cast<const uint2*>(ldsb + LDS_REC_OFF + (bundle % REC_AHEAD) * REC_BYTES + lane16 + 8u * half);
     };
-    const uint32_t NBND = p.n_bundles;
-    if (NBND == 0) return;
+    const uint32_t B0 = p.stream_first[stream], NBND = B0 + p.stream_count[stream];  // this wave's bundles [B0, NBND)
+    if (NBND == B0) return;
     auto clampb = [&](uint32_t b) { return b < NBND ? b : NBND - 1; };
     auto stage_rec = [&](uint32_t bundle) {  // records of `bundle` -> REC ring (the same record for the T lanes of a node slot)
         // (the record array is padded by REC_AHEAD bundles: no clamp)
@@ -227,22 +253,41 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     // issued in iteration b-2, and leaves the 7 operations of iteration b-1 in flight.
     static_assert(OPND_AHEAD == 2 && REC_AHEAD == 4, "the counted waits below are written for this pipeline depth");
 #pragma unroll
-    for (uint32_t q = 0; q < REC_AHEAD; ++q) stage_rec(q);
+    for (uint32_t q = 0; q < REC_AHEAD; ++q) stage_rec(B0 + q);  // (B0 is a multiple of the pipeline depths)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stage_operands(0, ld_rec2(0, 0));
-    stage_operands(1, ld_rec2(1, 0));
-    uint2 rec_hi = ld_rec2(0, 1);  // {dst | ctrl, a_lds | b_lds << 16} of the current bundle
-    uint2 rec_hi_n1 = ld_rec2(1, 1);  // ... of the next one (the record of bundle b+2 is read whole in iteration b)
-    uint32_t h_cur = hdr[0], h_n1 = hdr[clampb(1)];
+    stage_operands(B0, ld_rec2(B0, 0));
+    stage_operands(B0 + 1, ld_rec2(B0 + 1, 0));
+    uint2 rec_hi = ld_rec2(B0, 1);  // {dst | ctrl, a_lds | b_lds << 16} of the current bundle
+    uint2 rec_hi_n1 = ld_rec2(B0 + 1, 1);  // ... of the next one (the record of bundle b+2 is read whole in iteration b)
+    uint32_t h_cur = hdr[B0], h_n1 = hdr[clampb(B0 + 1)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_wave0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-    uint32_t hdr_off_n2 = 8u;  // byte offset of the header two bundles ahead
+    uint32_t hdr_off_n2 = 4u * B0 + 8u;  // byte offset of the header two bundles ahead
     Fr r_prev = fr_zero();  // results of the previous bundle, stored one iteration late (first iteration: zeros -> trash slot)
     uint32_t doff_prev = trash_doff;
-    for (uint32_t b = 0; b < NBND; ++b) {
+    for (uint32_t b = B0; b < NBND; ++b) {
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
         asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if (NW > 1 && (h & (HDR_POST | HDR_WAIT))) {  // (programs of several streams; a handful of bundles)
+            if (h & HDR_POST) {  // the stores of every bundle up to b - 2 are in memory: tell the other waves of the tile
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ++n_posts;
+                if (lane == 0) __hip_atomic_store(sync_words + stream, n_posts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (h & HDR_WAIT) {  // stream 0 waits for every other stream of its tile, the others for stream 0; the loads
+                                 // issued from here on (operands of bundle b + 2, third operands of b) see their values
+                ++n_waits;
+                bool ok = true;
+                if (stream != 0) {
+                    ok = post_wait(sync_words, n_waits);
+                } else {
+                    for (uint32_t s2 = 1; s2 < NS; ++s2)
+                        if (p.stream_count[s2]) ok = ok && post_wait(sync_words + s2, n_waits);
+                }
+                if (!ok) err_bits |= ST_DIVIDER_TIMEOUT;
+            }
+        }
         CWC_STAMP(st1);
         if constexpr (COOP) {
             uint32_t cls_q = h & HDR_CLASS_MASK;
@@ -645,11 +690,22 @@ __global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst,
 // ---- launchers (called from runtime.cc) -----------------------------------------------------------
 hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p,
                          const WsTable& wst, const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
-    const uint32_t tiles = (batch + T - 1) / T, nw = (W ? W : 1u) * pack;
-    if (nw == 0) return hipErrorInvalidValue;
-    dim3 grid((tiles + nw - 1) / nw), block((W ? (W + 1) * pack : pack) * 64);
+    const uint32_t tiles = (batch + T - 1) / T, nw = (W ? W : 1u) * pack, ns = p.n_streams ? p.n_streams : 1u;
+    if (nw == 0 || nw % ns != 0 || (ns > 1 && W > 1)) return hipErrorInvalidValue;
+    const uint32_t tiles_per_wg = nw / ns;
+    dim3 grid((tiles + tiles_per_wg - 1) / tiles_per_wg), block((W ? (W + 1) * pack : pack) * 64);
     const uint4* in = (const uint4*)inputs;
-    const InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes};
+    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
+        dims.stream_first[s] = p.stream_first[s];
+        dims.stream_count[s] = p.stream_count[s];
+        dims.stream_div_requests[s] = p.stream_div_requests[s];
+    }
+    if (ns == 1) {
+        dims.stream_first[0] = 0;
+        dims.stream_count[0] = p.n_bundles;
+        dims.stream_div_requests[0] = n_div_requests;
+    }
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
 #define CWC_LAUNCH3(TT, PP, WW, KK) interp_kernel<TT, PP, WW, KK><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
 #define CWC_LAUNCH2(TT, PP)                                  \
@@ -657,6 +713,7 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     else if (W == 0 && pack == 4) CWC_LAUNCH3(TT, PP, 0, 4); \
     else if (W == 1 && pack == 1) CWC_LAUNCH3(TT, PP, 1, 1); \
     else if (W == 1 && pack == 2) CWC_LAUNCH3(TT, PP, 1, 2); \
+    else if (W == 1 && pack == 4) CWC_LAUNCH3(TT, PP, 1, 4); \
     else if (W == 3 && pack == 1) CWC_LAUNCH3(TT, PP, 3, 1); \
     else if (W == 4 && pack == 1) CWC_LAUNCH3(TT, PP, 4, 1); \
     else return hipErrorInvalidValue;

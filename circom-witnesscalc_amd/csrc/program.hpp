@@ -40,20 +40,31 @@ struct Program {
     std::vector<uint32_t> consts;        // [n_const*8]      Montgomery form
     std::vector<uint32_t> witness_refs;  // [n_witness]      slot or REF_CONST|idx
     std::vector<uint32_t> div_lanes;     // [n_div_requests] active lanes of each division request
+    // Streams: the wavefronts of one tile, each with its own bundles [stream_first[s], stream_first[s] + stream_count[s])
+    // over the graph's independent parts (compile.cc); stream 0 evaluates the Input nodes for all of them.  With a
+    // divider (divider == 1 only) every stream has its own divider wave and serves stream_div_requests[s] requests.
+    uint32_t n_streams = 1;
+    uint32_t stream_first[MAX_STREAMS] = {0, 0, 0, 0}, stream_count[MAX_STREAMS] = {0, 0, 0, 0}, stream_div_requests[MAX_STREAMS] = {0, 0, 0, 0};
+    double stream_cycles[MAX_STREAMS] = {0, 0, 0, 0}, stream_cycles_mul_div[MAX_STREAMS] = {0, 0, 0, 0}, stream_chain_cycles[MAX_STREAMS] = {0, 0, 0, 0};  // lone-wave cycles of each stream's bundles
     ProgramStats stats;
 };
 
 // Validates the graph (backward references, evaluable ops, index ranges) and compiles it for tile width T
 // (power of two, 1..64); divider = W > 0 compiles divisions for a divider wave shared by W interpreter waves (W = 1 or
 // 4, T < 64 only).
-bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err);
+// streams = 2 or 4: the graph's independent parts are spread over that many wavefronts per tile (fewer when it has fewer
+// parts; divider 0 or 1 only).
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams = 1);
 // Validation and statistics of a loaded graph without compiling a program: out.stats, out.n_inputs, out.n_witness.
 bool probe_graph(const Graph& g, Program& out, std::string& err);
 // "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER | KEY_GROUP
 static const uint32_t KEY_DIVIDER = 0x100u;  // one divider wave per interpreter wave
 static const uint32_t KEY_GROUP = 0x200u;    // one divider wave per four interpreter waves
 static const uint32_t KEY_TRIPLE = 0x400u;   // one divider wave per three interpreter waves (a four-wave workgroup: one wave per SIMD)
-static const uint32_t KEY_MODE_MASK = KEY_DIVIDER | KEY_GROUP | KEY_TRIPLE;
+static const uint32_t KEY_STREAMS2 = 0x800u;  // two wavefronts per tile, each over its share of the graph's independent parts
+static const uint32_t KEY_STREAMS4 = 0x1000u; // four
+static const uint32_t KEY_MODE_MASK = KEY_DIVIDER | KEY_GROUP | KEY_TRIPLE | KEY_STREAMS2 | KEY_STREAMS4;
+static inline uint32_t key_streams(uint32_t key) { return key & KEY_STREAMS4 ? 4u : key & KEY_STREAMS2 ? 2u : 1u; }
 static inline uint32_t key_divider_waves(uint32_t key) { return key & KEY_GROUP ? 4u : key & KEY_TRIPLE ? 3u : key & KEY_DIVIDER ? 1u : 0u; }
 static inline uint32_t key_mode_of_divider(uint32_t divider) { return divider == 4 ? KEY_GROUP : divider == 3 ? KEY_TRIPLE : divider ? KEY_DIVIDER : 0u; }
 

@@ -68,6 +68,11 @@ static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_A
 // C_BIT: every lane's second operand is a constant and arrives in canonical (non-Montgomery) form from a second copy in
 // the constant table: the bundle skips that operand's conversion out of Montgomery form
 static const uint32_t HDR_BIT_BCANON = 1u << 14;
+// Programs of several streams (wavefronts of one tile with their own bundle sequences): at the top of such a bundle the
+// wave first posts -- every result of its bundles up to two back is in memory -- and / or waits: a stream other than 0
+// for stream 0's next post, stream 0 for the next post of every other stream.
+static const uint32_t HDR_POST = 1u << 15, HDR_WAIT = 1u << 16;
+static const uint32_t MAX_STREAMS = 4;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;
 static const uint32_t RING_BUNDLES = 4, OPND_AHEAD = 2, REC_AHEAD = 4;
 static const uint32_t RING_SLOT_BYTES = 2048, LDS_HALF_BYTES = 1024, STAGE_BYTES = 4096, REC_BYTES = 1024;
@@ -110,6 +115,7 @@ struct ProgramDev {
     const uint32_t* witness_refs;  // [n_witness]
     const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
+    uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4];  // (program.hpp; MAX_STREAMS entries)
 };
 
 // A launch covers up to WS_MAX_CHUNKS separately allocated workspaces: tile i lives in chunk i / tiles_per_chunk.
@@ -121,9 +127,11 @@ struct WsTable {
 };
 
 // Tile geometry shared by host and kernels.  A tile holds the values of T input sets:
-//   [n_const constant slots | n_slots value slots | trash slot], slot = 32*T bytes = [half][T][16 B].
+//   [n_const constant slots | n_slots value slots | two trash slots | sync slot], slot = 32*T bytes = [half][T][16 B].
 // Each tile has its own buffer descriptor (base = the tile, 32-bit tile-relative offsets), and its own copy of the
-// constants (written once per workspace by fill_consts_kernel), so that every operand is addressed the same way.
-CWC_HD uint64_t ws_tile_bytes(uint32_t n_const, uint32_t n_slots, uint32_t T) { return ((uint64_t)n_const + n_slots + 1u) * 32u * T; }
+// constants (written once per workspace by fill_consts_kernel), so that every operand is addressed the same way.  The
+// sync slot holds the post counters of the tile's streams (programs of several streams).
+CWC_HD uint64_t ws_tile_bytes(uint32_t n_const, uint32_t n_slots, uint32_t T) { return ((uint64_t)n_const + n_slots + 3u) * 32u * T; }
+CWC_HD uint64_t ws_sync_offset(uint32_t n_const, uint32_t n_slots, uint32_t T) { return ((uint64_t)n_const + n_slots + 2u) * 32u * T; }
 
 }  // namespace cwc

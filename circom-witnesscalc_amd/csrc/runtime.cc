@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -108,13 +109,21 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_inputs = p.n_inputs;
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
+    dp.dev.n_streams = p.n_streams;
+    for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
+        dp.dev.stream_first[s] = p.stream_first[s];
+        dp.dev.stream_count[s] = p.stream_count[s];
+        dp.dev.stream_div_requests[s] = p.stream_div_requests[s];
+    }
     return "";
 }
 
 // Interpreter waves per workgroup for programs without a divider wave: workgroups of four deal the waves evenly round
 // the four SIMDs of a CU (kernels.hip); below one wave per SIMD of the chip single-wave workgroups spread further.
 // CWC_WAVES_PER_WORKGROUP (1 or 4) overrides.
-uint32_t waves_per_workgroup(uint32_t divider, uint64_t tiles) {
+uint32_t waves_per_workgroup(uint32_t divider, uint64_t tiles, uint32_t streams = 1) {
+    // programs of several streams: the streams of a tile (and their divider waves) are one workgroup
+    if (streams > 1) return divider ? streams : 4u;
     const char* e = getenv("CWC_WAVES_PER_WORKGROUP");
     if (divider == 1) return e ? (atoi(e) >= 4 ? 2u : 1u) : (tiles > 256 ? 2u : 1u);  // units of (interpreter + divider)
     if (divider) return 1;
@@ -240,6 +249,23 @@ double estimate_cycles(const Program& p, size_t batch) {
     // (tiles of 8 sets and more: their bundles measure ~10 % above the per-class table, which was taken at T = 2 --
     // round 2, authV2-class: 8192 sets T = 4 41.2 ms, T = 8 44.2 ms, T = 8 + group divider 45.0 ms; 16384 sets T = 8 69.2 ms)
     const double wide = p.T >= 8 ? 1.10 : 1.0;
+    if (p.n_streams > 1) {
+        // Programs of several streams (round 2, authV2-class, profiles/r02_streams_ab.txt): a tile is done when its slowest
+        // stream is -- the longer of its bundles' cycles and its longest dependent chain with the divisions at the
+        // divider wave's latency; measured / modelled 0.98 at T = 1, 1.08 at T = 2, 1.2 at T = 4.  The streams of a
+        // tile and their divider waves are one workgroup: with dividers 98 KiB of LDS for four streams (one workgroup
+        // per CU, 256 tiles at a time), 49 KiB for two; without, four waves of 20 KiB.  More live waves than SIMDs
+        // (2 x 512 tiles + dividers measured x1.3) slow each other down.
+        const double tiles = (double)((batch + p.T - 1) / p.T);
+        const double t = program_wave_cycles(p);
+        double busy = 0;  // SIMDs' worth of work per tile: every stream and divider wave for the share of t it is busy
+        for (uint32_t s = 0; s < p.n_streams; ++s) busy += (p.stream_cycles[s] + 73500.0 * p.stream_div_requests[s]) / t;
+        const double wgs = p.divider ? tiles : std::ceil(tiles * p.n_streams / 4.0);
+        const double wg_per_cu = p.divider ? (p.n_streams == 4 ? 1.0 : 3.0) : 2.0;
+        const double rounds = std::max(1.0, wgs / (256.0 * wg_per_cu));
+        const double crowd = std::max(1.0, 1.1 * (tiles / rounds) * busy / 1024.0);
+        return t * (p.T >= 4 ? 1.2 * wide : p.T == 2 ? 1.08 : 1.0) * crowd * rounds;
+    }
     const double per_wave = program_wave_cycles(p) * wide;
     const double heavy = program_wave_cycles_mul_div(p) * wide;
     const double waves = (double)((batch + p.T - 1) / p.T);
@@ -277,8 +303,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
         while (min_t < 16 && (double)g->stats.depth * 1.25 * (4.0 + (per_bundle_t1 - 4.0) / min_t) > budget * 1048576.0) min_t *= 2;
         if ((rule & ~KEY_MODE_MASK) < min_t) rule = min_t | ((rule & KEY_MODE_MASK) && min_t < 64 ? (rule & KEY_MODE_MASK) : 0u);
     }
-    // tiny batches (the single-shot entry point): one tile either way, not worth compiling candidates
-    if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph || batch < 64) return rule;
+    if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph) return rule;
     auto hit = g->chosen.find(batch);
     if (hit != g->chosen.end()) return hit->second;
     size_t divider_tiles = 1024;
@@ -289,7 +314,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     uint32_t best = rule;
     double best_cost = -1;
     std::vector<uint32_t> keys;
-    for (uint32_t t = std::max(min_t, t0 >= 4 ? t0 / 4 : 1u); t <= t0 * 2 && t <= 32; t *= 2)
+    for (uint32_t t = std::max(min_t, t0 >= 4 ? t0 / 4 : 1u); t <= t0 * 2 && t <= 32 && (batch >= 64 || t == t0); t *= 2)  // (tiny batches: one tile either way)
         for (uint32_t mode : {0u, KEY_DIVIDER, KEY_TRIPLE, KEY_GROUP}) {
             const size_t tiles = (batch + t - 1) / t;
             if (tiles > 4 * 2048) continue;
@@ -301,6 +326,12 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
             if (mode == KEY_TRIPLE && !(has_div && tiles > 512 && tiles <= 768 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
             if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
             keys.push_back(t | mode);
+            // the graph's independent parts on wavefronts of their own (streams): while every stream of every tile has
+            // a SIMD to itself (small batches, the single-shot entry point)
+            if ((mode == 0 || mode == KEY_DIVIDER) && t < 64 && !getenv("CWC_NO_STREAMS")) {
+                if (tiles <= 256) keys.push_back(t | mode | KEY_STREAMS4);
+                else if (tiles <= 340) keys.push_back(t | mode | KEY_STREAMS2);
+            }
         }
     // the candidates that are not compiled yet, each on a thread of its own (the compiler only reads the graph)
     std::vector<std::pair<uint32_t, std::future<std::unique_ptr<Program>>>> jobs;
@@ -310,7 +341,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
             jobs.emplace_back(key, std::async(std::launch::async, [graph, key]() {
                                   std::unique_ptr<Program> p(new Program());
                                   std::string err;
-                                  if (!compile_program(*graph, key & ~KEY_MODE_MASK, key_divider_waves(key), *p, err)) p.reset();
+                                  if (!compile_program(*graph, key & ~KEY_MODE_MASK, key_divider_waves(key), *p, err, key_streams(key))) p.reset();
                                   return p;
                               }));
         }
@@ -351,7 +382,7 @@ std::string get_program(gwb_graph* g, uint32_t key, DeviceProgram** out) {
     if (pre != g->compiled.end()) {  // already compiled for the cost model
         dp->host = std::move(*pre->second);
         g->compiled.erase(pre);
-    } else if (!compile_program(g->graph, T, key_divider_waves(key), dp->host, err)) {
+    } else if (!compile_program(g->graph, T, key_divider_waves(key), dp->host, err, key_streams(key))) {
         return err;
     }
     err = upload_program(*dp);
@@ -419,6 +450,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     g->timing = gwb_timing_t{};
     g->timing.tile_width = T;
     g->timing.divider = p.divider;
+    g->timing.streams = p.n_streams;
     g->timing.n_bundles = p.n_bundles;
     g->timing.n_slots = p.n_slots;
     const size_t launch_sets = per_launch * chunk_sets;
@@ -444,7 +476,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         }
         g->pending.push_back(gwb_graph::ChunkEvents{e0, e1, e2});  // (owned by the handle from here on, also on an early return)
         HIP_TRY(hipEventRecord(e0, stream));
-        HIP_TRY(launch_interp(T, p.divider, waves_per_workgroup(p.divider, (nb + T - 1) / T), p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
+        HIP_TRY(launch_interp(T, p.divider, waves_per_workgroup(p.divider, (nb + T - 1) / T, p.n_streams), p.n_div_requests, dp->dev.div_lanes, dp->dev, wst, (const char*)d_inputs + s0 * p.n_inputs * 32, d_status + s0, nb, stream, g->d_prof));
         HIP_TRY(hipEventRecord(e1, stream));
         HIP_TRY(launch_pack(T, dp->dev, wst, (char*)d_witness + s0 * (size_t)p.n_witness * 32, nb, stream, montgomery));
         HIP_TRY(hipEventRecord(e2, stream));
@@ -786,8 +818,9 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
 
 int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
     const uint32_t T = key & ~KEY_MODE_MASK;
-    const uint32_t mode = key & KEY_MODE_MASK;
-    if (!g || T > 64 || (T & (T - 1)) || (mode && T == 0) || (mode & (mode - 1))) return 1;  // (at most one divider mode)
+    const uint32_t mode = key & (KEY_DIVIDER | KEY_GROUP | KEY_TRIPLE), smode = key & (KEY_STREAMS2 | KEY_STREAMS4);
+    if (!g || T > 64 || (T & (T - 1)) || ((mode | smode) && T == 0) || (mode & (mode - 1)) || (smode & (smode - 1))) return 1;  // (at most one divider mode, one stream count)
+    if (smode && (mode & (KEY_GROUP | KEY_TRIPLE))) return 1;  // (streams have a divider wave each, or none)
     g->forced_T = key;
     return 0;
 }
@@ -968,7 +1001,7 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
         p = &it->second->host;
     } else {
         if (!g->has_graph) return fail(status, "imported handle has no program for that tile width");
-        if (!compile_program(g->graph, T & ~KEY_MODE_MASK, key_divider_waves(T), tmp, err)) return fail(status, err);
+        if (!compile_program(g->graph, T & ~KEY_MODE_MASK, key_divider_waves(T), tmp, err, key_streams(T))) return fail(status, err);
         p = &tmp;
     }
     std::vector<uint8_t> b = program_to_blob(*p);

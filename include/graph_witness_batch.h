@@ -42,7 +42,7 @@ typedef struct {
   float interp_ms;           /* HIP-event time of the interpreter kernel(s), on the launch stream */
   float pack_ms;             /* HIP-event time of the witness pack kernel(s) */
   uint32_t divider;          /* interpreter waves per divider wave in the last call's programs: 0 (none), 1 or 4 */
-  uint32_t reserved;
+  uint32_t streams;          /* wavefronts per tile in the last call's program (1, or 2 / 4: GWB_TILE_STREAMS*) */
 } gwb_timing_t;
 
 /* Parse + validate a `wtns.graph.001` image (deserialize_witnesscalc_graph, src/storage.rs:214-249). */
@@ -75,6 +75,13 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
 /* ... or with GWB_TILE_TRIPLE_DIVIDER = one divider wave per THREE interpreter waves: a four-wave workgroup, one wave on
  * every SIMD of its CU, so 768 tiles run at the speed of one (the choice for 513..768 tiles). */
 #define GWB_TILE_TRIPLE_DIVIDER 0x400u
+/* ... and / or with GWB_TILE_STREAMS2 / GWB_TILE_STREAMS4 = two / four wavefronts per tile, each evaluating its share of
+ * the graph's independent parts (components that share nothing beyond a short prologue behind the inputs) with a bundle
+ * sequence of its own: the small-batch / single-call regime, where there are more SIMDs than tiles.  Combines with no
+ * divider or GWB_TILE_ASYNC_DIVIDER (every stream then has a divider wave of its own).  A graph that is one piece
+ * compiles to the single-stream program. */
+#define GWB_TILE_STREAMS2 0x800u
+#define GWB_TILE_STREAMS4 0x1000u
 /* 0 = choose from the batch size (default); else a program key */
 int gwb_set_tile_width(gwb_graph_t *g, uint32_t tile_width);
 /* the program key the static rule names for a batch of this size (no graph needed) */

@@ -19,7 +19,8 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I38Q"
+HDR_FMT = "<12I12I12d38Q"
+HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
 COOP_LANES, COOP_MAX_T = 4, 4
@@ -29,8 +30,13 @@ class Blob:
     def __init__(self, data):
         h = struct.unpack_from(HDR_FMT, data, 0)
         (self.magic, self.version, self.T, self.G, self.n_bundles, self.n_slots, self.n_const, self.n_inputs,
-         self.n_witness, self.divider, self.n_div_requests, _res) = h[:12]
-        st = h[12:]
+         self.n_witness, self.divider, self.n_div_requests, self.n_streams) = h[:12]
+        self.stream_first, self.stream_count, self.stream_div_requests = h[12:16], h[16:20], h[20:24]
+        self.stream_cycles = h[24:28]
+        assert self.n_streams in (1, 2, 3, 4) and all(f % 4 == 0 for f in self.stream_first[:self.n_streams])
+        assert sum(self.stream_div_requests[:self.n_streams]) == self.n_div_requests
+        assert self.n_streams == 1 or self.divider in (0, 1), "streams have a divider wave each, or none"
+        st = h[36:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
                           class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34], n_folded=st[35], n_numbered=st[36], n_shaken=st[37])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
@@ -64,29 +70,55 @@ def run(blob: Blob, inputs_row):
     NC = blob.n_const
     trash = (NC + blob.n_slots) * slot_bytes
     zero_off = (NC - 1) * slot_bytes
-    history = {}  # value slot -> list of (bundle that stored, value)
+    history = {}  # value slot -> list of (stream, bundle that stored, value)
     status = 0
-    ring = {}     # (ring cell, node slot) -> (bundle that wrote it, value)
-    mailbox = None  # operands of the division request in flight (asynchronous divider programs)
-    n_requests = 0
+    # Streams (wavefronts of the tile with their own bundle ranges) run at their own pace; what orders them is stream
+    # 0's post (every result of its bundles up to two back is in memory) and the wait in the first bundle of every
+    # other stream.  A slot belongs to the stream that writes it; another stream may read it only if it was written
+    # once, before the post, and the read is issued behind the wait.
+    post_at = None
+    for b in range(blob.stream_first[0], blob.stream_first[0] + blob.stream_count[0]):
+        if blob.hdr[b] & HDR_POST:
+            assert post_at is None
+            post_at = b
+    assert (post_at is not None) == (blob.n_streams > 1)
 
-    def mem_at(off, as_of_bundle):
-        """content of the tile at byte offset off, after the stores of bundles <= as_of_bundle"""
+    def mem_at(off, as_of_bundle, stream, issued_at):
+        """content of the tile at byte offset off, after the stores of the stream's bundles <= as_of_bundle; the load
+        is issued at the top of bundle `issued_at`"""
         assert off % slot_bytes == 0
         s_ = off // slot_bytes
         if s_ < NC:
             return blob.consts[s_]
         assert s_ < NC + blob.n_slots, "operand read from the trash slot"
-        for wb, val in reversed(history[s_ - NC]):
+        hist = history[s_ - NC]
+        if hist[0][0] != stream:
+            # (the slot may have held earlier values of stream 0; its last store is the one every other stream sees)
+            assert hist[0][0] == 0 and stream != 0, "only values of stream 0 cross streams"
+            assert hist[-1][1] <= post_at - 2 and issued_at >= blob.stream_first[stream], "cross-stream read outside the post / wait order"
+            cross_reads.add(s_ - NC)
+            return hist[-1][2]
+        for _, wb, val in reversed(hist):
             if wb <= as_of_bundle:
                 return val
         raise AssertionError("slot read before it was written")
 
-    for b in range(blob.n_bundles):
+    n_requests_total = 0
+    cross_reads = set()  # slots of stream 0 that other streams read: never written again behind the post
+    bundles = [(s_, b) for s_ in range(blob.n_streams) for b in range(blob.stream_first[s_], blob.stream_first[s_] + blob.stream_count[s_])]
+    assert blob.stream_first[0] == 0 and all(blob.stream_first[k] >= blob.stream_first[k - 1] + blob.stream_count[k - 1] for k in range(1, blob.n_streams))
+    assert blob.stream_first[blob.n_streams - 1] + blob.stream_count[blob.n_streams - 1] == blob.n_bundles
+    for stream, b in bundles:
+        if b == blob.stream_first[stream]:
+            ring = {}     # (ring cell, node slot) -> (bundle that wrote it, value)
+            mailbox = None  # operands of the division request in flight (asynchronous divider programs)
+            n_requests = 0
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
-        assert h >> 15 == 0 and 1 <= cnt <= G
         name = CLASS_NAMES[cls]
+        assert h >> 17 == 0 and (1 <= cnt <= G or (cnt == 0 and name == "LIN"))
+        assert bool(h & HDR_WAIT) == (blob.n_streams > 1 and stream != 0 and b == blob.stream_first[stream])
+        assert not (h & HDR_POST) or (stream == 0 and blob.n_streams > 1)
         # narrow multiplication bundle: four lanes per product, a node's record sits at positions 4j .. 4j+3 and its
         # value t + T * j is staged by lane 4 * T * j + t
         rep = COOP_LANES if name == "MULQ" else 1
@@ -120,7 +152,7 @@ def run(blob: Blob, inputs_row):
                         assert off % slot_bytes == 0 and off // slot_bytes < NC, "canonical second operands are constants"
                         ops.append(blob.consts_raw[off // slot_bytes])  # canonical copy: no conversion in the kernel
                     else:
-                        ops.append(mem_at(off, b - OPND_AHEAD - 1))
+                        ops.append(mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD))
                 else:
                     assert off == zero_off, "ring operand must stage the zero constant"
                     rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
@@ -141,7 +173,7 @@ def run(blob: Blob, inputs_row):
             elif name == "INPUT":
                 v = inputs_row[blob.crefs[b * G + j]] % model.M
             elif name == "TERN":
-                v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1))
+                v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1, stream, b))
             else:
                 op = SUB_NAMES[name][sub]
                 assert op is not None
@@ -158,8 +190,9 @@ def run(blob: Blob, inputs_row):
             results.append((dst, v))
         if name == "DIVREQ":
             mailbox = request
-            assert blob.div_lanes[n_requests] == cnt * T <= (64 if blob.divider == 1 else 32), "request must fit the mailbox"
+            assert blob.div_lanes[n_requests_total] == cnt * T <= (64 if blob.divider == 1 else 32), "request must fit the mailbox"
             n_requests += 1
+            n_requests_total += 1
         elif name == "DIVGET":
             mailbox = None
         else:
@@ -168,21 +201,27 @@ def run(blob: Blob, inputs_row):
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
             assert ((h >> 13) & 1) == (1 if all_x else 0), "BITX header bit must describe the records"
         else:
-            assert (h >> 13) == 0
+            assert ((h >> 13) & 3) == 0
         assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
         for d, v in results:
             assert d % slot_bytes == 0 and NC * slot_bytes <= d <= trash
             if d != trash:
-                history.setdefault(d // slot_bytes - NC, []).append((b, v))
+                hist = history.setdefault(d // slot_bytes - NC, [])
+                assert not hist or hist[0][0] == stream, "a slot is written by one stream only"
+                hist.append((stream, b, v))
         for j, (_, v) in enumerate(results):
             ring[(b % RING_BUNDLES, j)] = (b, v)
         for j in range(cnt if name != "DIVREQ" else 0, G):
             ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
 
-    assert mailbox is None and n_requests == blob.n_div_requests
+        if b == blob.stream_first[stream] + blob.stream_count[stream] - 1:
+            assert mailbox is None and n_requests == blob.stream_div_requests[stream]
+    assert n_requests_total == blob.n_div_requests
+    for slot in cross_reads:
+        assert history[slot][-1][1] <= post_at - 2, "a slot that other streams read is written again behind the post"
 
     def wit(r):
-        return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else history[r][-1][1]
+        return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else history[r][-1][2]
     return [wit(r) for r in blob.witness_refs], status

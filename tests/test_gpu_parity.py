@@ -695,3 +695,42 @@ def test_single_shot_cache_distinguishes_graphs_of_equal_length(pkg):
     for _ in range(2):
         assert pkg.calc_witness('{"x": "7"}', d1)[1] == 1049
         assert pkg.calc_witness('{"x": "7"}', d2)[1] == 2049
+
+
+STREAMS2, STREAMS4 = 0x800, 0x1000  # GWB_TILE_STREAMS2 / GWB_TILE_STREAMS4
+
+
+@pytest.mark.gpu
+def test_streams_two_and_four_wavefronts_per_tile(pkg):
+    """Programs of several streams (the graph's independent parts on wavefronts of their own, posts / waits through the
+    tile's sync slot, a divider wave per stream): every key gives the witnesses of the C oracle on the authV2-class graph
+    at a ragged batch size, on a graph that is one piece (compiles to one stream) and on fuzzed DAGs with panicking sets;
+    the automatic choice for a small batch is a stream program and agrees too."""
+    data = C.build_authv2_class(scale=0.15).to_bin()
+    g = pkg.Graph(data)
+    og = cbind.Graph(data)
+    rows = _synth("field", g.n_inputs, 77, 5)
+    want, wst = og.evaluate_batch(rows)
+    assert not wst.any()
+    for key in (1 | STREAMS4, 1 | DIVIDER | STREAMS4, 2 | DIVIDER | STREAMS2, 2 | STREAMS2, 4 | DIVIDER | STREAMS4, 8 | STREAMS4, 16 | DIVIDER | STREAMS2):
+        g.set_tile_width(key)
+        got, st = g.calc_witness_batch(rows)
+        tm = g.last_timing()
+        assert tm["streams"] == (4 if key & STREAMS4 else 2) and tm["tile_width"] == key & 0xff, key
+        assert not st.any() and np.array_equal(got, want), key
+    g.set_tile_width(0)
+    got, st = g.calc_witness_batch(rows)
+    assert g.last_timing()["streams"] > 1 and not st.any() and np.array_equal(got, want)
+    one, st1 = g.calc_witness_batch(rows[:1])  # (the single-call shape: one tile)
+    assert not st1.any() and np.array_equal(one, want[:1])
+    for seed in range(4):
+        data = C.build_random_dag(400 + seed, n_ops=600, panic_free=False).to_bin()
+        g2, o2 = pkg.Graph(data), cbind.Graph(data)
+        rows2 = cbind.ints_to_array([[1] + [random.Random(seed * 100 + i).randrange(model.M) for _ in range(g2.n_inputs - 1)] for i in range(40)])
+        want2, wst2 = o2.evaluate_batch(rows2)
+        for key in (1 | STREAMS4, 2 | DIVIDER | STREAMS2, 4 | STREAMS4):
+            g2.set_tile_width(key)
+            got2, st2 = g2.calc_witness_batch(rows2)
+            assert np.array_equal(st2 != 0, wst2 != 0), (seed, key)
+            ok = wst2 == 0
+            assert np.array_equal(got2[ok], want2[ok]), (seed, key)

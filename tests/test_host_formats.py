@@ -153,10 +153,13 @@ def test_wtns_framing(pkg):
 DIVIDER = 0x100  # GWB_TILE_ASYNC_DIVIDER: programs for the asynchronous divider wave
 GROUP = 0x200    # GWB_TILE_GROUP_DIVIDER: one divider wave per four interpreter waves
 TRIPLE = 0x400   # GWB_TILE_TRIPLE_DIVIDER: one divider wave per three interpreter waves
+STREAMS2 = 0x800   # GWB_TILE_STREAMS2: two wavefronts per tile, each over its share of the graph's independent parts
+STREAMS4 = 0x1000  # GWB_TILE_STREAMS4: four
 
 
 @pytest.mark.parametrize("tile", [1, 2, 4, 8, 16, 32, 64, 1 | DIVIDER, 2 | DIVIDER, 8 | DIVIDER, 32 | DIVIDER,
-                                  1 | GROUP, 4 | GROUP, 32 | GROUP, 1 | TRIPLE, 2 | TRIPLE, 16 | TRIPLE])
+                                  1 | GROUP, 4 | GROUP, 32 | GROUP, 1 | TRIPLE, 2 | TRIPLE, 16 | TRIPLE,
+                                  2 | STREAMS2, 1 | DIVIDER | STREAMS4, 4 | DIVIDER | STREAMS2, 8 | STREAMS4])
 def test_graph_compiler_emulated(pkg, tile):
     """Level scheduling, bundling, slot reuse and operand encoding for every tile width and both division
     strategies (host logic only)."""
@@ -170,6 +173,7 @@ def test_graph_compiler_emulated(pkg, tile):
         g = pkg.Graph(data)
         blob = pe.Blob(g.export_blob(key))
         assert blob.T == tile and blob.n_witness == len(wit) and blob.divider == (1 if key & DIVIDER else 4 if key & GROUP else 3 if key & TRIPLE else 0)
+        assert blob.n_streams in ((1, 2) if key & STREAMS2 else (1, 4) if key & STREAMS4 else (1,))
         n_div = sum(1 for n in nodes if n[0] == "Duo" and n[1] == "Div")
         gone = blob.stats["n_folded"] + blob.stats["n_numbered"] + blob.stats["n_shaken"]  # (the load-time optimiser may remove divisions)
         if key & (DIVIDER | GROUP | TRIPLE):
@@ -263,6 +267,33 @@ def test_power_of_two_division_rewrite_is_exact(pkg):
         assert pe.run(blob, [1, xv])[0] == model.evaluate(nodes, [1, xv], wit)
 
 
+@pytest.mark.parametrize("key", [1 | STREAMS4, 2 | DIVIDER | STREAMS4, 4 | DIVIDER | STREAMS2, 8 | STREAMS2, 2 | STREAMS2])
+def test_streams_split_the_independent_parts_of_a_graph(pkg, key):
+    """Programs of several streams (one wavefront per stream and tile): the authV2-class graph has four large independent
+    parts behind a short shared prologue.  The emulator runs every stream's bundles and checks what the kernel relies on:
+    a slot is written by one stream only, a value crosses streams only from stream 0's prologue, written once, before its
+    post and read behind the reader's wait; the witnesses equal the big-int oracle's."""
+    b = C.build_authv2_class(scale=0.08)
+    data = b.to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    g = pkg.Graph(data)
+    blob = pe.Blob(g.export_blob(key))
+    want_streams = 4 if key & STREAMS4 else 2
+    assert blob.n_streams == want_streams and sum(1 for c in blob.stream_count[:want_streams] if c) >= 2
+    assert sum(blob.stream_count[:blob.n_streams]) <= blob.n_bundles < sum(blob.stream_count[:blob.n_streams]) + 4 * blob.n_streams
+    inputs = C.authv2_reference_inputs()
+    rnd = random.Random(key)
+    for trial in range(2):
+        row = [1]
+        for name, n in C.AUTHV2_INPUTS:
+            row += [v if trial == 0 else rnd.randrange(model.M) for v in inputs[name][:n]] + [0] * (n - len(inputs[name][:n]))
+        got, st = pe.run(blob, row)
+        assert st == 0 and got == model.evaluate(nodes, row, wit)
+    # a graph that is one piece keeps one stream
+    one = pkg.Graph(C.build_sha256(64).to_bin())
+    assert pe.Blob(one.export_blob(key)).n_streams == 1
+
+
 @pytest.mark.parametrize("key", [2, 2 | DIVIDER, 16, 4 | GROUP, 2 | TRIPLE])
 def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
     """Tree-height reduction, shared subexpressions, dead-node elimination, linear riders in multiplication bundles and
@@ -347,12 +378,12 @@ def test_schedule_quality_guard(pkg):
     g = pkg.Graph(C.build_authv2_class().to_bin())
     blob = g.export_blob(2 | DIVIDER)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[12:][18:30]))
+    cb = dict(zip(pe.CLASS_NAMES, h[36:][18:30]))
     est = sum(cyc[k] * v for k, v in cb.items())
     assert est <= 31.5e6 and cb["MULQ"] >= 3000 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0, (est, cb)
     blob = g.export_blob(4)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[12:][18:30]))
+    cb = dict(zip(pe.CLASS_NAMES, h[36:][18:30]))
     assert h[4] <= 27500 and cb["DIV"] <= 275
     g = pkg.Graph(C.build_sha256(512).to_bin())
     h = struct.unpack_from(pe.HDR_FMT, g.export_blob(1), 0)
