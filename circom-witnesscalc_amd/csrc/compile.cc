@@ -361,11 +361,167 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
     g.nodes.swap(kept);
 }
 
+// ---- representation inference ------------------------------------------------------------------------------------
+// The interpreter keeps field elements in Montgomery form (x * 2^256 mod r); the integer operations of the reference
+// (shifts, bit operations, Idiv / Mod, ordered comparisons: src/graph.rs:112-133, 621-769) work on the canonical integer,
+// and a bundle of them spends most of its time converting: two operands out of Montgomery form, the result back in
+// (three products around a few dozen instructions of integer work).  Graphs that compute on limbs and bits (bigint /
+// long-division circuits, range checks) chain such operations through additions and multiplications, none of which
+// cares about the form: a + b and a - b hold in either form, and the Montgomery product of a canonical and a Montgomery
+// operand IS the canonical product.  So every value gets ONE form, Montgomery (REP_M) or canonical (REP_C):
+//   Input -> M.  Add / Sub / Neg / TernCond results: the common form of their operands.  Mul: (M, M) -> M, (M, C) -> C.
+//   Integer operations and comparisons read either form (per-bundle header bits say which operands still need the
+//   conversion) and write the form their users prefer.  Div: Montgomery operands, Montgomery result.
+// Where the forms of two operands do not fit (Add of an M and a C value, Mul of two C values, ...) one of them is
+// converted by an inserted multiplication with a constant: x_M * (2^-256)_M = x_C, x_C * (2^256)_M = x_M; a value is
+// converted at most once per direction.  Constants serve either form (the table holds canonical copies where needed).
+// Graphs without integer chains come out all-Montgomery, as before.
+static const uint8_t REP_M = 0, REP_C = 1;
+static const uint8_t VF_A_CANON = 1, VF_B_CANON = 2, VF_OUT_CANON = 4;
+static bool is_integer_class(int c) { return c == C_BIT || c == C_IDIVMOD || c == C_CMPS; }
+static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery) {
+    const size_t N = g.nodes.size();
+    const bool off = all_montgomery || getenv("CWC_NO_REP_INFERENCE") != nullptr;
+    // what the users of a value would rather read: > 0 canonical
+    std::vector<float> pref(N, 0.0f);
+    for (size_t i = N; !off && i-- > 0;) {
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (!ar) continue;
+        const int c = class_of(n);
+        float w = 0.0f;
+        if (is_integer_class(c)) w = 1.0f;
+        else if (c == C_DIV) w = -1.0f;
+        else if (c == C_LIN || c == C_MUL || c == C_TERN) w = 0.5f * std::max(-2.0f, std::min(2.0f, pref[i]));
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = (c == C_TERN ? 1 : 0); q < ar; ++q)  // (TernCond tests its first operand for zero: either form)
+            if (!(c == C_BIT && n.op == OP_BITX && q == 1) && g.nodes[ops[q]].kind != N_CONST) pref[ops[q]] += w;
+    }
+    std::vector<Node> out;
+    out.reserve(N + N / 8);
+    std::vector<uint32_t> at(N, 0xffffffffu);            // old node -> new index
+    std::vector<uint32_t> converted(N, 0xffffffffu);     // old node -> new index of its value in the other form
+    std::vector<uint8_t> orep(N, REP_M);
+    rep.clear();
+    vflags.clear();
+    uint32_t k_to_c = 0xffffffffu, k_to_m = 0xffffffffu;  // constant nodes 2^-256 and 2^256 mod r
+    auto emit = [&](const Node& n, uint8_t r, uint8_t f) -> uint32_t {
+        out.push_back(n);
+        rep.push_back(r);
+        vflags.push_back(f);
+        return (uint32_t)out.size() - 1;
+    };
+    auto konst = [&](bool to_c) -> uint32_t {
+        uint32_t& k = to_c ? k_to_c : k_to_m;
+        if (k == 0xffffffffu) {
+            // 2^256 mod r and its inverse (canonical values; the table holds their Montgomery forms 2^512 mod r and 1)
+            const Fr r1 = Fr{{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u}};
+            const Fr rinv = fr_from_mont(fr_from_mont(r1));  // ((2^256 * 2^-256) * 2^-256) = 2^-256
+            g.const_values.push_back(to_c ? rinv : r1);
+            k = emit(Node{N_CONST, 0, (uint32_t)g.const_values.size() - 1, 0, 0}, REP_M, 0);
+        }
+        return k;
+    };
+    auto is_const = [&](uint32_t o) { return g.nodes[o].kind == N_CONST; };
+    // operand o (old index) in form `want`; constants serve either form
+    auto get = [&](uint32_t o, uint8_t want) -> uint32_t {
+        if (is_const(o) || orep[o] == want) return at[o];
+        if (converted[o] == 0xffffffffu) {
+            const uint32_t k = konst(want == REP_C);
+            converted[o] = emit(Node{N_DUO, OP_MUL, at[o], k, 0}, want, 0);
+            ++n_conversions;
+        }
+        return converted[o];
+    };
+    for (size_t i = 0; i < N; ++i)  // constants first: the rewrites append theirs behind their users
+        if (g.nodes[i].kind == N_CONST) at[i] = emit(g.nodes[i], REP_M, 0);
+    for (size_t i = 0; i < N; ++i) {
+        Node n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        const int ar = arity_of(n);
+        const int c = class_of(n);
+        uint8_t r = REP_M, f = 0;
+        if (ar && !off) {
+            const bool want_c = pref[i] > 0.0f;
+            auto form_of = [&](uint32_t o, uint8_t if_const) -> uint8_t { return is_const(o) ? if_const : orep[o]; };
+            if (is_integer_class(c) || c == C_CMPZ) {
+                if (is_integer_class(c)) {
+                    f |= form_of(n.a, REP_C) == REP_C ? VF_A_CANON : 0;
+                    f |= (n.op == OP_BITX || form_of(n.b, REP_C) == REP_C) ? VF_B_CANON : 0;
+                    n.a = at[n.a];
+                    n.b = at[n.b];
+                } else if (n.op == OP_EQ || n.op == OP_NEQ) {  // equal forms on both sides (a constant follows the other side)
+                    const uint8_t side = is_const(n.a) ? form_of(n.b, REP_M) : orep[n.a];
+                    n.a = get(n.a, side);
+                    n.b = get(n.b, side);
+                    f |= side == REP_C ? VF_A_CANON : 0;  // (not a header bit for this class: which copy of a constant operand is read)
+                } else {  // Land / Lor: zero tests
+                    n.a = at[n.a];
+                    n.b = at[n.b];
+                }
+                r = want_c ? REP_C : REP_M;
+                f |= want_c ? VF_OUT_CANON : 0;
+            } else if (c == C_MUL) {
+                uint8_t ra = form_of(n.a, REP_M), rb = form_of(n.b, REP_M);
+                if (is_const(n.a) != is_const(n.b)) {  // x * constant: the constant in Montgomery form keeps x's form
+                    r = is_const(n.a) ? rb : ra;
+                    n.a = at[n.a];
+                    n.b = at[n.b];
+                } else {
+                    if (ra == REP_C && rb == REP_C) {  // one factor into Montgomery form: the one that is already converted, else the second
+                        if (!is_const(n.a) && converted[n.a] != 0xffffffffu) ra = REP_M;
+                        else rb = REP_M;
+                    }
+                    n.a = get(n.a, ra);
+                    n.b = get(n.b, rb);
+                    r = (ra == REP_C || rb == REP_C) ? REP_C : REP_M;
+                }
+            } else if (c == C_DIV) {
+                n.a = get(n.a, REP_M);
+                n.b = get(n.b, REP_M);
+            } else if (c == C_LIN || c == C_TERN) {
+                const uint32_t x = n.kind == N_UNO ? n.a : n.kind == N_TRES ? n.b : n.a, y = n.kind == N_UNO ? n.a : n.kind == N_TRES ? n.c : n.b;
+                uint8_t side;
+                if (is_const(x) && is_const(y)) side = want_c ? REP_C : REP_M;
+                else if (is_const(x)) side = orep[y];
+                else if (is_const(y)) side = orep[x];
+                else if (orep[x] == orep[y]) side = orep[x];
+                else side = want_c ? REP_C : REP_M;
+                if (n.kind == N_UNO) {
+                    n.a = get(n.a, side);
+                } else if (n.kind == N_TRES) {
+                    n.a = at[n.a];
+                    n.b = get(n.b, side);
+                    n.c = get(n.c, side);
+                } else {
+                    n.a = get(n.a, side);
+                    n.b = get(n.b, side);
+                }
+                r = side;
+            }
+        } else if (ar) {
+            n.a = at[n.a];
+            if (ar >= 2) n.b = at[n.b];
+            if (ar >= 3) n.c = at[n.c];
+            if (is_integer_class(c)) f = (uint8_t)((is_const(g.nodes[i].a) ? VF_A_CANON : 0) | ((n.op == OP_BITX || is_const(g.nodes[i].b)) ? VF_B_CANON : 0));
+        }
+        orep[i] = r;
+        n_canonical += ar && r == REP_C;
+        at[i] = emit(n, r, f);
+    }
+    for (uint32_t& w : g.witness_signals) w = at[w];
+    g.nodes.swap(out);
+}
+
 // Lone-wave shader cycles per bundle class in the product kernel (stamped build minus its five ~40-cycle stamps,
 // profiles/r02_class_profile.txt; check: 12 953 MUL + 7 258 LIN + 265 request / collect pairs -> 32.8 M cycles = 13.7 ms
 // at 2.4 GHz against 13.6 ms measured for the round-1 program).
-static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 2200, 8500, 1450, 1490, 3700, 1306};
-static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60;
+// Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
+// profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
+// inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
+static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306};
+// (round 2, bigint-class graph with every operand and result canonical: BIT 2 650, IDIVMOD 2 880, CMPS 1 900 net of stamps)
+static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60, kCyclesOperandForm = 1200, kCyclesResultForm = 1450, kCyclesBitxOperandForm = 600;
 double program_wave_cycles(const Program& p) {
     if (p.n_streams > 1) {  // the tile is done when its slowest stream is
         double m = 0;
@@ -374,7 +530,7 @@ double program_wave_cycles(const Program& p) {
     }
     double c = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)p.stats.class_bundles[k];
-    return c - (kCycles[C_BIT] - kCyclesBitx) * (double)p.stats.n_bitx_bundles + kCyclesCoopRiders * (double)p.stats.n_coop_rider_bundles;
+    return c - (kCycles[C_BIT] - kCyclesBitx) * (double)p.stats.n_bitx_bundles + kCyclesCoopRiders * (double)p.stats.n_coop_rider_bundles - (double)p.stats.form_cycles_saved;
 }
 
 // the multiplication and inversion bundles' part of it (bundles that are bound by instruction issue)
@@ -396,6 +552,7 @@ double program_wave_cycles_mul_div(const Program& p) {
 struct CoopPolicy {
     uint32_t fill;
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
+    bool all_montgomery = false;  // no representation inference: every value in Montgomery form
 };
 // The rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) depends on the fusion switch and on
 // the weight table only: the schedule variants of one compile_program call share it instead of redoing it.
@@ -440,9 +597,21 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
             fusion = false;
         }
     }
+    // Representation inference is a heuristic too: where it had to insert conversions, the all-Montgomery program competes
+    if (out.stats.n_conversions != 0 && !getenv("CWC_NO_REP_INFERENCE") && g.nodes.size() <= 2000000) {
+        CoopPolicy plain = base;
+        plain.all_montgomery = true;
+        Program alt;
+        std::string err2;
+        if (compile_variant(g, T, divider, fusion, plain, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
+            out = std::move(alt);
+            base.all_montgomery = true;
+        }
+    }
     if (base.fill == 0 || forced || g.nodes.size() > 2000000) return true;  // (huge graphs: one schedule, compile time counts)
     const CoopPolicy more[] = {{0, 0}, {std::max(12u, G * 3 / 8), 0}, {G / 2, 2}, {G * 5 / 8, 2}};
-    for (const CoopPolicy& pol : more) {
+    for (CoopPolicy pol : more) {
+        pol.all_montgomery = base.all_montgomery;
         Program alt;
         std::string err2;
         if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
@@ -614,6 +783,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     }  // (!hit)
 
     phase("rewrites");
+    // ---- one form per value: Montgomery or canonical (inserts the conversions; see infer_representations) ----
+    std::vector<uint8_t> node_rep, node_vflags;
+    infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery);
+    N = g.nodes.size();
+    phase("representation inference");
     // ---- constants -> table (Montgomery form), node -> ref ----
     std::vector<uint32_t> ref(N, 0);  // for consts: REF_CONST|idx ; for others: slot (filled later)
     for (size_t i = 0; i < N; ++i)
@@ -623,15 +797,28 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             out.consts.insert(out.consts.end(), m.v, m.v + 8);
         }
     st.n_const = out.consts.size() / 8;
-    // canonical (non-Montgomery) copies of the constants that BIT-class nodes take as second operand (shift amounts,
-    // masks): a bundle whose second operands all are such constants skips their conversion (HDR_BIT_BCANON)
+    // canonical (non-Montgomery) copies of the constants that are read in canonical form: operands of integer-class
+    // nodes (shift amounts, masks, divisors, bounds) and of additions / selections / equality tests of canonical values
     std::unordered_map<uint32_t, uint32_t> canon_const;  // constant node -> table index of its canonical copy
+    auto reads_canonical_constants = [&](size_t i, int q) -> bool {  // operand q of node i, a constant: which copy?
+        const Node& n = g.nodes[i];
+        const int c = class_of(n);
+        if (is_integer_class(c)) return q < 2 && !(n.op == OP_BITX && q == 1);
+        if (c == C_CMPZ) return (n.op == OP_EQ || n.op == OP_NEQ) && (node_vflags[i] & VF_A_CANON);
+        if (c == C_LIN) return node_rep[i] == REP_C;
+        if (c == C_TERN) return q >= 1 && node_rep[i] == REP_C;
+        return false;  // Mul / Div: Montgomery form
+    };
     for (size_t i = 0; i < N; ++i) {
         const Node& n = g.nodes[i];
-        if (class_of(n) != C_BIT || n.op == OP_BITX || g.nodes[n.b].kind != N_CONST || canon_const.count(n.b)) continue;
-        canon_const[n.b] = (uint32_t)(out.consts.size() / 8);
-        const Fr& v = g.const_values[g.nodes[n.b].a];
-        out.consts.insert(out.consts.end(), v.v, v.v + 8);
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) {
+            const uint32_t o = ops[q];
+            if (g.nodes[o].kind != N_CONST || canon_const.count(o) || !reads_canonical_constants(i, q)) continue;
+            canon_const[o] = (uint32_t)(out.consts.size() / 8);
+            const Fr& v = g.const_values[g.nodes[o].a];
+            out.consts.insert(out.consts.end(), v.v, v.v + 8);
+        }
     }
     const uint32_t zero_const = (uint32_t)(out.consts.size() / 8);  // index of the trailing dummy (value 0)
     out.consts.insert(out.consts.end(), 8, 0u);  // trailing dummy entry: the table is never empty (prefetch target)
@@ -773,9 +960,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             }
             // ready heaps per class, keyed by (height, -index)
             typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
-            std::vector<std::vector<Key>> heap(C_COUNT);
+            // (integer-class nodes: one heap per combination of operand / result forms, a bundle's header bits are uniform)
+            const int NH = (int)C_COUNT * 9;
+            std::vector<std::vector<Key>> heap(NH);
             auto push = [&](uint32_t i) {
-                auto& h = heap[class_of(g.nodes[i])];
+                int hc = class_of(g.nodes[i]);
+                if (is_integer_class(hc)) hc += (int)C_COUNT * (1 + node_vflags[i]);
+                else if (hc == C_CMPZ) hc += (int)C_COUNT * (1 + (node_vflags[i] & VF_OUT_CANON));
+                auto& h = heap[hc];
                 h.push_back(Key(height[i] + (prologue[i] ? kPrologueBoost : 0ull), tie_reverse ? i : ~i));
                 std::push_heap(h.begin(), h.end());
             };
@@ -820,12 +1012,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             }
             while (remaining) {
                 int best = -1;
-                for (int c = 0; c < (int)C_COUNT; ++c)
+                for (int c = 0; c < NH; ++c)
                     if (!heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
                 if (!in_flight.empty()) {
                     // collect when the quotients are due, or when nothing else can run (the interpreter then waits)
                     bool other_ready = false;
-                    for (int c = 0; c < (int)C_COUNT; ++c) other_ready |= c != C_DIV && !heap[c].empty();
+                    for (int c = 0; c < NH; ++c) other_ready |= c != C_DIV && !heap[c].empty();
                     if (clock >= in_flight_ready || !other_ready) {
                         emit_bundle(in_flight, false, true);
                         ss.div_lanes.push_back((uint32_t)in_flight.size() * T);
@@ -836,7 +1028,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     }
                     if (best == C_DIV) {  // a second request has to wait for the first one: run the best other class
                         best = -1;
-                        for (int c = 0; c < (int)C_COUNT; ++c)
+                        for (int c = 0; c < NH; ++c)
                             if (c != C_DIV && !heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
                     }
                 }
@@ -849,7 +1041,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 // operations of its own division (its ready node goes first), so that sibling chains divide together.
                 if (best == C_DIV) {
                     int other = -1;
-                    for (int c = 0; c < (int)C_COUNT; ++c) {
+                    for (int c = 0; c < NH; ++c) {
                         if (c == C_DIV || heap[c].empty()) continue;
                         // the heap top is the class's most urgent node; scan the ready nodes of the class for one that
                         // is about to reach a division
@@ -919,7 +1111,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     in_flight_ready = clock + kClockCost[C_DIV];
                 } else {
                     emit_bundle(picked, false, false, coop);
-                    clock += kClockCost[coop ? (int)C_MULQ : best];
+                    clock += kClockCost[coop ? (int)C_MULQ : best % (int)C_COUNT];
                 }
             }
             return true;
@@ -1133,6 +1325,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     uint64_t stream_class_bundles[MAX_STREAMS][C_COUNT];
     memset(stream_class_bundles, 0, sizeof stream_class_bundles);
     uint64_t stream_bitx[MAX_STREAMS] = {0, 0, 0, 0}, stream_riders[MAX_STREAMS] = {0, 0, 0, 0};
+    double stream_form_saved[MAX_STREAMS] = {0, 0, 0, 0};
     std::vector<uint32_t> dying;  // nodes whose slot is released after the current bundle
     uint32_t n_slots = 0;
     const uint32_t zero_off = (uint32_t)((uint64_t)zero_const * slot_bytes);
@@ -1170,15 +1363,21 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         dying.clear();
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
-        bool b_canon = cl == C_BIT;  // every second operand that is read is a constant with a canonical copy
-        bool b_read = false;
-        for (uint32_t k = k0; b_canon && k < k1; ++k) {
-            const Node& n = g.nodes[order[k] & ~REQ_FLAG];
-            if (n.op == OP_BITX) continue;
-            b_read = true;
-            b_canon = canon_const.count(n.b) != 0;
+        // integer-class bundles: which operands arrive as canonical integers, and whether the result stays one
+        uint32_t form_bits = 0;
+        if (!idle && (is_integer_class(cl) || cl == C_CMPZ)) {
+            const uint8_t f0 = node_vflags[order[k0] & ~REQ_FLAG];
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint8_t f = node_vflags[order[k] & ~REQ_FLAG];
+                if ((cl == C_CMPZ ? (f ^ f0) & VF_OUT_CANON : (f ^ f0)) != 0) {
+                    err = "internal error: operand forms differ inside a bundle";
+                    return false;
+                }
+            }
+            if (cl != C_CMPZ) form_bits |= (f0 & VF_A_CANON ? HDR_A_CANON : 0u) | (f0 & VF_B_CANON ? HDR_B_CANON : 0u);
+            form_bits |= f0 & VF_OUT_CANON ? HDR_OUT_CANON : 0u;
         }
-        b_canon = b_canon && b_read;
+        double form_saved = 0;  // (priced below, once the bundle is known to be all bit extracts or not)
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k] & ~REQ_FLAG;
             const Node& n = g.nodes[i];
@@ -1201,7 +1400,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 if (route(producer, i, q) == SRC_RING) {
                     lds[q] = LDS_RING_OFF + (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
                 } else {
-                    const uint64_t o = mem_off(producer);
+                    const uint64_t o = g.nodes[producer].kind == N_CONST && reads_canonical_constants(i, q) ? (uint64_t)canon_const[producer] * slot_bytes : mem_off(producer);
                     off[q] = (uint32_t)o;
                 }
             };
@@ -1227,12 +1426,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         break;
                     }
                     enc_operand(n.b, 1);
-                    if (b_canon) off[1] = (uint32_t)((uint64_t)canon_const[n.b] * slot_bytes);
                     break;
                 case N_TRES:
                     enc_operand(n.a, 0);
                     enc_operand(n.b, 1);
-                    out.crefs[(size_t)b * G + js] = (uint32_t)mem_off(n.c);  // third operand always through memory
+                    out.crefs[(size_t)b * G + js] = g.nodes[n.c].kind == N_CONST && reads_canonical_constants(i, 2) ? (uint32_t)((uint64_t)canon_const[n.c] * slot_bytes)
+                                                                                                                      : (uint32_t)mem_off(n.c);  // third operand always through memory
                     break;
             }
             r[0] = off[0];
@@ -1261,14 +1460,21 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 lin_bits |= HDR_BITX_ALL;
                 st.n_bitx_bundles++;
                 stream_bitx[stream]++;
+                form_saved = form_bits & HDR_A_CANON ? kCyclesBitxOperandForm : 0.0;
             }
-            if (b_canon) lin_bits |= HDR_BIT_BCANON;
+        }
+        if (is_integer_class(cl) && !(lin_bits & HDR_BITX_ALL))
+            form_saved = (form_bits & HDR_A_CANON ? kCyclesOperandForm : 0.0) + (form_bits & HDR_B_CANON ? kCyclesOperandForm : 0.0) +
+                         ((form_bits & HDR_OUT_CANON) && cl != C_CMPS ? kCyclesResultForm : 0.0);
+        if (b < s_first[stream] + s_count[stream]) {
+            st.form_cycles_saved += (uint64_t)form_saved;
+            stream_form_saved[stream] += form_saved;
         }
         if (cl == C_MULQ && lin_bits) {
             st.n_coop_rider_bundles++;
             stream_riders[stream]++;
         }
-        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits | bundle_flags[b];
+        out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits | form_bits | bundle_flags[b];
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);
@@ -1306,7 +1512,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         out.stream_div_requests[s] = s_div[s];
         double c = 0, heavy = 0;
         for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)stream_class_bundles[s][k];
-        c += kCyclesCoopRiders * (double)stream_riders[s] - (kCycles[C_BIT] - kCyclesBitx) * (double)stream_bitx[s];
+        c += kCyclesCoopRiders * (double)stream_riders[s] - (kCycles[C_BIT] - kCyclesBitx) * (double)stream_bitx[s] - stream_form_saved[s];
         for (int k : {(int)C_MUL, (int)C_MULQ, (int)C_DIV}) heavy += kCycles[k] * (double)stream_class_bundles[s][k];
         out.stream_cycles[s] = c;
         out.stream_chain_cycles[s] = s_chain[s];
@@ -1315,7 +1521,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     out.n_inputs = (uint32_t)n_in_buf;
     out.n_witness = (uint32_t)g.witness_signals.size();
     out.witness_refs.resize(out.n_witness);
-    for (size_t i = 0; i < g.witness_signals.size(); ++i) out.witness_refs[i] = ref[g.witness_signals[i]];
+    for (size_t i = 0; i < g.witness_signals.size(); ++i) {
+        const uint32_t w = g.witness_signals[i];
+        out.witness_refs[i] = ref[w] | (g.nodes[w].kind != N_CONST && node_rep[w] == REP_C ? REF_CANON : 0u);
+    }
     phase("slots + encoding");
     return true;
 }
@@ -1363,10 +1572,12 @@ bool validate_program(const Program& p, std::string& err) {
         }
         const bool executed = b < p.stream_first[stream] + p.stream_count[stream];
         const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
-        if (cls >= C_COUNT || (h >> 17) != 0) return bad("bundle " + std::to_string(b) + ": header");
+        if (cls >= C_COUNT || (h >> 19) != 0) return bad("bundle " + std::to_string(b) + ": header");
         // posts and waits: stream 0 posts once, every other stream waits in its first bundle (nothing else is compiled)
         if ((h & HDR_POST) && !(NS > 1 && stream == 0 && executed && n_posts++ == 0)) return bad("bundle " + std::to_string(b) + ": post");
         if (((h & HDR_WAIT) != 0) != (NS > 1 && stream != 0 && executed && b == p.stream_first[stream])) return bad("bundle " + std::to_string(b) + ": wait");
+        if ((h & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
+        if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ)) return bad("bundle " + std::to_string(b) + ": result form bit");
         const uint32_t rep = cls == C_MULQ ? COOP_LANES : 1u;
         if ((cnt == 0 && cls != C_LIN) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
         if (!executed && cnt != 0) return bad("bundle " + std::to_string(b) + ": outside every stream");
@@ -1406,7 +1617,7 @@ bool validate_program(const Program& p, std::string& err) {
     if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
     if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)
-        if ((w & REF_CONST) ? (w & ~REF_CONST) >= p.n_const : w >= p.n_slots) return bad("witness reference");
+        if ((w & REF_CONST) ? (w & ~REF_CONST) >= p.n_const : (w & ~REF_CANON) >= p.n_slots) return bad("witness reference");
     return true;
 }
 

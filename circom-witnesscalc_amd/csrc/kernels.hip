@@ -412,6 +412,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             }
         };
         Fr r;
+        // booleans in the form the bundle's users read: Montgomery (2^256 mod r) or the canonical integer 1
+        const Fr one_out = (h & HDR_OUT_CANON) ? Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}} : fr_one();
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul_wave(a_op, b_op, pv);
             // linear nodes riding in this bundle's free node slots (graph.rs:110-111)
@@ -484,31 +486,31 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             case C_CMPZ: {  // graph.rs:122-129 Eq/Neq, :134-135 Land/Lor
                 const bool az = u256_is_zero(a_op), cz = u256_is_zero(b_op), eq = u256_eq(a_op, b_op);
                 const bool v = sub == SUB_EQ ? eq : sub == SUB_NEQ ? !eq : sub == SUB_LAND ? (!az && !cz) : (!az || !cz);
-                r = u256_select(v, fr_one(), fr_zero());
+                r = u256_select(v, one_out, fr_zero());
                 break;
             }
             case C_CMPS: {  // graph.rs:130-133 with u_lt/u_gt/u_lte/u_gte :723-769
-                const Fr x = fr_from_mont(a_op), y = fr_from_mont(b_op);
+                const Fr x = (h & HDR_A_CANON) ? a_op : fr_from_mont(a_op), y = (h & HDR_B_CANON) ? b_op : fr_from_mont(b_op);
                 const bool xn = u256_lt(fr_half(), x), yn = u256_lt(fr_half(), y);
                 const bool same = xn == yn;
                 const bool lt = same ? u256_lt(x, y) : xn;
                 const bool gt = same ? u256_lt(y, x) : yn;
                 const bool v = sub == SUB_LT ? lt : sub == SUB_GT ? gt : sub == SUB_LEQ ? !gt : !lt;
-                r = u256_select(v, fr_one(), fr_zero());
+                r = u256_select(v, one_out, fr_zero());
                 break;
             }
             case C_BIT: {  // graph.rs:621-717
-                const Fr x = fr_from_mont(a_op);
+                const Fr x = (h & HDR_A_CANON) ? a_op : fr_from_mont(a_op);
                 // compiler-made bit extract (a >> k) & 1 (Band(Shr(a, k), 1), graph.rs:637-672 + :674-687): k rides in
                 // the b_lds field, the result is a boolean -- no second conversion, no conversion back
                 const uint32_t kx = rec_hi.y >> 20;  // (b_lds = 16 * k)
                 const bool is_x = sub == SUB_BITX;
                 if (h & HDR_BITX_ALL) {
                     const Fr e = u256_shr(x, kx);
-                    r = u256_select((e.v[0] & 1u) != 0u, fr_one(), fr_zero());
+                    r = u256_select((e.v[0] & 1u) != 0u, one_out, fr_zero());
                     break;
                 }
-                const Fr y = (h & HDR_BIT_BCANON) ? b_op : fr_from_mont(b_op);  // (canonical copies of constants)
+                const Fr y = (h & HDR_B_CANON) ? b_op : fr_from_mont(b_op);  // (canonical values, canonical copies of constants)
                 uint32_t hi_or = 0;
 #pragma unroll
                 for (int i = 1; i < 8; ++i) hi_or |= y.v[i];
@@ -541,7 +543,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 }
                 // boolean-valued results (Num2Bits-style Band(x,1)) skip the Montgomery multiplication
                 const bool small = (d.v[0] < 2u) && ((d.v[1] | d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) == 0u);
-                if (wave_any(!small)) {
+                if (h & HDR_OUT_CANON) {  // the users read the canonical integer
+                    r = d;
+                } else if (wave_any(!small)) {
                     r = fr_mul_wave(d, fr_r2(), pv);
                 } else {
                     r = u256_select(d.v[0] != 0u, fr_one(), fr_zero());
@@ -549,7 +553,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 break;
             }
             case C_IDIVMOD: {  // graph.rs:112-121
-                const Fr x = fr_from_mont(a_op), y = fr_from_mont(b_op);
+                const Fr x = (h & HDR_A_CANON) ? a_op : fr_from_mont(a_op), y = (h & HDR_B_CANON) ? b_op : fr_from_mont(b_op);
                 const bool yz = u256_is_zero(y);
                 Fr ys = y;
                 ys.v[0] |= yz ? 1u : 0u;
@@ -566,7 +570,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     u256_divrem_digits(q, rem, x, ys, dig, ly);
                 }
                 const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));
-                r = fr_mul_wave(d, fr_r2(), pv);
+                r = (h & HDR_OUT_CANON) ? d : fr_mul_wave(d, fr_r2(), pv);
                 break;
             }
             case C_TERN: {  // graph.rs:221-225  a == 0 ? c : b ; the third operand is always a memory reference
@@ -617,6 +621,13 @@ __global__ __launch_bounds__(256) void fill_consts_kernel(ProgramDev p, WsTable 
     }
 }
 
+// a stored value in the form the output rows carry: canonical integers (MONT = false) or Montgomery form
+template <bool MONT>
+__device__ __forceinline__ Fr pack_form(const Fr& v, bool canon) {
+    if (MONT) return canon ? fr_mul(v, fr_r2()) : v;
+    return canon ? v : fr_from_mont(v);
+}
+
 // One thread = one witness index of ONE tile, all T sets of it: the thread reads its slot whole ([half][T][16 B] = 32 T
 // contiguous bytes, every 64- or 128-byte line of the tile fetched by exactly one wave instruction stream) and writes T
 // rows; a wave's 64 consecutive indices make 2 KiB runs in every output row.  (Round 1 split the sets of a slot over
@@ -627,7 +638,9 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
     const uint32_t T = TT ? (uint32_t)TT : T_;
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= p.n_witness) return;
-    const uint32_t ref = p.witness_refs[w];
+    const uint32_t ref_raw = p.witness_refs[w];
+    const bool canon = (ref_raw & REF_CANON) != 0;  // the slot holds the canonical integer (representation inference, compile.cc)
+    const uint32_t ref = ref_raw & ~REF_CANON;
     const uint32_t n_tiles = (batch + T - 1) / T;
     const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
     const uint32_t slot = (ref & REF_CONST) ? (ref & ~REF_CONST) : p.n_const + ref;  // every tile holds the constants too
@@ -645,7 +658,7 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
             for (int t = 0; t < TT; ++t) {
                 const uint32_t set = tile * TT + t;
                 if (set >= batch) break;
-                const Fr c = MONT ? fr_from_u4(lo[t], hi[t]) : fr_from_mont(fr_from_u4(lo[t], hi[t]));
+                const Fr c = pack_form<MONT>(fr_from_u4(lo[t], hi[t]), canon);
                 uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
                 o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
                 o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
@@ -654,7 +667,7 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
             for (uint32_t t = 0; t < T; ++t) {
                 const uint32_t set = tile * T + t;
                 if (set >= batch) break;
-                const Fr c = MONT ? fr_from_u4(q[t], q[T + t]) : fr_from_mont(fr_from_u4(q[t], q[T + t]));
+                const Fr c = pack_form<MONT>(fr_from_u4(q[t], q[T + t]), canon);
                 uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
                 o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
                 o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
@@ -668,7 +681,9 @@ template <bool MONT>
 __global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
     const uint32_t w = blockIdx.x * 64u + threadIdx.x;
     if (w >= p.n_witness) return;
-    const uint32_t ref = p.witness_refs[w];
+    const uint32_t ref_raw = p.witness_refs[w];
+    const bool canon = (ref_raw & REF_CANON) != 0;
+    const uint32_t ref = ref_raw & ~REF_CANON;
     const uint32_t n_tiles = (batch + T - 1) / T;
     const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
     const uint32_t slot = (ref & REF_CONST) ? (ref & ~REF_CONST) : p.n_const + ref;
@@ -679,7 +694,7 @@ __global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst,
             const uint32_t set = tile * T + t;
             if (set >= batch) break;
             const uint4* q = q0 + t;
-            const Fr c = MONT ? fr_from_u4(q[0], q[T]) : fr_from_mont(fr_from_u4(q[0], q[T]));
+            const Fr c = pack_form<MONT>(fr_from_u4(q[0], q[T]), canon);
             uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
             o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
             o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);

@@ -26,6 +26,7 @@ struct ProgramStats {
     uint64_t n_bitx_nodes = 0;          // bit-extract nodes made by the compiler
     uint64_t algorithmic_bytes_per_set = 0;  // 32*[sum_ops(arity+1) + 2*n_input_nodes + 2*W]  
     uint64_t n_coop_rider_bundles = 0;  // narrow multiplication bundles that carry linear riders
+    uint64_t n_conversions = 0, n_canonical = 0, form_cycles_saved = 0;  // representation inference: inserted conversions, operations whose value is kept as a canonical integer
     uint64_t n_folded = 0, n_numbered = 0, n_shaken = 0;  // load-time optimiser: operations folded to constants / aliases, nodes merged by value numbering, unused nodes dropped
 };
 

@@ -65,9 +65,10 @@ CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_L
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
 static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
-// C_BIT: every lane's second operand is a constant and arrives in canonical (non-Montgomery) form from a second copy in
-// the constant table: the bundle skips that operand's conversion out of Montgomery form
-static const uint32_t HDR_BIT_BCANON = 1u << 14;
+// C_BIT / C_IDIVMOD / C_CMPS (integer operations on canonical values): every lane's first / second operand arrives as a
+// canonical integer (a value the compiler keeps in that form, or the canonical copy of a constant) -- the bundle skips
+// that operand's conversion out of Montgomery form; OUT: the result stays canonical (these classes and C_CMPZ's booleans).
+static const uint32_t HDR_B_CANON = 1u << 14, HDR_A_CANON = 1u << 17, HDR_OUT_CANON = 1u << 18;
 // Programs of several streams (wavefronts of one tile with their own bundle sequences): at the top of such a bundle the
 // wave first posts -- every result of its bundles up to two back is in memory -- and / or waits: a stream other than 0
 // for stream 0's next post, stream 0 for the next post of every other stream.
@@ -99,6 +100,7 @@ enum SubOp : uint32_t {
 
 // witness reference (pack kernel): bit 31 set -> constant table index, else value slot of the tile
 static const uint32_t REF_CONST = 0x80000000u;
+static const uint32_t REF_CANON = 0x40000000u;  // the slot holds the canonical integer, not the Montgomery form
 
 // per-set status bits written by the kernels (the reference panics in these cases)
 enum SetStatus : uint32_t {

@@ -8,6 +8,8 @@ import struct
 from oracle import model
 
 REF_CONST = 0x80000000
+REF_CANON = 0x40000000  # the slot holds the canonical integer, not the Montgomery form
+HDR_B_CANON, HDR_A_CANON, HDR_OUT_CANON = 1 << 14, 1 << 17, 1 << 18
 CTRL_SUB_MASK, CTRL_ACTIVE, CTRL_MASK = 7, 8, 15
 RING_BUNDLES, OPND_AHEAD, REC_AHEAD = 4, 2, 4
 RING_SLOT_BYTES, LDS_HALF_BYTES, STAGE_BYTES = 2048, 1024, 4096
@@ -19,7 +21,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I12d38Q"
+HDR_FMT = "<12I12I12d41Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
@@ -38,7 +40,7 @@ class Blob:
         assert self.n_streams == 1 or self.divider in (0, 1), "streams have a divider wave each, or none"
         st = h[36:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34], n_folded=st[35], n_numbered=st[36], n_shaken=st[37])
+                          class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34], n_conversions=st[35], n_canonical=st[36], form_cycles_saved=st[37], n_folded=st[38], n_numbered=st[39], n_shaken=st[40])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -61,7 +63,9 @@ class Blob:
 
 def run(blob: Blob, inputs_row):
     """Evaluate one input set (list of ints) through the format-v4 program the way the interpreter kernel does, for
-    t = 0; returns (witness ints, status bits).  Models the timing rules of the pipeline: the staging load of bundle b
+    t = 0; returns (witness ints, status bits).  Values are held the way the kernel holds them -- the Montgomery form
+    x * 2^256 mod r, or the canonical integer where the compiler's representation inference keeps one -- and every
+    operation is done on those words: a value read in the wrong form gives a wrong witness.  Models the timing rules of the pipeline: the staging load of bundle b
     sees the tile as it is after the stores of bundle b - OPND_AHEAD - 1 (it is issued before bundle b - OPND_AHEAD
     stores), a ring cell holds the result of the last bundle that wrote it.  Raises on any read of a slot or ring cell
     that does not hold the value the compiler meant (scheduling / liveness / encoding bug)."""
@@ -89,7 +93,7 @@ def run(blob: Blob, inputs_row):
         assert off % slot_bytes == 0
         s_ = off // slot_bytes
         if s_ < NC:
-            return blob.consts[s_]
+            return blob.consts_raw[s_]
         assert s_ < NC + blob.n_slots, "operand read from the trash slot"
         hist = history[s_ - NC]
         if hist[0][0] != stream:
@@ -116,7 +120,11 @@ def run(blob: Blob, inputs_row):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         name = CLASS_NAMES[cls]
-        assert h >> 17 == 0 and (1 <= cnt <= G or (cnt == 0 and name == "LIN"))
+        assert h >> 19 == 0 and (1 <= cnt <= G or (cnt == 0 and name == "LIN"))
+        a_canon, b_canon, out_canon = bool(h & HDR_A_CANON), bool(h & HDR_B_CANON), bool(h & HDR_OUT_CANON)
+        assert not (a_canon or b_canon) or name in ("BIT", "IDIVMOD", "CMPS")
+        assert not out_canon or name in ("BIT", "IDIVMOD", "CMPS", "CMPZ")
+        one_out = 1 if out_canon else R_MONT
         assert bool(h & HDR_WAIT) == (blob.n_streams > 1 and stream != 0 and b == blob.stream_first[stream])
         assert not (h & HDR_POST) or (stream == 0 and blob.n_streams > 1)
         # narrow multiplication bundle: four lanes per product, a node's record sits at positions 4j .. 4j+3 and its
@@ -148,11 +156,7 @@ def run(blob: Blob, inputs_row):
                     continue
                 own_cell = stage + 2 * q * LDS_HALF_BYTES + j * rep * T * 16
                 if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
-                    if name == "BIT" and (h >> 14) & 1 and q == 1 and j < cnt:
-                        assert off % slot_bytes == 0 and off // slot_bytes < NC, "canonical second operands are constants"
-                        ops.append(blob.consts_raw[off // slot_bytes])  # canonical copy: no conversion in the kernel
-                    else:
-                        ops.append(mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD))
+                    ops.append(mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD))
                 else:
                     assert off == zero_off, "ring operand must stage the zero constant"
                     rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
@@ -164,29 +168,44 @@ def run(blob: Blob, inputs_row):
                 assert dst == trash and a_off == zero_off and b_off == zero_off
                 continue
             sub = ctrl & CTRL_SUB_MASK
+
+            def mont_div(x, y):  # fr_inv: Montgomery in, Montgomery out; b == 0 -> 0 (graph.rs:109)
+                return x * pow(y, -1, model.M) * R_MONT % model.M if y % model.M else 0
             if name == "DIVREQ":
                 request[j] = (ops[0], ops[1])
                 assert dst == trash
                 v = 0
             elif name == "DIVGET":
-                v = model.eval_duo("Div", *mailbox[j])
+                v = mont_div(*mailbox[j])
             elif name == "INPUT":
-                v = inputs_row[blob.crefs[b * G + j]] % model.M
+                v = inputs_row[blob.crefs[b * G + j]] % model.M * R_MONT % model.M
             elif name == "TERN":
-                v = model.eval_tres("TernCond", ops[0], ops[1], mem_at(blob.crefs[b * G + j], b - 1, stream, b))
+                v = mem_at(blob.crefs[b * G + j], b - 1, stream, b) if ops[0] == 0 else ops[1]
             else:
                 op = SUB_NAMES[name][sub]
                 assert op is not None
-                if op == "BitX":
-                    results.append((dst, (ops[0] >> ops[1]) & 1))
-                    continue
-                if name in ("LIN", "MUL", "MULQ") and op != "Mul":
-                    lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
-                try:
-                    v = model.eval_duo(op, ops[0], ops[1])
-                except model.ReferencePanic:
-                    status |= 1 if op == "Shl" else 2
-                    v = 0
+                if name in ("LIN", "MUL", "MULQ"):
+                    if op != "Mul":
+                        lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
+                        v = model.eval_duo(op, ops[0], ops[1])  # (a +- b mod r: the same words in either form)
+                    else:
+                        v = ops[0] * ops[1] * R_INV % model.M    # Montgomery product
+                elif name == "DIV":
+                    v = mont_div(ops[0], ops[1])
+                elif name == "CMPZ":  # zero tests and equality of the stored words; both sides are in one form
+                    v = one_out if model.eval_duo(op, ops[0], ops[1]) else 0
+                else:  # BIT / IDIVMOD / CMPS: on the canonical integers
+                    x = ops[0] if a_canon else ops[0] * R_INV % model.M
+                    if op == "BitX":
+                        results.append((dst, one_out if (x >> ops[1]) & 1 else 0))
+                        continue
+                    y = ops[1] if b_canon else ops[1] * R_INV % model.M
+                    try:
+                        d = model.eval_duo(op, x, y)
+                    except model.ReferencePanic:
+                        status |= 1 if op == "Shl" else 2
+                        d = 0
+                    v = d if out_canon else d * R_MONT % model.M
             results.append((dst, v))
         if name == "DIVREQ":
             mailbox = request
@@ -201,7 +220,7 @@ def run(blob: Blob, inputs_row):
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
             assert ((h >> 13) & 1) == (1 if all_x else 0), "BITX header bit must describe the records"
         else:
-            assert ((h >> 13) & 3) == 0
+            assert ((h >> 13) & 1) == 0
         assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
@@ -223,5 +242,8 @@ def run(blob: Blob, inputs_row):
         assert history[slot][-1][1] <= post_at - 2, "a slot that other streams read is written again behind the post"
 
     def wit(r):
-        return blob.consts[r & 0x7FFFFFFF] if r & REF_CONST else history[r][-1][2]
+        if r & REF_CONST:
+            return blob.consts[r & 0x3FFFFFFF]
+        raw = history[r & ~REF_CANON][-1][2]
+        return raw if r & REF_CANON else raw * R_INV % model.M
     return [wit(r) for r in blob.witness_refs], status
