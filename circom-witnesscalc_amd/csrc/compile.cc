@@ -847,6 +847,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint8_t> stream_of(N, 0);
     uint32_t P = 1;
     uint32_t s_first[MAX_STREAMS] = {0, 0, 0, 0}, s_count[MAX_STREAMS] = {0, 0, 0, 0}, s_div[MAX_STREAMS] = {0, 0, 0, 0};
+    uint32_t s_cref[MAX_STREAMS] = {0, 0, 0, 0};  // rows of the third-operand / input-index table in front of each stream
     double s_chain[MAX_STREAMS] = {0, 0, 0, 0};  // longest dependent chain of each stream, lone-wave cycles (divisions at the divider wave's latency)
     if (G == 1) {
         for (size_t i = 0; i < N; ++i)
@@ -1320,7 +1321,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     const uint32_t NC = out.n_const;
     out.hdr.resize(NB);
     out.recs.assign((size_t)NB * G * 4, 0);
-    out.crefs.assign((size_t)NB * G, 0);
+    out.crefs.clear();  // one row of G words per C_INPUT / C_TERN bundle, in bundle order (the interpreter counts rows)
+    uint32_t cref_row = 0;
     std::vector<uint32_t> free_slots;
     uint64_t stream_class_bundles[MAX_STREAMS][C_COUNT];
     memset(stream_class_bundles, 0, sizeof stream_class_bundles);
@@ -1363,6 +1365,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         dying.clear();
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
+        if (b == s_first[stream]) s_cref[stream] = cref_row;
+        const bool has_crefs = cl == C_INPUT || cl == C_TERN;
+        if (has_crefs) out.crefs.resize((size_t)(cref_row + 1) * G, 0);
         // integer-class bundles: which operands arrive as canonical integers, and whether the result stays one
         uint32_t form_bits = 0;
         if (!idle && (is_integer_class(cl) || cl == C_CMPZ)) {
@@ -1412,7 +1417,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         err = "Input index out of range";
                         return false;
                     }
-                    out.crefs[(size_t)b * G + js] = n.a;  // input index
+                    out.crefs[(size_t)cref_row * G + js] = n.a;  // input index
                     break;
                 case N_UNO:  // Neg(a) = 0 - a  (graph.rs:188-194: 0 -> 0, else r - a); a travels in the b position
                     ctrl |= SUB_SUB;
@@ -1430,7 +1435,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 case N_TRES:
                     enc_operand(n.a, 0);
                     enc_operand(n.b, 1);
-                    out.crefs[(size_t)b * G + js] = g.nodes[n.c].kind == N_CONST && reads_canonical_constants(i, 2) ? (uint32_t)((uint64_t)canon_const[n.c] * slot_bytes)
+                    out.crefs[(size_t)cref_row * G + js] = g.nodes[n.c].kind == N_CONST && reads_canonical_constants(i, 2) ? (uint32_t)((uint64_t)canon_const[n.c] * slot_bytes)
                                                                                                                       : (uint32_t)mem_off(n.c);  // third operand always through memory
                     break;
             }
@@ -1475,6 +1480,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             stream_riders[stream]++;
         }
         out.hdr[b] = (uint32_t)cl | (cnt << HDR_COUNT_SHIFT) | lin_bits | form_bits | bundle_flags[b];
+        if (has_crefs) {  // (inactive node slots repeat the first word: a valid input index / slot offset)
+            for (uint32_t q = cnt; q < G; ++q) out.crefs[(size_t)cref_row * G + q] = out.crefs[(size_t)cref_row * G];
+            ++cref_row;
+        }
         std::sort(dying.begin(), dying.end());
         dying.erase(std::unique(dying.begin(), dying.end()), dying.end());
         for (uint32_t o : dying) free_slots.push_back(ref[o]);
@@ -1501,15 +1510,16 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             r[2] = trash_off | (ctrl_of[(size_t)b * G] & CTRL_SUB_MASK);
             const uint32_t cell = (q / rep) * rep * T * 16u;  // (C_MULQ: the four positions of an idle group read one zero cell)
             r[3] = (stage + cell) | ((stage + 2u * LDS_HALF_BYTES + cell) << 16);
-            out.crefs[(size_t)b * G + q] = out.crefs[(size_t)b * G];
         }
     }
     out.n_slots = n_slots;
     out.n_streams = P;
+    out.n_cref_rows = cref_row;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         out.stream_first[s] = s_first[s];
         out.stream_count[s] = s_count[s];
         out.stream_div_requests[s] = s_div[s];
+        out.stream_cref_first[s] = s < P && s_count[s] ? s_cref[s] : cref_row;
         double c = 0, heavy = 0;
         for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)stream_class_bundles[s][k];
         c += kCyclesCoopRiders * (double)stream_riders[s] - (kCycles[C_BIT] - kCyclesBitx) * (double)stream_bitx[s] - stream_form_saved[s];
@@ -1544,7 +1554,7 @@ bool validate_program(const Program& p, std::string& err) {
     const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
     if (p.n_const == 0 || p.n_slots == 0 || tile_bytes > 0xffffffffull) return bad("tile size");
     if ((uint64_t)p.n_bundles * G * 16ull > 0xffffffffull) return bad("record stream size");
-    if (p.hdr.size() != p.n_bundles || p.recs.size() != (size_t)p.n_bundles * G * 4 || p.crefs.size() != (size_t)p.n_bundles * G ||
+    if (p.hdr.size() != p.n_bundles || p.recs.size() != (size_t)p.n_bundles * G * 4 || p.crefs.size() != (size_t)p.n_cref_rows * G ||
         p.consts.size() != (size_t)p.n_const * 8 || p.witness_refs.size() != p.n_witness || p.div_lanes.size() != p.n_div_requests)
         return bad("array sizes");
     const uint32_t slot_bytes = 32u * T, HI = 16u * T;
@@ -1563,8 +1573,9 @@ bool validate_program(const Program& p, std::string& err) {
     if (p.stream_first[0] != 0 || (NS == 1 && p.stream_count[0] != p.n_bundles) || req_sum != p.n_div_requests) return bad("stream ranges");
     uint32_t n_req = 0, n_get = 0, n_posts = 0;
     bool in_flight = false;
-    uint32_t stream = 0, stream_req = 0;
+    uint32_t stream = 0, stream_req = 0, cref_row = 0;
     for (uint32_t b = 0; b < p.n_bundles; ++b) {
+        if (b == p.stream_first[stream] && p.stream_count[stream] && p.stream_cref_first[stream] != cref_row) return bad("third-operand rows of stream " + std::to_string(stream));
         while (stream + 1 < NS && b >= p.stream_first[stream + 1]) {
             if (in_flight || stream_req != p.stream_div_requests[stream]) return bad("division requests of stream " + std::to_string(stream));
             ++stream;
@@ -1608,12 +1619,16 @@ bool validate_program(const Program& p, std::string& err) {
             // (a bit-extract lane carries its shift amount there; idle lanes of such a bundle keep a stage address, unused)
             const bool active = (r[2] & CTRL_ACTIVE) != 0;
             if (bitx ? (active && lb / 16 >= 254) : ((lb % 16) != 0 || lb + 16u * (T - 1) + LDS_HALF_BYTES + 16u > LDS_BYTES)) return bad("bundle " + std::to_string(b) + ": LDS address");
-            const uint32_t cr = p.crefs[(size_t)b * G + q];
+            const bool has_row = cls == C_INPUT || cls == C_TERN;
+            if (has_row && cref_row >= p.n_cref_rows) return bad("bundle " + std::to_string(b) + ": third-operand row");
+            const uint32_t cr = has_row ? p.crefs[(size_t)cref_row * G + q] : 0u;
             if (cls == C_INPUT && cr >= p.n_inputs) return bad("bundle " + std::to_string(b) + ": input index");
             if (cls == C_TERN && ((cr % slot_bytes) != 0 || (uint64_t)cr + slot_bytes > tile_bytes)) return bad("bundle " + std::to_string(b) + ": third operand");
         }
         (void)HI;
+        cref_row += cls == C_INPUT || cls == C_TERN;
     }
+    if (cref_row != p.n_cref_rows) return bad("third-operand rows");
     if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
     if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)
@@ -1625,7 +1640,8 @@ bool validate_program(const Program& p, std::string& err) {
 static const uint32_t kBlobMagic = 0x47505743u;  // "CWPG"
 struct BlobHeader {
     uint32_t magic, version, T, G, n_bundles, n_slots, n_const, n_inputs, n_witness, divider, n_div_requests, n_streams;
-    uint32_t stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS];
+    uint32_t stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS], stream_cref_first[MAX_STREAMS];
+    uint32_t n_cref_rows, reserved;
     double stream_cycles[MAX_STREAMS], stream_cycles_mul_div[MAX_STREAMS], stream_chain_cycles[MAX_STREAMS];
     ProgramStats stats;
 };
@@ -1634,13 +1650,14 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 10;
+    h.version = 11;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
     h.n_streams = p.n_streams;
+    h.n_cref_rows = p.n_cref_rows;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
-        h.stream_first[s] = p.stream_first[s]; h.stream_count[s] = p.stream_count[s]; h.stream_div_requests[s] = p.stream_div_requests[s];
+        h.stream_first[s] = p.stream_first[s]; h.stream_count[s] = p.stream_count[s]; h.stream_div_requests[s] = p.stream_div_requests[s]; h.stream_cref_first[s] = p.stream_cref_first[s];
         h.stream_cycles[s] = p.stream_cycles[s]; h.stream_cycles_mul_div[s] = p.stream_cycles_mul_div[s]; h.stream_chain_cycles[s] = p.stream_chain_cycles[s];
     }
     h.stats = p.stats;
@@ -1654,17 +1671,18 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 10 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 11 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;
     p.divider = h.divider; p.n_div_requests = h.n_div_requests;
     p.n_streams = h.n_streams;
+    p.n_cref_rows = h.n_cref_rows;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
-        p.stream_first[s] = h.stream_first[s]; p.stream_count[s] = h.stream_count[s]; p.stream_div_requests[s] = h.stream_div_requests[s];
+        p.stream_first[s] = h.stream_first[s]; p.stream_count[s] = h.stream_count[s]; p.stream_div_requests[s] = h.stream_div_requests[s]; p.stream_cref_first[s] = h.stream_cref_first[s];
         p.stream_cycles[s] = h.stream_cycles[s]; p.stream_cycles_mul_div[s] = h.stream_cycles_mul_div[s]; p.stream_chain_cycles[s] = h.stream_chain_cycles[s];
     }
-    const size_t n_hdr = p.n_bundles, n_recs = (size_t)p.n_bundles * p.G * 4, n_c = (size_t)p.n_bundles * p.G,
+    const size_t n_hdr = p.n_bundles, n_recs = (size_t)p.n_bundles * p.G * 4, n_c = (size_t)p.n_cref_rows * p.G,
                  n_k = (size_t)p.n_const * 8, n_w = p.n_witness, n_d = p.n_div_requests;
     if (len != sizeof h + 4 * (n_hdr + n_recs + n_c + n_k + n_w + n_d)) { err = "program blob size mismatch"; return false; }
     const uint32_t* q = (const uint32_t*)(data + sizeof h);

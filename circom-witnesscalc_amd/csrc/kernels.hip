@@ -40,7 +40,7 @@ struct InterpDims {
     const uint32_t* div_lanes;  // active lanes of each division request (divider programs)
     // streams: interpreter wave w of a workgroup evaluates bundles [stream_first[s], stream_first[s] + stream_count[s]),
     // s = w % n_streams, of tile w / n_streams (program.hpp); with divider waves, divider d serves interpreter wave d
-    uint32_t n_streams, stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS];
+    uint32_t n_streams, stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS], stream_cref_first[MAX_STREAMS];
 };
 static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox wait gave up (never expected)
 
@@ -180,6 +180,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     if (tile_raw >= n_tiles) return;  // an interpreter wave without a tile (last workgroup)
     uint32_t div_seq = 0;  // requests posted / collected so far (interpreter wave)
     uint32_t n_posts = 0, n_waits = 0;
+    uint32_t cref_row = p.stream_cref_first[stream];  // row of the third-operand / input-index table for the next C_TERN / C_INPUT bundle
 
     auto ld = [&](uint32_t off) -> Fr {  // synchronous load of a slot (third operands only)
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
@@ -444,7 +445,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         }
         switch (cls) {
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
-                const uint32_t idx = crefs[(size_t)b * G + j];
+                const uint32_t idx = crefs[(size_t)cref_row * G + j];
+                ++cref_row;
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + idx) * 2;
                 r = fr_mul_wave(fr_from_u4(q[0], q[1]), fr_r2(), pv);  // (any value below 2^256 is reduced: Fr::new)
                 break;
@@ -574,7 +576,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 break;
             }
             case C_TERN: {  // graph.rs:221-225  a == 0 ? c : b ; the third operand is always a memory reference
-                const uint32_t cr = crefs[(size_t)b * G + j];
+                const uint32_t cr = crefs[(size_t)cref_row * G + j];
+                ++cref_row;
                 const Fr y = ld(cr + t16);
                 r = u256_select(u256_is_zero(a_op), y, b_op);
                 break;
@@ -710,11 +713,12 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     const uint32_t tiles_per_wg = nw / ns;
     dim3 grid((tiles + tiles_per_wg - 1) / tiles_per_wg), block((W ? (W + 1) * pack : pack) * 64);
     const uint4* in = (const uint4*)inputs;
-    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dims.stream_first[s] = p.stream_first[s];
         dims.stream_count[s] = p.stream_count[s];
         dims.stream_div_requests[s] = p.stream_div_requests[s];
+        dims.stream_cref_first[s] = p.stream_cref_first[s];
     }
     if (ns == 1) {
         dims.stream_first[0] = 0;

@@ -37,7 +37,7 @@ struct Program {
     uint32_t n_bundles = 0, n_slots = 0, n_const = 0, n_inputs = 0, n_witness = 0;
     std::vector<uint32_t> hdr;           // [n_bundles]      see program_dev.h (format v4)
     std::vector<uint32_t> recs;          // [n_bundles*G*4]  {a_off, b_off, dst | ctrl, a_lds | b_lds << 16}
-    std::vector<uint32_t> crefs;         // [n_bundles*G]    third operand byte offset (C_TERN) / input index (C_INPUT)
+    std::vector<uint32_t> crefs;         // [n_cref_rows*G]  third operand byte offset (C_TERN) / input index (C_INPUT): one row per such bundle, in bundle order
     std::vector<uint32_t> consts;        // [n_const*8]      Montgomery form
     std::vector<uint32_t> witness_refs;  // [n_witness]      slot or REF_CONST|idx
     std::vector<uint32_t> div_lanes;     // [n_div_requests] active lanes of each division request
@@ -45,6 +45,7 @@ struct Program {
     // over the graph's independent parts (compile.cc); stream 0 evaluates the Input nodes for all of them.  With a
     // divider (divider == 1 only) every stream has its own divider wave and serves stream_div_requests[s] requests.
     uint32_t n_streams = 1;
+    uint32_t n_cref_rows = 0, stream_cref_first[MAX_STREAMS] = {0, 0, 0, 0};  // rows of crefs; rows in front of each stream's first bundle
     uint32_t stream_first[MAX_STREAMS] = {0, 0, 0, 0}, stream_count[MAX_STREAMS] = {0, 0, 0, 0}, stream_div_requests[MAX_STREAMS] = {0, 0, 0, 0};
     double stream_cycles[MAX_STREAMS] = {0, 0, 0, 0}, stream_cycles_mul_div[MAX_STREAMS] = {0, 0, 0, 0}, stream_chain_cycles[MAX_STREAMS] = {0, 0, 0, 0};  // lone-wave cycles of each stream's bundles
     ProgramStats stats;

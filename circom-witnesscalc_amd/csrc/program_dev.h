@@ -60,8 +60,9 @@ CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_L
 //   dst          tile-relative byte offset of the destination slot (trash slot when the value needs none);
 //                low 4 bits = ctrl: bits 0-2 sub-op within the class (SubOp), bit 3 active
 //   a_lds/b_lds  LDS byte address of the operand's low half for t = 0 (the lane adds 16*t): its STAGE cell or a RING cell
-// crefs[bundle][node slot]: TernCond third operand (tile-relative byte offset, always MEM, loaded in place);
-//                           INPUT bundles: index into the set's input row.
+// crefs[row][node slot]: TernCond third operand (tile-relative byte offset, always MEM, loaded in place);
+//                        INPUT bundles: index into the set's input row.  One row per C_TERN / C_INPUT bundle in bundle
+//                        order; a wave counts the rows it has used (its stream starts at stream_cref_first).
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
 static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
@@ -112,12 +113,12 @@ enum SetStatus : uint32_t {
 struct ProgramDev {
     const uint32_t* hdr;           // [n_bundles]
     const uint32_t* recs;          // [n_bundles*G*4], 16-byte aligned records
-    const uint32_t* crefs;         // [n_bundles*G]
+    const uint32_t* crefs;         // [n_cref_rows*G]: a row per C_INPUT / C_TERN bundle
     const uint32_t* consts;        // [n_const*8] Montgomery form (the last entry is a dummy zero)
     const uint32_t* witness_refs;  // [n_witness]
     const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
-    uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4];  // (program.hpp; MAX_STREAMS entries)
+    uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4], stream_cref_first[4];  // (program.hpp; MAX_STREAMS entries)
 };
 
 // A launch covers up to WS_MAX_CHUNKS separately allocated workspaces: tile i lives in chunk i / tiles_per_chunk.

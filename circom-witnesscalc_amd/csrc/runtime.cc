@@ -87,7 +87,7 @@ std::string upload_program(DeviceProgram& dp) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     // (the interpreter reads the header two bundles ahead without a clamp: 16 bytes of zero padding behind the array)
     const size_t o_hdr = 0, o_recs = o_hdr + al(p.hdr.size() * 4 + 16), o_crefs = o_recs + al(p.recs.size() * 4 + REC_AHEAD * 1024u),  // (records are staged REC_AHEAD bundles ahead, unclamped)
-                 o_consts = o_crefs + al(p.crefs.size() * 4), o_wit = o_consts + al(p.consts.size() * 4 + 32),
+                 o_consts = o_crefs + al(p.crefs.size() * 4 + 256), o_wit = o_consts + al(p.consts.size() * 4 + 32),
                  o_div = o_wit + al(p.witness_refs.size() * 4 + 4), total = o_div + al(p.div_lanes.size() * 4 + 4);
     HIP_TRY(hipMalloc(&dp.d_blob, total));
     char* d = (char*)dp.d_blob;
@@ -114,6 +114,7 @@ std::string upload_program(DeviceProgram& dp) {
         dp.dev.stream_first[s] = p.stream_first[s];
         dp.dev.stream_count[s] = p.stream_count[s];
         dp.dev.stream_div_requests[s] = p.stream_div_requests[s];
+        dp.dev.stream_cref_first[s] = p.stream_cref_first[s];
     }
     return "";
 }
@@ -292,14 +293,14 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     }
     uint32_t rule = gwb_pick_tile_width(batch);
     // Deep graphs: a program is one header word, G records and G third-operand words per bundle, and a bundle per
-    // dependency level at least -- 1 KiB + 260 B per bundle at T = 1 (2 GB for the 10.5 M-node bigint-class graph of
+    // dependency level at least -- 1 KiB per bundle at T = 1 (1.6 GB for the 10.5 M-node bigint-class graph of
     // BASELINE config 5, depth 1.29 M).  Small batches fill the same number of SIMDs whatever the tile width (every tile
-    // is one wave), so the width is raised until the program stream fits CWC_PROGRAM_MB (default 768): 0.5 GB at T = 4.
+    // is one wave), so the width is raised until the program stream fits CWC_PROGRAM_MB (default 960): 0.85 GB at T = 2.
     uint32_t min_t = 1;
     {
-        double budget = 768.0;
+        double budget = 960.0;
         if (const char* e = getenv("CWC_PROGRAM_MB")) budget = atof(e);
-        const double per_bundle_t1 = 4.0 + 64.0 * 20.0;
+        const double per_bundle_t1 = 4.0 + 64.0 * 16.0;
         while (min_t < 16 && (double)g->stats.depth * 1.25 * (4.0 + (per_bundle_t1 - 4.0) / min_t) > budget * 1048576.0) min_t *= 2;
         if ((rule & ~KEY_MODE_MASK) < min_t) rule = min_t | ((rule & KEY_MODE_MASK) && min_t < 64 ? (rule & KEY_MODE_MASK) : 0u);
     }

@@ -21,7 +21,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I12d41Q"
+HDR_FMT = "<12I12I6I12d41Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
@@ -33,12 +33,13 @@ class Blob:
         h = struct.unpack_from(HDR_FMT, data, 0)
         (self.magic, self.version, self.T, self.G, self.n_bundles, self.n_slots, self.n_const, self.n_inputs,
          self.n_witness, self.divider, self.n_div_requests, self.n_streams) = h[:12]
-        self.stream_first, self.stream_count, self.stream_div_requests = h[12:16], h[16:20], h[20:24]
-        self.stream_cycles = h[24:28]
+        self.stream_first, self.stream_count, self.stream_div_requests, self.stream_cref_first = h[12:16], h[16:20], h[20:24], h[24:28]
+        self.n_cref_rows = h[28]
+        self.stream_cycles = h[30:34]
         assert self.n_streams in (1, 2, 3, 4) and all(f % 4 == 0 for f in self.stream_first[:self.n_streams])
         assert sum(self.stream_div_requests[:self.n_streams]) == self.n_div_requests
         assert self.n_streams == 1 or self.divider in (0, 1), "streams have a divider wave each, or none"
-        st = h[36:]
+        st = h[42:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
                           class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34], n_conversions=st[35], n_canonical=st[36], form_cycles_saved=st[37], n_folded=st[38], n_numbered=st[39], n_shaken=st[40])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
@@ -51,7 +52,7 @@ class Blob:
             return v
         self.hdr = take(self.n_bundles)
         self.recs = take(self.n_bundles * self.G * 4)
-        self.crefs = take(self.n_bundles * self.G)
+        self.crefs = take(self.n_cref_rows * self.G)  # one row per INPUT / TERN bundle, in bundle order
         k = take(self.n_const * 8)
         self.consts_raw = [sum(k[8 * i + j] << (32 * j) for j in range(8)) for i in range(self.n_const)]
         self.consts = [v * R_INV % model.M for v in self.consts_raw]
@@ -117,6 +118,7 @@ def run(blob: Blob, inputs_row):
             ring = {}     # (ring cell, node slot) -> (bundle that wrote it, value)
             mailbox = None  # operands of the division request in flight (asynchronous divider programs)
             n_requests = 0
+            cref_row = blob.stream_cref_first[stream]
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         name = CLASS_NAMES[cls]
@@ -178,9 +180,9 @@ def run(blob: Blob, inputs_row):
             elif name == "DIVGET":
                 v = mont_div(*mailbox[j])
             elif name == "INPUT":
-                v = inputs_row[blob.crefs[b * G + j]] % model.M * R_MONT % model.M
+                v = inputs_row[blob.crefs[cref_row * G + j]] % model.M * R_MONT % model.M
             elif name == "TERN":
-                v = mem_at(blob.crefs[b * G + j], b - 1, stream, b) if ops[0] == 0 else ops[1]
+                v = mem_at(blob.crefs[cref_row * G + j], b - 1, stream, b) if ops[0] == 0 else ops[1]
             else:
                 op = SUB_NAMES[name][sub]
                 assert op is not None
@@ -207,6 +209,7 @@ def run(blob: Blob, inputs_row):
                         d = 0
                     v = d if out_canon else d * R_MONT % model.M
             results.append((dst, v))
+        cref_row += name in ("INPUT", "TERN")
         if name == "DIVREQ":
             mailbox = request
             assert blob.div_lanes[n_requests_total] == cnt * T <= (64 if blob.divider == 1 else 32), "request must fit the mailbox"

@@ -378,12 +378,12 @@ def test_schedule_quality_guard(pkg):
     g = pkg.Graph(C.build_authv2_class().to_bin())
     blob = g.export_blob(2 | DIVIDER)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[36:][18:30]))
+    cb = dict(zip(pe.CLASS_NAMES, h[42:][18:30]))
     est = sum(cyc[k] * v for k, v in cb.items())
     assert est <= 31.5e6 and cb["MULQ"] >= 3000 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0, (est, cb)
     blob = g.export_blob(4)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[36:][18:30]))
+    cb = dict(zip(pe.CLASS_NAMES, h[42:][18:30]))
     assert h[4] <= 27500 and cb["DIV"] <= 275
     g = pkg.Graph(C.build_sha256(512).to_bin())
     h = struct.unpack_from(pe.HDR_FMT, g.export_blob(1), 0)
