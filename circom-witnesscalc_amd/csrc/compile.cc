@@ -521,6 +521,7 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
 static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306};
 // (round 2, bigint-class graph with every operand and result canonical: BIT 2 650, IDIVMOD 2 880, CMPS 1 900 net of stamps)
+static const double kCyclesBitStraight = 1500;  // what a Shr-only / Band-only bundle saves against the per-lane select over all bit operations
 static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60, kCyclesOperandForm = 1200, kCyclesResultForm = 1450, kCyclesBitxOperandForm = 600;
 double program_wave_cycles(const Program& p) {
     if (p.n_streams > 1) {  // the tile is done when its slowest stream is
@@ -962,11 +963,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             // ready heaps per class, keyed by (height, -index)
             typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
             // (integer-class nodes: one heap per combination of operand / result forms, a bundle's header bits are uniform)
-            const int NH = (int)C_COUNT * 9;
+            const int NH = (int)C_COUNT * 17;
             std::vector<std::vector<Key>> heap(NH);
             auto push = [&](uint32_t i) {
                 int hc = class_of(g.nodes[i]);
-                if (is_integer_class(hc)) hc += (int)C_COUNT * (1 + node_vflags[i]);
+                if (hc == C_BIT) hc += (int)C_COUNT * (1 + node_vflags[i] + 8 * (g.nodes[i].op == OP_SHR || g.nodes[i].op == OP_BAND ? 1 : 0));  // (bundles of Shr / Band nodes take a straight path)
+                else if (is_integer_class(hc)) hc += (int)C_COUNT * (1 + node_vflags[i]);
                 else if (hc == C_CMPZ) hc += (int)C_COUNT * (1 + (node_vflags[i] & VF_OUT_CANON));
                 auto& h = heap[hc];
                 h.push_back(Key(height[i] + (prologue[i] ? kPrologueBoost : 0ull), tie_reverse ? i : ~i));
@@ -1461,6 +1463,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         if (cl == C_BIT) {
             bool all = true;
             for (uint32_t k = k0; k < k1; ++k) all = all && (ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK) == SUB_BITX;
+            bool limb_ops = true, any_shr = false;  // Shr and Band nodes only: the straight path
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK;
+                limb_ops = limb_ops && (sub == SUB_SHR || sub == SUB_BAND);
+                any_shr = any_shr || sub == SUB_SHR;
+            }
+            lin_bits |= !limb_ops ? 0u : any_shr ? HDR_BIT_ALL_SHR : HDR_BIT_ALL_BAND;
             if (all) {
                 lin_bits |= HDR_BITX_ALL;
                 st.n_bitx_bundles++;
@@ -1468,7 +1477,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 form_saved = form_bits & HDR_A_CANON ? kCyclesBitxOperandForm : 0.0;
             }
         }
-        if (is_integer_class(cl) && !(lin_bits & HDR_BITX_ALL))
+        if (cl == C_BIT && (lin_bits & (HDR_BIT_ALL_SHR | HDR_BIT_ALL_BAND)) && !(lin_bits & HDR_BITX_ALL))  // (straight path: measured with every form canonical)
+            form_saved = (form_bits & HDR_A_CANON ? kCyclesOperandForm : 0.0) + (form_bits & HDR_B_CANON ? kCyclesOperandForm : 0.0) +
+                         (form_bits & HDR_OUT_CANON ? kCyclesResultForm : 0.0) + kCyclesBitStraight;
+        else if (is_integer_class(cl) && !(lin_bits & HDR_BITX_ALL))
             form_saved = (form_bits & HDR_A_CANON ? kCyclesOperandForm : 0.0) + (form_bits & HDR_B_CANON ? kCyclesOperandForm : 0.0) +
                          ((form_bits & HDR_OUT_CANON) && cl != C_CMPS ? kCyclesResultForm : 0.0);
         if (b < s_first[stream] + s_count[stream]) {

@@ -513,6 +513,27 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     break;
                 }
                 const Fr y = (h & HDR_B_CANON) ? b_op : fr_from_mont(b_op);  // (canonical values, canonical copies of constants)
+                // the canonical result d in the form the users read: canonical, or Montgomery (booleans without a product)
+                auto bit_result = [&](const Fr& d) -> Fr {
+                    if (h & HDR_OUT_CANON) return d;
+                    const bool small = (d.v[0] < 2u) && ((d.v[1] | d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) == 0u);
+                    if (wave_any(!small)) return fr_mul_wave(d, fr_r2(), pv);
+                    return u256_select(d.v[0] != 0u, fr_one(), fr_zero());
+                };
+                if (h & (HDR_BIT_ALL_SHR | HDR_BIT_ALL_BAND)) {
+                    // every node is a Shr or a Band (limb arithmetic: Idiv / Mod by 2^n after the compiler's strength
+                    // reduction, masks).  Band: x & y <= min(x, y) < r, nothing to check; Shr: graph.rs:637-672, b >= 254 -> 0
+                    Fr d;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d.v[i] = x.v[i] & y.v[i];
+                    if (h & HDR_BIT_ALL_SHR) {  // (some or all of them shift)
+                        const bool big = (y.v[1] | y.v[2] | y.v[3] | y.v[4] | y.v[5] | y.v[6] | y.v[7]) != 0u || y.v[0] >= 254u;
+                        const Fr sh = u256_select(big, fr_zero(), u256_shr(x, big ? 0u : y.v[0]));
+                        d = u256_select(sub == SUB_SHR, sh, d);
+                    }
+                    r = bit_result(d);
+                    break;
+                }
                 uint32_t hi_or = 0;
 #pragma unroll
                 for (int i = 1; i < 8; ++i) hi_or |= y.v[i];
@@ -544,14 +565,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     }
                 }
                 // boolean-valued results (Num2Bits-style Band(x,1)) skip the Montgomery multiplication
-                const bool small = (d.v[0] < 2u) && ((d.v[1] | d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) == 0u);
-                if (h & HDR_OUT_CANON) {  // the users read the canonical integer
-                    r = d;
-                } else if (wave_any(!small)) {
-                    r = fr_mul_wave(d, fr_r2(), pv);
-                } else {
-                    r = u256_select(d.v[0] != 0u, fr_one(), fr_zero());
-                }
+                r = bit_result(d);
                 break;
             }
             case C_IDIVMOD: {  // graph.rs:112-121
@@ -559,16 +573,16 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const bool yz = u256_is_zero(y);
                 Fr ys = y;
                 ys.v[0] |= yz ? 1u : 0u;
-                // quotient digits (32 bits each) of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 bits
-                const uint32_t lx = u256_bitlen(x), ly = u256_bitlen(ys);
-                const uint32_t my_dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;  // 0..8
-                uint32_t dig = 0;  // wave-wide maximum by ballots (cheaper than a shuffle reduction: the range is tiny)
-#pragma unroll
-                for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
                 Fr q, rem;
-                if (!wave_any(lx > 128u || ly > 64u)) {
-                    u128_divrem_64(q, rem, x, ys);  // limb-sized operands everywhere in the wave: short division
+                if (!wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | ys.v[2] | ys.v[3] | ys.v[4] | ys.v[5] | ys.v[6] | ys.v[7]) != 0u)) {
+                    u128_divrem_64(q, rem, x, ys);  // limb-sized operands everywhere in the wave (x < 2^128, y < 2^64): short division
                 } else {
+                    // quotient digits (32 bits each) of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 bits
+                    const uint32_t lx = u256_bitlen(x), ly = u256_bitlen(ys);
+                    const uint32_t my_dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;  // 0..8
+                    uint32_t dig = 0;  // wave-wide maximum by ballots (cheaper than a shuffle reduction: the range is tiny)
+#pragma unroll
+                    for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
                     u256_divrem_digits(q, rem, x, ys, dig, ly);
                 }
                 const Fr d = u256_select(yz, fr_zero(), u256_select(sub == SUB_IDIV, q, rem));

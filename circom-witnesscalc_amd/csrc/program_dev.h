@@ -66,6 +66,9 @@ CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_L
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
 static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
+// C_BIT (the same two bits): every node of the bundle is a Shr or a Band (SHR: some shift; BAND alone: none does) -- limb arithmetic (Idiv / Mod by 2^n after the
+// compiler's strength reduction, masks) takes a straight path instead of the per-lane select over all five operations
+static const uint32_t HDR_BIT_ALL_SHR = 1u << 11, HDR_BIT_ALL_BAND = 1u << 12;
 // C_BIT / C_IDIVMOD / C_CMPS (integer operations on canonical values): every lane's first / second operand arrives as a
 // canonical integer (a value the compiler keeps in that form, or the canonical copy of a constant) -- the bundle skips
 // that operand's conversion out of Montgomery form; OUT: the result stays canonical (these classes and C_CMPZ's booleans).

@@ -222,6 +222,9 @@ def run(blob: Blob, inputs_row):
         if name == "BIT":
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
             assert ((h >> 13) & 1) == (1 if all_x else 0), "BITX header bit must describe the records"
+            subs = [blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK for jj in range(cnt)]
+            limb = all(s_ in (1, 3) for s_ in subs)  # Shr and Band nodes only: bit 11 if any shifts, else bit 12
+            lin_seen = 0 if not limb else (1 << 11) if 1 in subs else (1 << 12)
         else:
             assert ((h >> 13) & 1) == 0
         assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
