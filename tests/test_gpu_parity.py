@@ -724,7 +724,7 @@ def test_streams_two_and_four_wavefronts_per_tile(pkg):
     one, st1 = g.calc_witness_batch(rows[:1])  # (the single-call shape: one tile)
     assert not st1.any() and np.array_equal(one, want[:1])
     for seed in range(4):
-        data = C.build_random_dag(400 + seed, n_ops=600, panic_free=False).to_bin()
+        data = C.build_random_dag(400 + seed, n_ops=200, panic_free=False, parts=2 + seed).to_bin()
         g2, o2 = pkg.Graph(data), cbind.Graph(data)
         rows2 = cbind.ints_to_array([[1] + [random.Random(seed * 100 + i).randrange(model.M) for _ in range(g2.n_inputs - 1)] for i in range(40)])
         want2, wst2 = o2.evaluate_batch(rows2)

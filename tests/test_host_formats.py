@@ -289,6 +289,23 @@ def test_streams_split_the_independent_parts_of_a_graph(pkg, key):
             row += [v if trial == 0 else rnd.randrange(model.M) for v in inputs[name][:n]] + [0] * (n - len(inputs[name][:n]))
         got, st = pe.run(blob, row)
         assert st == 0 and got == model.evaluate(nodes, row, wit)
+    # fuzzed forests: independent random DAGs over every operation behind shared inputs (canonical and Montgomery values,
+    # inserted conversions, divisions in several streams, sets that panic)
+    for seed in range(4):
+        fb = C.build_random_dag(900 + seed, n_ops=120, panic_free=(seed % 2 == 0), parts=2 + seed)
+        fdata = fb.to_bin()
+        fnodes, fwit, _ = model.deserialize_witnesscalc_graph(fdata)
+        fblob = pe.Blob(pkg.Graph(fdata).export_blob(key))
+        assert fblob.n_streams == want_streams
+        for trial in range(3):
+            row = [1] + [rnd.randrange(model.M) if rnd.random() < 0.6 else rnd.randrange(1 << 10) for _ in range(6)]
+            got, st = pe.run(fblob, row)
+            try:
+                want = model.evaluate(fnodes, row, fwit)
+            except model.ReferencePanic:
+                assert st != 0
+                continue
+            assert st == 0 and got == want
     # a graph that is one piece keeps one stream
     one = pkg.Graph(C.build_sha256(64).to_bin())
     assert pe.Blob(one.export_blob(key)).n_streams == 1

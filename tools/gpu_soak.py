@@ -15,15 +15,18 @@ from tools.graphgen import circuits as C
 M = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 EDGE = [0, 1, 2, 3, 63, 64, 65, 127, 128, 253, 254, 255, 256, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, 1 << 64,
         (1 << 128) - 1, 1 << 200, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
-KEYS = [1, 2, 4, 8, 16, 32, 64, 1 | 0x100, 2 | 0x100, 8 | 0x100, 32 | 0x100, 1 | 0x200, 4 | 0x200, 16 | 0x200, 1 | 0x400, 2 | 0x400, 8 | 0x400]
+KEYS = [1, 2, 4, 8, 16, 32, 64, 1 | 0x100, 2 | 0x100, 8 | 0x100, 32 | 0x100, 1 | 0x200, 4 | 0x200, 16 | 0x200, 1 | 0x400, 2 | 0x400, 8 | 0x400,
+        1 | 0x800, 2 | 0x1000, 1 | 0x100 | 0x1000, 4 | 0x100 | 0x800, 8 | 0x1000, 16 | 0x100 | 0x1000]  # (0x800 / 0x1000: two / four streams per tile)
 def run(n_seeds, base, verbose=True):
     """returns the number of mismatching (graph, program) runs"""
     rnd = random.Random(base)
     bad = 0
     t0 = time.time()
     for s in range(n_seeds):
-        kind = rnd.choice(["dag", "dag", "dag_panic", "chains"])
-        if kind == "chains":
+        kind = rnd.choice(["dag", "dag", "dag_panic", "chains", "forest", "forest_panic"])
+        if kind.startswith("forest"):  # independent parts behind shared inputs: what the stream programs split
+            b, n_in = C.build_random_dag(rnd.randrange(1 << 30), n_ops=rnd.randrange(40, 250), panic_free=(kind == "forest"), parts=rnd.randrange(2, 6)), 7
+        elif kind == "chains":
             b, n_in = C.build_chain_heavy(rnd.randrange(1 << 30), n_chains=rnd.randrange(4, 20)), 6
         else:
             b, n_in = C.build_random_dag(rnd.randrange(1 << 30), n_ops=rnd.randrange(50, 600), panic_free=(kind == "dag")), 7

@@ -626,20 +626,20 @@ def authv2_reference_inputs():
     }
 
 
-def build_random_dag(seed, n_ops=400, n_inputs=6, ops=None, panic_free=True):
+def build_random_dag(seed, n_ops=400, n_inputs=6, ops=None, panic_free=True, parts=1):
     """Random DAG fuzzer over every evaluable op (all 20 DuoOps except Pow, Neg, TernCond).
     Operands are drawn mostly from recent nodes; small-value nodes (masks, booleans, small constants)
     are mixed in so that shifts / compares / bit ops see interesting ranges.  With `panic_free` the
     operand choice avoids the reference's two panic edges by construction (Shl only of values masked
-    to < 2^100 by < 128 bits; Bor/Bxor only of values masked to 253 bits)."""
+    to < 2^100 by < 128 bits; Bor/Bxor only of values masked to 253 bits).  `parts` > 1: that many independent DAGs of
+    n_ops operations each over the same inputs and a few shared operations next to them (what programs of several
+    streams split over wavefronts)."""
     rnd = random.Random(seed)
     b = Builder()
     ins = b.input("in", n_inputs)
+    hubs = [b.add(ins[1], ins[2]), b.mul(ins[2], ins[3])] if parts > 1 else []
     edge = [0, 1, 2, 3, 5, 63, 64, 65, 127, 128, 129, 191, 192, 193, 253, 254, 255, 256, R - 1, R - 2,
             R // 2, R // 2 + 1, R // 2 + 2, 1 << 253, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 200]
-    pool = list(ins)      # general values
-    small = []            # values known < 2^100
-    m253 = []             # values known < 2^253
     allops = ops or ["Mul", "Div", "Add", "Sub", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land",
                      "Lor", "Shl", "Shr", "Bor", "Band", "Bxor", "Neg", "TernCond"]
 
@@ -651,7 +651,13 @@ def build_random_dag(seed, n_ops=400, n_inputs=6, ops=None, panic_free=True):
             return lst[-1 - min(len(lst) - 1, int(rnd.expovariate(0.15)))]
         return rnd.choice(lst)
 
-    for _ in range(n_ops):
+    for step in range(n_ops * parts):
+        if step % n_ops == 0:  # (a new part starts from the inputs and the shared operations)
+            if step:
+                b.signal(pool[-1])
+            pool = list(ins) + hubs  # general values
+            small = []               # values known < 2^100
+            m253 = []                # values known < 2^253
         op = rnd.choice(allops)
         if op == "Neg":
             h = b.neg(pick())
