@@ -69,11 +69,13 @@ class Workload:
             self.name = "graph file %s" % os.path.basename(path)
             self.source = "CWC_GRAPH_BIN"
         else:
-            builder = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512)
+            # (bigint: BASELINE config 5's shape -- 32 limbs x 4000 rounds of multiply / long-divide / compare = 10.5 M nodes,
+            # depth 1.29 M; about two minutes of generation and graph compilation in front of the timed steps)
+            builder = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else C.build_bigint_class(k=32, rounds=4000)
             nodes, wit, self.inputs = builder.finalize()
             self.stats = graph_stats(nodes, wit)
             self.data = builder.to_bin()
-            self.name = "authV2-class graph" if kind == "authv2" else "sha256_512 graph"
+            self.name = {"authv2": "authV2-class graph", "sha256": "sha256_512 graph", "bigint": "bigint / long_div-class graph"}[kind]
             self.source = "generated (tools/graphgen): real circom graphs cannot be built offline"
         self.input_kind = "bits" if kind == "sha256" else "field"
 
@@ -125,8 +127,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=2, help="BASELINE config timed as `value`")
-    ap.add_argument("--batch-per-gpu", type=int, default=0, help="0 = the config's own (1024 / 4096 / 8192)")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2, help="BASELINE config timed as `value`")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="0 = the config's own (1024 / 4096 / 8192 / 32)")
     ap.add_argument("--graph", choices=["authv2", "sha256"], default=None, help="(old spelling of --config 2 / 3)")
     ap.add_argument("--tile-width", type=int, default=0, help="0 = the library's cost model")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="input sets timed on one host core (0 = skip)")
@@ -139,8 +141,10 @@ def main():
     if args.extra_batch == 0 and args.host_path == 0:
         args.extras = 0
     cfg = args.config
-    kind = "sha256" if cfg == 3 else "authv2"
-    B = args.batch_per_gpu or {2: 1024, 3: 4096, 4: 8192}[cfg]
+    kind = "sha256" if cfg == 3 else "bigint" if cfg == 5 else "authv2"
+    B = args.batch_per_gpu or {2: 1024, 3: 4096, 4: 8192, 5: 32}[cfg]
+    if cfg == 5:
+        args.extras = 0  # (the sub-records belong to the default run)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -206,7 +210,7 @@ def main():
                        "global set index * n_inputs + k; set 0 = the reference's input file" % cfg,
                        "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth,
                        "op_histogram": wl.stats["hist"], "batch_per_gpu": B, "tile_width": tm["tile_width"],
-                       "interpreter_waves_per_divider_wave": tm["divider"],
+                       "interpreter_waves_per_divider_wave": tm["divider"], "streams_per_tile": tm["streams"],
                        "bundles": tm["n_bundles"], "slots": tm["n_slots"], "sets_with_error_status": bad_sets,
                        "parallelism": "contiguous shards of one global batch x%d, cost-model program broadcast over RCCL" % world if distributed
                        else "single process, 1 GPU"},
