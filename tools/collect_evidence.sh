@@ -29,6 +29,9 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 python tools/gpu_host_path.py > $O/hostpath_$R.log 2>&1
 python tools/gpu_single_shot.py > $O/single_shot_$R.log 2>&1
 BIGINT_ROUNDS=4000 PROBE_T=0 python tools/gpu_bigint.py > $O/config5_$R.log 2>&1
+python bench.py --config 5 --cpu-sample 32 > $O/bench_config5_$R.json 2> $O/bench_config5_$R.err
+python tools/gpu_streams.py > $O/streams_$R.log 2>&1
+SOAK_SEEDS=20000 SOAK_BASE=20261003 python tools/gpu_soak.py > $O/soak_$R.log 2>&1
 bash tools/gpu_policies.sh "X=0 --" "CWC_NO_COOP_MUL=1 --" "CWC_COOP_FILL=32 CWC_COOP_SLACK=4000000000 --" "CWC_COOP_FILL=16 CWC_COOP_SLACK=2 --" \
     "CWC_SCHED_MUL_COST=47 CWC_SCHED_LIN_COST=12 --" "CWC_SCHED_MUL_COST=26 CWC_SCHED_LIN_COST=14 --" "CWC_SCHED_MUL_COST=30 CWC_SCHED_LIN_COST=24 --" \
     "CWC_PACK_V1=1 --" "X=0 -- --batch-per-gpu 256" "CWC_NO_COOP_MUL=1 -- --batch-per-gpu 256" > $O/policies_$R.log 2>&1
