@@ -140,7 +140,7 @@ static void fuse_bit_extract(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 14};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
 // The same for graphs whose linear nodes outnumber their multiplications (sha256-like: wide, LIN bundles are half of
 // the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
 // first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
@@ -149,12 +149,12 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 17
 // what a narrow bundle and a linear bundle cost (1 306 : 706 cycles in the product kernel = 26 : 14; measured best of
 // 26..40 : 14..24 on the authV2-class graph: 1024 sets 13.27 -> 12.19 ms, 256 sets 12.27 -> 10.52 ms; wider tiles, whose
 // multiplication bundles stay full-width, keep the table above: 8192 sets 32.6 ms with either, 33.4 ms with this one).
-static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 16, 1470, 25, 100, 110, 175, 38, 22, 22, 26};
-static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26};
+static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 16, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 16};
+static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 47};
 // What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
 // at the end of round 1 (MUL 2 100, LIN 670, request / collect 1 300).
-static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24};
+static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24, 14};
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -519,7 +519,7 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
 // Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
 // profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
-static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306};
+static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900};
 // (round 2, bigint-class graph with every operand and result canonical: BIT 2 650, IDIVMOD 2 880, CMPS 1 900 net of stamps)
 static const double kCyclesBitStraight = 1500;  // what a Shr-only / Band-only bundle saves against the per-lane select over all bit operations
 static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60, kCyclesOperandForm = 1200, kCyclesResultForm = 1450, kCyclesBitxOperandForm = 600;
@@ -941,8 +941,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         struct StreamSched {
             std::vector<uint32_t> order, bundle_start, div_lanes;
             std::vector<uint8_t> bundle_coop;
+            std::vector<uint32_t> bundle_flags;  // HDR_POST / HDR_WAIT: the bundle is a C_SYNC bundle
             uint64_t class_bundles[C_COUNT] = {0};
-            uint32_t n_div_requests = 0, last_prologue_bundle = 0;
+            uint32_t n_div_requests = 0;
             double cycles() const {
                 double c = 0;
                 for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)class_bundles[k];
@@ -951,14 +952,16 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         };
         // `so`: stream of every node; producers in another stream do not gate a node (the streams' phases do).  With
         // record = false nothing outside `ss` is written (pricing a candidate partition).
-        auto schedule_stream = [&](uint32_t s, const std::vector<uint8_t>& so, StreamSched& ss, bool record) -> bool {
+        auto schedule_stream = [&](uint32_t s, const std::vector<uint8_t>& so, StreamSched& ss, bool record, bool several) -> bool {
             std::vector<uint32_t> indeg(N, 0);
-            size_t remaining = 0;
+            size_t remaining = 0, prologue_left = 0;
+            bool posted = !(several && s == 0);  // stream 0 of several: a post bundle right behind the last prologue node
             for (size_t i = 0; i < N; ++i) {
                 if (g.nodes[i].kind == N_CONST) continue;
                 for (uint32_t u : users[i])
                     if (so[u] == s && so[i] == s) indeg[u]++;
                 remaining += so[i] == s;
+                prologue_left += so[i] == s && prologue[i];
             }
             // ready heaps per class, keyed by (height, -index)
             typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
@@ -983,14 +986,16 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             uint64_t clock = 0;
             std::vector<uint32_t> in_flight;  // nodes of the pending request
             uint64_t in_flight_ready = 0;
-            auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false) {
+            auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false, uint32_t sync_flags = 0) {
                 const uint32_t b = (uint32_t)ss.bundle_start.size();
                 ss.bundle_start.push_back((uint32_t)ss.order.size());
                 ss.bundle_coop.push_back(coop ? 1 : 0);
-                const int cl = request ? (int)C_DIVREQ : collect && divider ? (int)C_DIVGET : coop ? (int)C_MULQ : nodes.empty() ? (int)C_LIN : class_of(g.nodes[nodes[0]]);
+                ss.bundle_flags.push_back(sync_flags);
+                const int cl = sync_flags ? (int)C_SYNC : request ? (int)C_DIVREQ : collect && divider ? (int)C_DIVGET : coop ? (int)C_MULQ : nodes.empty() ? (int)C_LIN : class_of(g.nodes[nodes[0]]);
                 if ((unsigned)cl < (unsigned)C_COUNT) ss.class_bundles[cl]++;
+                (void)b;
                 for (uint32_t i : nodes) {
-                    if (prologue[i] && !request) ss.last_prologue_bundle = b;
+                    if (prologue[i] && !request) --prologue_left;
                     if (request) {
                         if (record) use_bundle_of[i] = b;
                         ss.order.push_back(i | REQ_FLAG);
@@ -1008,12 +1013,18 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     for (uint32_t u : users[i])
                         if (so[u] == s && --indeg[u] == 0) push(u);
             };
-            if (s != 0) {  // two idle bundles: the first one waits for stream 0's post (the values of the Input nodes), and
-                           // the staging loads of bundles 0 and 1 are issued before the loop, ahead of that wait
+            if (s != 0) {  // the wait for stream 0's post (the prologue's values), then two idle bundles: the staging loads of
+                           // bundles 0 and 1 are issued before the loop and those of bundle 2 in front of the wait
+                emit_bundle(picked, false, false, false, HDR_WAIT);
                 emit_bundle(picked, false, false);
                 emit_bundle(picked, false, false);
             }
             while (remaining) {
+                if (!posted && prologue_left == 0 && in_flight.empty()) {  // (the post's vmcnt(0) covers every store issued so far)
+                    emit_bundle(std::vector<uint32_t>(), false, false, false, HDR_POST);
+                    posted = true;
+                    continue;
+                }
                 int best = -1;
                 for (int c = 0; c < NH; ++c)
                     if (!heap[c].empty() && (best < 0 || heap[c].front() > heap[best].front())) best = c;
@@ -1117,6 +1128,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     clock += kClockCost[coop ? (int)C_MULQ : best % (int)C_COUNT];
                 }
             }
+            if (!posted) emit_bundle(std::vector<uint32_t>(), false, false, false, HDR_POST);
             return true;
         };
 
@@ -1227,17 +1239,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 s_first[s] = (uint32_t)bundle_start.size();
                 continue;
             }
-            if (!schedule_stream(s, stream_of, ss, true)) return false;
-            uint32_t nb = (uint32_t)ss.bundle_start.size();
-            uint32_t post_at = 0xffffffffu;
-            if (P > 1 && s == 0) {  // the post behind the Input bundles: their stores are complete two bundles later
-                post_at = ss.last_prologue_bundle + 2;
-                while (nb <= post_at) {
-                    ss.bundle_start.push_back((uint32_t)ss.order.size());
-                    ss.bundle_coop.push_back(0);
-                    ++nb;
-                }
-            }
+            if (!schedule_stream(s, stream_of, ss, true, P > 1)) return false;
+            const uint32_t nb = (uint32_t)ss.bundle_start.size();
             const uint32_t base = (uint32_t)bundle_start.size();
             s_first[s] = base;
             s_count[s] = nb;
@@ -1246,7 +1249,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             for (uint32_t b = 0; b < nb; ++b) {
                 bundle_start.push_back(obase + ss.bundle_start[b]);
                 bundle_coop.push_back(ss.bundle_coop[b]);
-                bundle_flags.push_back(b == post_at ? HDR_POST : (P > 1 && s != 0 && b == 0) ? HDR_WAIT : 0u);
+                bundle_flags.push_back(ss.bundle_flags[b]);
             }
             for (uint32_t e : ss.order) {
                 const uint32_t i = e & ~REQ_FLAG;
@@ -1356,7 +1359,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         const bool request = !idle && (order[k0] & REQ_FLAG) != 0, collect = !idle && is_collect(order[k0]);
         const bool coop = bundle_coop[b] != 0;
         const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ node's record is written COOP_LANES times (positions 4j .. 4j+3)
-        const int cl = idle ? (int)C_LIN : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
+        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
         uint32_t stream = 0;
         while (stream + 1 < P && b >= s_first[stream + 1]) ++stream;
         if (b == s_first[stream]) free_slots.clear();  // a slot is reused inside the stream that freed it only (the others run at their own pace)
@@ -1596,13 +1599,15 @@ bool validate_program(const Program& p, std::string& err) {
         const bool executed = b < p.stream_first[stream] + p.stream_count[stream];
         const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
         if (cls >= C_COUNT || (h >> 19) != 0) return bad("bundle " + std::to_string(b) + ": header");
-        // posts and waits: stream 0 posts once, every other stream waits in its first bundle (nothing else is compiled)
+        // posts and waits are C_SYNC bundles without nodes: stream 0 posts once, every other stream waits in its first bundle
+        // (nothing else is compiled)
+        if (((h & (HDR_POST | HDR_WAIT)) != 0) != (cls == C_SYNC) || (cls == C_SYNC && cnt != 0)) return bad("bundle " + std::to_string(b) + ": post / wait bits");
         if ((h & HDR_POST) && !(NS > 1 && stream == 0 && executed && n_posts++ == 0)) return bad("bundle " + std::to_string(b) + ": post");
         if (((h & HDR_WAIT) != 0) != (NS > 1 && stream != 0 && executed && b == p.stream_first[stream])) return bad("bundle " + std::to_string(b) + ": wait");
         if ((h & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
         if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ)) return bad("bundle " + std::to_string(b) + ": result form bit");
         const uint32_t rep = cls == C_MULQ ? COOP_LANES : 1u;
-        if ((cnt == 0 && cls != C_LIN) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
+        if ((cnt == 0 && cls != C_LIN && cls != C_SYNC) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
         if (!executed && cnt != 0) return bad("bundle " + std::to_string(b) + ": outside every stream");
         if (cls == C_MULQ && T > COOP_MAX_T) return bad("bundle " + std::to_string(b) + ": narrow bundle at this tile width");
         if ((cls == C_DIVREQ || cls == C_DIVGET) && !p.divider) return bad("bundle " + std::to_string(b) + ": request / collect without a divider");
@@ -1662,7 +1667,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 11;
+    h.version = 12;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -1683,7 +1688,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 11 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 12 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

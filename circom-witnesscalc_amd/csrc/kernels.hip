@@ -54,7 +54,8 @@ __device__ __forceinline__ bool mbox_wait(const volatile uint32_t* seq, uint32_t
     return false;
 }
 // Wait for another stream's post (a word in the tile's sync slot, read past the CU's vector cache).  Bounded like mbox_wait.
-__device__ __forceinline__ bool post_wait(uint32_t* word, uint32_t need) {
+__device__ __noinline__ bool post_wait(uint32_t* word, uint32_t need) {
+#pragma nounroll
     for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
         if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
         __builtin_amdgcn_s_sleep(8);
@@ -237,10 +238,11 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     uint32_t nq1 = cq == 0 ? CWC_P1 : cq == 1 ? CWC_P3 : cq == 2 ? CWC_P5 : CWC_P7;
     asm volatile("" : "+v"(nq0), "+v"(nq1));
     const uint32_t trash_doff = (p.n_const + p.n_slots) * 2u * HI | t16;
-    unsigned long long pf[C_COUNT][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
+    constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
+    unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
     if (PROF) {
 #pragma unroll
-        for (int c = 0; c < (int)C_COUNT; ++c) pf[c][0] = pf[c][1] = 0;
+        for (int c = 0; c < C_PROF; ++c) pf[c][0] = pf[c][1] = 0;
     }
 #define CWC_STAMP(var) unsigned long long var = 0; if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
 
@@ -270,25 +272,6 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         CWC_STAMP(st0);
         const uint32_t h = h_cur;
         asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        if (NW > 1 && (h & (HDR_POST | HDR_WAIT))) {  // (programs of several streams; a handful of bundles)
-            if (h & HDR_POST) {  // the stores of every bundle up to b - 2 are in memory: tell the other waves of the tile
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ++n_posts;
-                if (lane == 0) __hip_atomic_store(sync_words + stream, n_posts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (h & HDR_WAIT) {  // stream 0 waits for every other stream of its tile, the others for stream 0; the loads
-                                 // issued from here on (operands of bundle b + 2, third operands of b) see their values
-                ++n_waits;
-                bool ok = true;
-                if (stream != 0) {
-                    ok = post_wait(sync_words, n_waits);
-                } else {
-                    for (uint32_t s2 = 1; s2 < NS; ++s2)
-                        if (p.stream_count[s2]) ok = ok && post_wait(sync_words + s2, n_waits);
-                }
-                if (!ok) err_bits |= ST_DIVIDER_TIMEOUT;
-            }
-        }
         CWC_STAMP(st1);
         if constexpr (COOP) {
             uint32_t cls_q = h & HDR_CLASS_MASK;
@@ -396,7 +379,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring write belongs to this bundle
                 const unsigned long long t_now = __builtin_amdgcn_s_memtime();
     #pragma unroll
-                for (int c = 0; c < (int)C_COUNT; ++c)
+                for (int c = 0; c < C_PROF; ++c)
                     if (cls == (uint32_t)c) {
                         pf[c][0] += t_now - st0;  // cycles of this bundle in the pipelined loop (stamp bookkeeping excluded)
                         pf[c][1] += 1;
@@ -413,8 +396,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             }
         };
         Fr r;
-        // booleans in the form the bundle's users read: Montgomery (2^256 mod r) or the canonical integer 1
-        const Fr one_out = (h & HDR_OUT_CANON) ? Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}} : fr_one();
+        // booleans in the form the bundle's users read: Montgomery (2^256 mod r) or the canonical integer 1 (evaluated in the
+        // classes that produce booleans only: in front of the dispatch it costs every bundle ten issue slots)
+        auto one_out = [&]() -> Fr { return (h & HDR_OUT_CANON) ? Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}} : fr_one(); };
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul_wave(a_op, b_op, pv);
             // linear nodes riding in this bundle's free node slots (graph.rs:110-111)
@@ -488,7 +472,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             case C_CMPZ: {  // graph.rs:122-129 Eq/Neq, :134-135 Land/Lor
                 const bool az = u256_is_zero(a_op), cz = u256_is_zero(b_op), eq = u256_eq(a_op, b_op);
                 const bool v = sub == SUB_EQ ? eq : sub == SUB_NEQ ? !eq : sub == SUB_LAND ? (!az && !cz) : (!az || !cz);
-                r = u256_select(v, one_out, fr_zero());
+                r = u256_select(v, one_out(), fr_zero());
                 break;
             }
             case C_CMPS: {  // graph.rs:130-133 with u_lt/u_gt/u_lte/u_gte :723-769
@@ -498,7 +482,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const bool lt = same ? u256_lt(x, y) : xn;
                 const bool gt = same ? u256_lt(y, x) : yn;
                 const bool v = sub == SUB_LT ? lt : sub == SUB_GT ? gt : sub == SUB_LEQ ? !gt : !lt;
-                r = u256_select(v, one_out, fr_zero());
+                r = u256_select(v, one_out(), fr_zero());
                 break;
             }
             case C_BIT: {  // graph.rs:621-717
@@ -509,7 +493,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const bool is_x = sub == SUB_BITX;
                 if (h & HDR_BITX_ALL) {
                     const Fr e = u256_shr(x, kx);
-                    r = u256_select((e.v[0] & 1u) != 0u, one_out, fr_zero());
+                    r = u256_select((e.v[0] & 1u) != 0u, one_out(), fr_zero());
                     break;
                 }
                 const Fr y = (h & HDR_B_CANON) ? b_op : fr_from_mont(b_op);  // (canonical values, canonical copies of constants)
@@ -596,6 +580,27 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 r = u256_select(u256_is_zero(a_op), y, b_op);
                 break;
             }
+            case C_SYNC: {  // programs of several streams: post and / or wait (a handful of bundles per program)
+                r = fr_zero();
+                if (h & HDR_POST) {  // the stores of every earlier bundle are in memory: tell the other waves of the tile
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ++n_posts;
+                    if (lane == 0) __hip_atomic_store(sync_words + stream, n_posts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (h & HDR_WAIT) {  // stream 0 waits for every other stream of its tile, the others for stream 0; the loads issued
+                                     // from the next iteration on (operands of bundle b + 3, third operands of b + 1) see their values
+                    ++n_waits;
+                    bool ok = true;
+                    if (stream != 0) {
+                        ok = post_wait(sync_words, n_waits);
+                    } else {
+                        for (uint32_t s2 = 1; s2 < NS; ++s2)
+                            if (p.stream_count[s2]) ok = ok && post_wait(sync_words + s2, n_waits);
+                    }
+                    if (!ok) err_bits |= ST_DIVIDER_TIMEOUT;
+                }
+                break;
+            }
             default: r = fr_zero(); break;
         }
         finish(r);
@@ -612,7 +617,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     }
     if (PROF && lane == 0 && (tile % 64u) == 0u) {
 #pragma unroll
-        for (int c = 0; c < (int)C_COUNT; ++c) {
+        for (int c = 0; c < C_PROF; ++c) {
             atomicAdd(&prof[c * 4 + 0], pf[c][0]);
             atomicAdd(&prof[c * 4 + 3], pf[c][1]);
         }

@@ -33,7 +33,11 @@ enum BundleClass : uint32_t {
     // instead of 322 (fr_mul_coop4_gfx950.inc); value v = t + T * j sits in ring / stage cell v as in every other bundle.
     // The node's record is written four times (record positions 4j .. 4j+3): lane l takes record l / T like everywhere.
     C_MULQ = 11,    // graph.rs:105
-    C_COUNT = 12
+    // programs of several streams (wavefronts of one tile with their own bundle sequences): a bundle without nodes in which
+    // the wave posts -- every result of its earlier bundles is in memory -- and / or waits: a stream other than 0 for stream
+    // 0's next post, stream 0 for the next post of every other stream (header bits HDR_POST / HDR_WAIT)
+    C_SYNC = 12,
+    C_COUNT = 13
 };
 static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4;
 CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_LANES * T) : 0u; }  // nodes of a C_MULQ bundle
@@ -73,9 +77,8 @@ static const uint32_t HDR_BIT_ALL_SHR = 1u << 11, HDR_BIT_ALL_BAND = 1u << 12;
 // canonical integer (a value the compiler keeps in that form, or the canonical copy of a constant) -- the bundle skips
 // that operand's conversion out of Montgomery form; OUT: the result stays canonical (these classes and C_CMPZ's booleans).
 static const uint32_t HDR_B_CANON = 1u << 14, HDR_A_CANON = 1u << 17, HDR_OUT_CANON = 1u << 18;
-// Programs of several streams (wavefronts of one tile with their own bundle sequences): at the top of such a bundle the
-// wave first posts -- every result of its bundles up to two back is in memory -- and / or waits: a stream other than 0
-// for stream 0's next post, stream 0 for the next post of every other stream.
+// C_SYNC bundles: post and / or wait (see the class).  The loads a wave issues behind its wait are the staging loads of
+// the bundle three further on and the third-operand loads of the next bundle.
 static const uint32_t HDR_POST = 1u << 15, HDR_WAIT = 1u << 16;
 static const uint32_t MAX_STREAMS = 4;
 static const uint32_t CTRL_SUB_MASK = 7u, CTRL_ACTIVE = 8u, CTRL_MASK = 15u;

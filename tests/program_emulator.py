@@ -21,10 +21,10 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d41Q"
+HDR_FMT = "<12I12I6I12d43Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC"]
 COOP_LANES, COOP_MAX_T = 4, 4
 
 
@@ -41,7 +41,7 @@ class Blob:
         assert self.n_streams == 1 or self.divider in (0, 1), "streams have a divider wave each, or none"
         st = h[42:]
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:18], class_bundles=st[18:30], n_op_compiled=st[30], n_bitx_bundles=st[31], n_bitx_nodes=st[32], algorithmic_bytes_per_set=st[33], n_coop_rider_bundles=st[34], n_conversions=st[35], n_canonical=st[36], form_cycles_saved=st[37], n_folded=st[38], n_numbered=st[39], n_shaken=st[40])
+                          class_nodes=st[6:19], class_bundles=st[19:32], n_op_compiled=st[32], n_bitx_bundles=st[33], n_bitx_nodes=st[34], algorithmic_bytes_per_set=st[35], n_coop_rider_bundles=st[36], n_conversions=st[37], n_canonical=st[38], form_cycles_saved=st[39], n_folded=st[40], n_numbered=st[41], n_shaken=st[42])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -78,8 +78,9 @@ def run(blob: Blob, inputs_row):
     history = {}  # value slot -> list of (stream, bundle that stored, value)
     status = 0
     # Streams (wavefronts of the tile with their own bundle ranges) run at their own pace; what orders them is stream
-    # 0's post (every result of its bundles up to two back is in memory) and the wait in the first bundle of every
-    # other stream.  A slot belongs to the stream that writes it; another stream may read it only if it was written
+    # 0's post bundle (every result of its earlier bundles is in memory) and the wait bundle that every other stream
+    # starts with (the loads issued from the next iteration on see those results: the staging loads of the bundle three
+    # further on, the third-operand loads of the next bundle).  A slot belongs to the stream that writes it; another stream may read it only if it was written
     # once, before the post, and the read is issued behind the wait.
     post_at = None
     for b in range(blob.stream_first[0], blob.stream_first[0] + blob.stream_count[0]):
@@ -100,7 +101,7 @@ def run(blob: Blob, inputs_row):
         if hist[0][0] != stream:
             # (the slot may have held earlier values of stream 0; its last store is the one every other stream sees)
             assert hist[0][0] == 0 and stream != 0, "only values of stream 0 cross streams"
-            assert hist[-1][1] <= post_at - 2 and issued_at >= blob.stream_first[stream], "cross-stream read outside the post / wait order"
+            assert hist[-1][1] <= post_at - 1 and issued_at >= blob.stream_first[stream] + 1, "cross-stream read outside the post / wait order"
             cross_reads.add(s_ - NC)
             return hist[-1][2]
         for _, wb, val in reversed(hist):
@@ -122,7 +123,8 @@ def run(blob: Blob, inputs_row):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         name = CLASS_NAMES[cls]
-        assert h >> 19 == 0 and (1 <= cnt <= G or (cnt == 0 and name == "LIN"))
+        assert h >> 19 == 0 and (1 <= cnt <= G or (cnt == 0 and name in ("LIN", "SYNC")))
+        assert (name == "SYNC") == bool(h & (HDR_POST | HDR_WAIT)) and not (name == "SYNC" and cnt)
         a_canon, b_canon, out_canon = bool(h & HDR_A_CANON), bool(h & HDR_B_CANON), bool(h & HDR_OUT_CANON)
         assert not (a_canon or b_canon) or name in ("BIT", "IDIVMOD", "CMPS")
         assert not out_canon or name in ("BIT", "IDIVMOD", "CMPS", "CMPZ")
@@ -245,7 +247,7 @@ def run(blob: Blob, inputs_row):
             assert mailbox is None and n_requests == blob.stream_div_requests[stream]
     assert n_requests_total == blob.n_div_requests
     for slot in cross_reads:
-        assert history[slot][-1][1] <= post_at - 2, "a slot that other streams read is written again behind the post"
+        assert history[slot][-1][1] <= post_at - 1, "a slot that other streams read is written again behind the post"
 
     def wit(r):
         if r & REF_CONST:

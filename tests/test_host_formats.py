@@ -391,16 +391,16 @@ def test_schedule_quality_guard(pkg):
     class with the cycles measured on MI355X (compile.cc kCycles): authV2-class at T = 2 with the divider wave 30.5 M
     cycles in round 2 (narrow four-lane multiplication bundles; 33.0 M without them), sha256_512 at T = 1: 5 399 bundles."""
     import struct
-    cyc = dict(INPUT=4000, MUL=2015, LIN=706, DIV=73500, CMPZ=1000, CMPS=4700, BIT=2200, IDIVMOD=8500, TERN=1450, DIVREQ=1490, DIVGET=3700, MULQ=1306)
+    cyc = dict(INPUT=4000, MUL=2015, LIN=706, DIV=73500, CMPZ=1000, CMPS=4700, BIT=2200, IDIVMOD=8500, TERN=1450, DIVREQ=1490, DIVGET=3700, MULQ=1306, SYNC=900)
     g = pkg.Graph(C.build_authv2_class().to_bin())
     blob = g.export_blob(2 | DIVIDER)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[42:][18:30]))
+    cb = dict(zip(pe.CLASS_NAMES, h[42:][19:32]))
     est = sum(cyc[k] * v for k, v in cb.items())
     assert est <= 31.5e6 and cb["MULQ"] >= 3000 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0, (est, cb)
     blob = g.export_blob(4)
     h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[42:][18:30]))
+    cb = dict(zip(pe.CLASS_NAMES, h[42:][19:32]))
     assert h[4] <= 27500 and cb["DIV"] <= 275
     g = pkg.Graph(C.build_sha256(512).to_bin())
     h = struct.unpack_from(pe.HDR_FMT, g.export_blob(1), 0)
