@@ -277,6 +277,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             uint32_t cls_q = h & HDR_CLASS_MASK;
             asm volatile("" : "+s"(cls_q));
             if (cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
+                // (laid out behind the loop's main line: a taken branch costs a lone wave ~50 cycles, and two of three bundles are not narrow)
                 const uint32_t la = rec_hi.y + (t16c | (t16c << 16));
                 const Fr a_op = ld_lds(la & 0xffffu);
                 const uint2 bq = *reinterpret_cast<const uint2*>(ldsb + (la >> 16) + coop_chunk);
