@@ -1590,12 +1590,13 @@ bool validate_program(const Program& p, std::string& err) {
     bool in_flight = false;
     uint32_t stream = 0, stream_req = 0, cref_row = 0;
     for (uint32_t b = 0; b < p.n_bundles; ++b) {
-        if (b == p.stream_first[stream] && p.stream_count[stream] && p.stream_cref_first[stream] != cref_row) return bad("third-operand rows of stream " + std::to_string(stream));
         while (stream + 1 < NS && b >= p.stream_first[stream + 1]) {
             if (in_flight || stream_req != p.stream_div_requests[stream]) return bad("division requests of stream " + std::to_string(stream));
             ++stream;
             stream_req = 0;
         }
+        // (checked for the stream b belongs to: the interpreter wave of stream s starts its row counter at stream_cref_first[s])
+        if (b == p.stream_first[stream] && p.stream_count[stream] && p.stream_cref_first[stream] != cref_row) return bad("third-operand rows of stream " + std::to_string(stream));
         const bool executed = b < p.stream_first[stream] + p.stream_count[stream];
         const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
         if (cls >= C_COUNT || (h >> 19) != 0) return bad("bundle " + std::to_string(b) + ": header");
@@ -1604,6 +1605,8 @@ bool validate_program(const Program& p, std::string& err) {
         if (((h & (HDR_POST | HDR_WAIT)) != 0) != (cls == C_SYNC) || (cls == C_SYNC && cnt != 0)) return bad("bundle " + std::to_string(b) + ": post / wait bits");
         if ((h & HDR_POST) && !(NS > 1 && stream == 0 && executed && n_posts++ == 0)) return bad("bundle " + std::to_string(b) + ": post");
         if (((h & HDR_WAIT) != 0) != (NS > 1 && stream != 0 && executed && b == p.stream_first[stream])) return bad("bundle " + std::to_string(b) + ": wait");
+        // the staging loads of the two bundles behind a wait are issued in front of it: they must not read anything
+        if (NS > 1 && stream != 0 && executed && (b == p.stream_first[stream] + 1 || b == p.stream_first[stream] + 2) && cnt != 0) return bad("bundle " + std::to_string(b) + ": work right behind a wait");
         if ((h & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
         if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ)) return bad("bundle " + std::to_string(b) + ": result form bit");
         const uint32_t rep = cls == C_MULQ ? COOP_LANES : 1u;

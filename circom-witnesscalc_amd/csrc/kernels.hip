@@ -43,6 +43,7 @@ struct InterpDims {
     uint32_t n_streams, stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS], stream_cref_first[MAX_STREAMS];
 };
 static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox wait gave up (never expected)
+static const uint32_t ST_SYNC_TIMEOUT = 0x40000000u;     // internal: the wait for stream 0's post gave up (never expected)
 
 // Mailbox wait of the asynchronous divider protocol: sleeps until the sequence word reaches `need`.  Bounded, so that
 // a protocol bug ends the kernel with an error status instead of hanging the device.
@@ -588,17 +589,11 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     ++n_posts;
                     if (lane == 0) __hip_atomic_store(sync_words + stream, n_posts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (h & HDR_WAIT) {  // stream 0 waits for every other stream of its tile, the others for stream 0; the loads issued
-                                     // from the next iteration on (operands of bundle b + 3, third operands of b + 1) see their values
+                if (h & HDR_WAIT) {  // a stream other than 0 waits for stream 0's post (the compiler emits nothing else and the
+                                     // validator rejects a wait on stream 0); the loads issued from the next iteration on
+                                     // (operands of bundle b + 3, third operands of b + 1) see the prologue's values
                     ++n_waits;
-                    bool ok = true;
-                    if (stream != 0) {
-                        ok = post_wait(sync_words, n_waits);
-                    } else {
-                        for (uint32_t s2 = 1; s2 < NS; ++s2)
-                            if (p.stream_count[s2]) ok = ok && post_wait(sync_words + s2, n_waits);
-                    }
-                    if (!ok) err_bits |= ST_DIVIDER_TIMEOUT;
+                    if (!post_wait(sync_words, n_waits)) err_bits |= ST_SYNC_TIMEOUT;
                 }
                 break;
             }

@@ -405,6 +405,22 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     const uint32_t T = p.T;
     if (!g->last_done) HIP_TRY(hipEventCreateWithFlags(&g->last_done, hipEventDisableTiming));
     if (g->has_last && g->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, g->last_done, 0));
+    // From the first enqueue on, every way out (errors included) leaves the ordering state pointing at this stream: the
+    // next call on another stream waits for whatever was enqueued here (the workspace and the constant fill are shared).
+    struct OrderGuard {
+        gwb_graph* g;
+        hipStream_t stream;
+        ~OrderGuard() {
+            if (hipEventRecord(g->last_done, stream) == hipSuccess) {
+                g->last_stream = stream;
+                g->has_last = true;
+            } else {
+                (void)hipGetLastError();
+                g->has_last = false;
+                (void)hipDeviceSynchronize();  // (cannot order by event: nothing of this call is left in flight)
+            }
+        }
+    } order_guard{g, stream};
     // Workspace: tiles of (constants | value slots | trash slot), grouped into separately allocated chunks of at most
     // CWC_WORKSPACE_GB; larger batches than WS_MAX_CHUNKS chunks hold are evaluated in several launches.
     const uint64_t bytes_per_tile = ws_tile_bytes(p.n_const, p.n_slots, T);
@@ -485,10 +501,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         g->timing.n_launches++;
     }
     g->timing_pending = true;
-    HIP_TRY(hipEventRecord(g->last_done, stream));
     if (done_event) HIP_TRY(hipEventRecord(done_event, stream));
-    g->last_stream = stream;
-    g->has_last = true;
     return "";
 }
 
@@ -625,6 +638,7 @@ std::string set_status_text(uint32_t bits) {
     std::string s;
     if (bits & ST_SHL_OVERFLOW) s += "Shl result does not fit the field (reference panics at graph.rs:634)";
     if (bits & 0x80000000u) s += std::string(s.empty() ? "" : "; ") + "internal error: divider mailbox wait timed out";
+    if (bits & 0x40000000u) s += std::string(s.empty() ? "" : "; ") + "internal error: wait for another stream's post timed out";
     if (bits & ST_BITOP_EQ_R) s += std::string(s.empty() ? "" : "; ") + "bit operation result equals the modulus (reference panics at graph.rs:686/701/716)";
     return s;
 }
@@ -779,17 +793,26 @@ int gwb_inputs_from_json_batch(const gwb_graph_t* g, const char* text, size_t te
     if (n_threads > spans.size()) n_threads = (unsigned)spans.size();
     std::vector<std::string> errs(n_threads ? n_threads : 1);
     std::vector<size_t> bad(n_threads ? n_threads : 1, (size_t)-1);
-    auto work = [&](unsigned w) {
+    auto work = [&](unsigned w) {  // (no exception leaves a worker thread: it would end the process)
         const size_t lo = spans.size() * w / n_threads, hi = spans.size() * (w + 1) / n_threads;
-        InputList list;
-        for (size_t i = lo; i < hi; ++i) {
-            std::string e;
-            if (!deserialize_inputs(text + spans[i].first, spans[i].second - spans[i].first, list, e) ||
-                !populate_inputs(list, meta, (uint8_t*)rows + i * (size_t)g->n_inputs * 32, g->n_inputs, e)) {
-                errs[w] = e;
-                bad[w] = i;
-                return;
+        size_t i = lo;
+        try {
+            InputList list;
+            for (; i < hi; ++i) {
+                std::string e;
+                if (!deserialize_inputs(text + spans[i].first, spans[i].second - spans[i].first, list, e) ||
+                    !populate_inputs(list, meta, (uint8_t*)rows + i * (size_t)g->n_inputs * 32, g->n_inputs, e)) {
+                    errs[w] = e;
+                    bad[w] = i;
+                    return;
+                }
             }
+        } catch (const std::bad_alloc&) {
+            errs[w] = "out of memory";
+            bad[w] = i;
+        } catch (...) {
+            errs[w] = "internal error";
+            bad[w] = i;
         }
     };
     if (n_threads <= 1) {
@@ -797,9 +820,21 @@ int gwb_inputs_from_json_batch(const gwb_graph_t* g, const char* text, size_t te
         if (!spans.empty()) work(0);
     } else {
         std::vector<std::thread> th;
-        for (unsigned w = 1; w < n_threads; ++w) th.emplace_back(work, w);
+        struct Joiner {  // every started worker is joined on every way out (a thread that cannot be started included)
+            std::vector<std::thread>& th;
+            ~Joiner() {
+                for (auto& t : th)
+                    if (t.joinable()) t.join();
+            }
+        } joiner{th};
+        th.reserve(n_threads);
+        unsigned started = 1;
+        try {
+            for (; started < n_threads; ++started) th.emplace_back(work, started);
+        } catch (...) {  // (thread creation failed: the sets of the missing workers are parsed here)
+        }
         work(0);
-        for (auto& t : th) t.join();
+        for (unsigned w = started; w < n_threads; ++w) work(w);
     }
     for (unsigned w = 0; w < n_threads; ++w)
         if (bad[w] != (size_t)-1) return fail(status, "Failed to calculate witness: input set " + std::to_string(bad[w]) + ": " + errs[w]);
@@ -1098,7 +1133,6 @@ int gwb_graph_broadcast(gwb_graph_t* g, uint32_t tile_width, size_t batch_per_ra
                         gwb_graph_t** out, gw_status_t* status) {
     return guarded(status, [&]() -> int {
     if (!out || !nccl_comm) return fail(status, "null argument");
-    if (rank == root && !g) return fail(status, "the root rank needs a loaded graph");
     typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     typedef const char* (*errstr_fn)(int);
     bcast_fn bcast = (bcast_fn)dlsym(RTLD_DEFAULT, "ncclBroadcast");
@@ -1114,17 +1148,24 @@ int gwb_graph_broadcast(gwb_graph_t* g, uint32_t tile_width, size_t batch_per_ra
     hipStream_t stream = (hipStream_t)hip_stream;
     void* blob = nullptr;
     size_t blob_len = 0;
-    if (rank == root) {
+    // A failure on the root before the first collective must not leave the other ranks blocked in the length broadcast:
+    // the root then still broadcasts a length of 0, which every receiver rejects, and all ranks return an error together.
+    std::string root_err;
+    if (rank == root && !g) root_err = "the root rank needs a loaded graph";
+    if (rank == root && g) {
         if (!tile_width) {
-            if (!batch_per_rank) return fail(status, "tile_width = 0 needs the shard size");
-            tile_width = gwb_graph_pick_tile_width(g, batch_per_rank);
-            if (!tile_width) return fail(status, "no program for that batch size");
+            if (!batch_per_rank) root_err = "tile_width = 0 needs the shard size";
+            else if (!(tile_width = gwb_graph_pick_tile_width(g, batch_per_rank))) root_err = "no program for that batch size";
         }
-        gw_status_t st2{OK, nullptr};
-        if (gwb_graph_export(g, tile_width, &blob, &blob_len, &st2) != 0) {
-            std::string m = st2.error_msg ? st2.error_msg : "export failed";
-            gwb_free_status(&st2);
-            return fail(status, m);
+        if (root_err.empty()) {
+            gw_status_t st2{OK, nullptr};
+            if (gwb_graph_export(g, tile_width, &blob, &blob_len, &st2) != 0) {
+                root_err = st2.error_msg ? st2.error_msg : "export failed";
+                gwb_free_status(&st2);
+                free(blob);
+                blob = nullptr;
+                blob_len = 0;
+            }
         }
     }
     struct Bufs {
@@ -1140,14 +1181,20 @@ int gwb_graph_broadcast(gwb_graph_t* g, uint32_t tile_width, size_t batch_per_ra
     bufs.h_blob = blob;
     auto nccl_fail = [&](int rc, const char* what) { return fail(status, std::string(what) + ": " + (errstr ? errstr(rc) : "RCCL error " + std::to_string(rc))); };
     const int ncclUint8 = 1, ncclUint64 = 5;
-    unsigned long long len64 = blob_len;
+    // the root uploads its blob BEFORE the length goes out: an allocation or copy that fails there becomes length 0 too
+    if (rank == root && root_err.empty() &&
+        (hipMalloc(&bufs.d_blob, blob_len) != hipSuccess || hipMemcpy(bufs.d_blob, blob, blob_len, hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)hipGetLastError();
+        root_err = "hipMalloc / hipMemcpy of the program failed on the root rank";
+    }
+    unsigned long long len64 = root_err.empty() ? blob_len : 0;
     if (hipMalloc(&bufs.d_len, 8) != hipSuccess || hipMemcpy(bufs.d_len, &len64, 8, hipMemcpyHostToDevice) != hipSuccess) return fail(status, "hipMalloc failed");
     int rc = bcast(bufs.d_len, bufs.d_len, 1, ncclUint64, root, nccl_comm, stream);
     if (rc != 0) return nccl_fail(rc, "ncclBroadcast (length)");
     if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(&len64, bufs.d_len, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(status, "hipMemcpy failed");
-    if (len64 == 0 || len64 > (1ull << 40)) return fail(status, "bad program length in broadcast");
-    if (hipMalloc(&bufs.d_blob, (size_t)len64) != hipSuccess) return fail(status, "hipMalloc failed");
-    if (rank == root && hipMemcpy(bufs.d_blob, blob, (size_t)len64, hipMemcpyHostToDevice) != hipSuccess) return fail(status, "hipMemcpy failed");
+    if (!root_err.empty()) return fail(status, root_err);
+    if (len64 == 0 || len64 > (1ull << 40)) return fail(status, len64 == 0 ? "the root rank failed before the broadcast (program length 0)" : "bad program length in broadcast");
+    if (rank != root && hipMalloc(&bufs.d_blob, (size_t)len64) != hipSuccess) return fail(status, "hipMalloc failed");
     rc = bcast(bufs.d_blob, bufs.d_blob, (size_t)len64, ncclUint8, root, nccl_comm, stream);
     if (rc != 0) return nccl_fail(rc, "ncclBroadcast (program)");
     if (hipStreamSynchronize(stream) != hipSuccess) return fail(status, "hipStreamSynchronize failed");

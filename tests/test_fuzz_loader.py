@@ -130,3 +130,44 @@ def test_oversized_input_map_is_refused(pkg):
             pkg.Graph(serialize_graph(nodes, wit, {"a": (off, n)}))
     # a sane entry beyond the Input run only grows the buffer (reference: panic at lib.rs:158-161; here: reported size)
     assert pkg.Graph(serialize_graph(nodes, wit, {"a": (1, 1), "pad": (5, 3)})).n_inputs == 8
+
+
+def test_stream_programs_are_validated_for_every_stream(pkg):
+    """validate_program used to compare stream_cref_first with the running row count before moving on to the stream a
+    bundle belongs to, so the check only ever fired for stream 0; and the two bundles behind a wait have their staging
+    loads issued in front of it, so they must be idle.  A blob that is wrong there (checksum recomputed: a hostile or
+    buggy sender) is refused before anything reaches the device."""
+    import struct
+    from tests import program_emulator as E
+
+    def refnv(body):
+        h = 1469598103934665603
+        for byte in body:
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    g = pkg.Graph(C.build_random_dag(11, n_ops=150, parts=4).to_bin())
+    blob = g.export_blob(1 | 0x1000)
+    bl = E.Blob(blob)
+    assert bl.n_streams > 1
+    body, (exact, padded, _) = bytearray(blob[:-24]), struct.unpack("<3Q", blob[-24:])
+    with pytest.raises(pkg.WitnessCalcError, match="no HIP device"):
+        pkg.Graph.from_blob(blob)
+    tested = 0
+    for s in range(1, bl.n_streams):
+        if not bl.stream_count[s]:
+            continue
+        # (a) the stream's first third-operand row
+        d = bytearray(body)
+        pos = 4 * (24 + s)
+        struct.pack_into("<I", d, pos, bl.stream_cref_first[s] + 1)
+        with pytest.raises(pkg.WitnessCalcError, match="third-operand rows of stream %d" % s):
+            pkg.Graph.from_blob(bytes(d) + struct.pack("<3Q", exact, padded, refnv(d)))
+        # (b) work in the bundle right behind the wait: node count 1 in an idle bundle's header
+        d = bytearray(body)
+        b1 = bl.stream_first[s] + 1
+        assert (bl.hdr[b1] >> 4) & 0x7F == 0
+        struct.pack_into("<I", d, E.HDR_SIZE + 4 * b1, bl.hdr[b1] | (1 << 4))
+        with pytest.raises(pkg.WitnessCalcError, match="behind a wait|bundle %d" % b1):
+            pkg.Graph.from_blob(bytes(d) + struct.pack("<3Q", exact, padded, refnv(d)))
+        tested += 1
+    assert tested >= 1
