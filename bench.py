@@ -57,8 +57,8 @@ class Workload:
     """graph bytes + what is needed to make inputs for it and to check its witnesses"""
 
     def __init__(self, kind):
-        from tools.graphgen import circuits as C
-        from tools.graphgen.builder import graph_stats
+        C = pkg.graphgen.circuits
+        graph_stats = pkg.graphgen.builder.graph_stats
         self.kind = kind
         path = os.environ.get("CWC_GRAPH_BIN") if kind == "authv2" else None
         if path:
@@ -76,7 +76,7 @@ class Workload:
             self.stats = graph_stats(nodes, wit)
             self.data = builder.to_bin()
             self.name = {"authv2": "authV2-class graph", "sha256": "sha256_512 graph", "bigint": "bigint / long_div-class graph"}[kind]
-            self.source = "generated (tools/graphgen): real circom graphs cannot be built offline"
+            self.source = "generated (circom-witnesscalc_amd/graphgen, written through the C-ABI producer gwb_builder_*): real circom graphs cannot be built offline"
         self.input_kind = "bits" if kind == "sha256" else "field"
 
     def first_row(self, g):

@@ -63,6 +63,8 @@ EXPORTED_SYMBOLS = [
     "gwb_last_timing", "gwb_wtns_size", "gwb_wtns_from_witness", "gwb_graph_export", "gwb_graph_import",
     "gwb_free_status", "gwb_profile_classes", "gwb_pick_tile_width", "gwb_inputs_from_json_batch", "gwb_wtns_save_batch",
     "gwb_host_alloc", "gwb_host_free", "gwb_timing_history", "gwb_calc_witness_batch_handoff", "gwb_ubench_modmul", "gwb_graph_pick_tile_width", "gwb_graph_broadcast",
+    "gwb_builder_new", "gwb_builder_free", "gwb_builder_input", "gwb_builder_constant", "gwb_builder_uno", "gwb_builder_duo", "gwb_builder_tres",
+    "gwb_builder_witness", "gwb_builder_input_signal", "gwb_builder_node_count", "gwb_builder_finish",
 ]
 
 
@@ -124,6 +126,20 @@ def lib():
         L.gwb_graph_pick_tile_width.argtypes = [vp, sz]
         L.gwb_pick_tile_width.restype = ctypes.c_uint32
         L.gwb_pick_tile_width.argtypes = [sz]
+        u32 = ctypes.c_uint32
+        L.gwb_builder_new.restype = vp
+        L.gwb_builder_new.argtypes = []
+        L.gwb_builder_free.restype = None
+        L.gwb_builder_free.argtypes = [vp]
+        for name, args in (("input", [u32]), ("constant", [ctypes.c_char_p, sz]), ("uno", [u32, u32]), ("duo", [u32, u32, u32]), ("tres", [u32, u32, u32, u32])):
+            f = getattr(L, "gwb_builder_" + name)
+            f.restype = u32
+            f.argtypes = [vp] + args
+        L.gwb_builder_witness.argtypes = [vp, u32]
+        L.gwb_builder_input_signal.argtypes = [vp, ctypes.c_char_p, u32, u32]
+        L.gwb_builder_node_count.restype = ctypes.c_uint64
+        L.gwb_builder_node_count.argtypes = [vp]
+        L.gwb_builder_finish.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
         _lib = L
     return _lib
 
@@ -355,3 +371,6 @@ class Graph:
         if lib().gwb_last_timing(self._h, ctypes.byref(t)) != 0:
             raise WitnessCalcError("gwb_last_timing failed")
         return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+
+from . import graphgen  # noqa: E402,F401  (graph generator library on top of the C-ABI producer)

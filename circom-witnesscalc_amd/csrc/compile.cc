@@ -155,6 +155,10 @@ static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100,
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
 // at the end of round 1 (MUL 2 100, LIN 670, request / collect 1 300).
 static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24, 14};
+// The inversion entries of the three tables follow the cycle table (model_class_cycles(C_DIV) / 50): one number to change
+// when the inversion gets faster, and what CWC_MODEL_CYCLES overrides.
+static uint32_t div_cost50();
+static inline uint64_t cost_of(const uint32_t* table, int c) { return c == (int)C_DIV ? div_cost50() : table[c]; }
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -247,7 +251,7 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
             if (ar >= 1) t = rt[c.a];
             if (ar >= 2) t = std::max(t, rt[c.b]);
             if (ar >= 3) t = std::max(t, rt[c.c]);
-            m[i] = emit(c, t + class_cost[class_of(n)]);
+            m[i] = emit(c, t + cost_of(class_cost, class_of(n)));
             continue;
         }
         if (inner[i]) {
@@ -519,7 +523,29 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
 // Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
 // profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
-static const double kCycles[C_COUNT] = {4000, 2015, 706, 73500, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900};
+static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900};
+// (CWC_MODEL_CYCLES="class:cycles,..." overrides entries: what-if runs of the cost model and same-box recalibration)
+struct CycleTable {
+    double v[C_COUNT];
+    CycleTable() {
+        for (int c = 0; c < (int)C_COUNT; ++c) v[c] = kCyclesDefault[c];
+        if (const char* e = getenv("CWC_MODEL_CYCLES")) {
+            while (*e) {
+                char* end = nullptr;
+                const long c = strtol(e, &end, 10);
+                if (end == e || *end != ':') break;
+                const double cyc = strtod(end + 1, &end);
+                if (c >= 0 && c < (long)C_COUNT && cyc > 0) v[c] = cyc;
+                e = *end == ',' ? end + 1 : end;
+                if (*end != ',') break;
+            }
+        }
+    }
+    double operator[](int c) const { return v[c]; }
+};
+static const CycleTable kCycles;
+double model_class_cycles(int c) { return c >= 0 && c < (int)C_COUNT ? kCycles[c] : 0.0; }
+static uint32_t div_cost50() { return (uint32_t)(kCycles[C_DIV] / 50.0); }
 // (round 2, bigint-class graph with every operand and result canonical: BIT 2 650, IDIVMOD 2 880, CMPS 1 900 net of stamps)
 static const double kCyclesBitStraight = 1500;  // what a Shr-only / Band-only bundle saves against the per-lane select over all bit operations
 static const double kCyclesBitx = 1300, kCyclesCoopRiders = 60, kCyclesOperandForm = 1200, kCyclesResultForm = 1450, kCyclesBitxOperandForm = 600;
@@ -883,7 +909,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             if (g.nodes[i].kind == N_CONST) continue;
             uint64_t h = 0;
             for (uint32_t u : users[i]) h = std::max(h, height[u]);
-            height[i] = h + class_cost[class_of(g.nodes[i])];
+            height[i] = h + cost_of(class_cost, class_of(g.nodes[i]));
         }
         if (getenv("CWC_DEBUG_CRITICAL_PATH")) {  // diagnostic: class composition of the cost-weighted critical path
             uint32_t cur = 0xffffffffu;
@@ -1122,10 +1148,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     emit_bundle(picked, true, false);
                     in_flight = picked;
                     clock += kClockCost[C_DIVREQ];
-                    in_flight_ready = clock + kClockCost[C_DIV];
+                    in_flight_ready = clock + div_cost50();
                 } else {
                     emit_bundle(picked, false, false, coop);
-                    clock += kClockCost[coop ? (int)C_MULQ : best % (int)C_COUNT];
+                    clock += cost_of(kClockCost, coop ? (int)C_MULQ : best % (int)C_COUNT);
                 }
             }
             if (!posted) emit_bundle(std::vector<uint32_t>(), false, false, false, HDR_POST);

@@ -346,7 +346,8 @@ FRD int64_t mad_i64(int32_t a, int32_t b, int64_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     int64_t d;
     unsigned long long cy;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    // (volatile: the four accumulator chains of sgcd_update_all stay interleaved as written)
+    asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
     return d;
 #else
     return (int64_t)a * b + c;
@@ -403,44 +404,138 @@ FRD void sgcd_update_de(S30& d, S30& e, const Trans2x2& t) {
     e.v[8] = (int32_t)ce;
 }
 
+// c >>= 30 on a signed 64-bit accumulator as two 32-bit operations (funnel shift + arithmetic shift of the high word)
+FRD int64_t sgcd_sar30(int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CWC_SGCD_SHIFT64)
+    const uint32_t lo = (uint32_t)c, hi = (uint32_t)((uint64_t)c >> 32);
+    const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 30);
+    const int32_t nhi = (int32_t)hi >> 30;
+    return (int64_t)(((uint64_t)(uint32_t)nhi << 32) | nlo);
+#else
+    return c >> 30;
+#endif
+}
+// Both updates of a batch in one pass, the four accumulator chains (d, e, f, g) interleaved limb by limb: a
+// v_mad_i64_i32 whose result feeds the next instruction costs a wait state, four independent chains never wait
+// (round 2 ran update_de and update_fg one after the other: 75 of their 229 issue slots were s_nop).
+FRD void sgcd_update_all(S30& d, S30& e, S30& f, S30& g, const Trans2x2& t) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CWC_SGCD_CXX_UPDATE)
+    // one asm block (tools/codegen/gen_sgcd_update.py, emulated against big integers there): statement by statement the
+    // compiler pads every v_mad_i64_i32 with a wait state
+#if defined(CWC_SGCD_UPDATE_INC)
+#include CWC_SGCD_UPDATE_INC
+#else
+#include "sgcd_update_gfx950.inc"
+#endif
+    return;
+#endif
+    const int32_t M30 = 0x3fffffff;
+    const int32_t p30[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x3064};
+    const uint32_t pinv30 = 0x10000001u;  // r^-1 mod 2^30
+    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+    int32_t md = (t.u & sd) + (t.v & se);
+    int32_t me = (t.q & sd) + (t.r & se);
+    int64_t cd = mad_i64(t.u, d.v[0], 0);
+    int64_t ce = mad_i64(t.q, d.v[0], 0);
+    int64_t cf = mad_i64(t.u, f.v[0], 0);
+    int64_t cg = mad_i64(t.q, f.v[0], 0);
+    cd = mad_i64(t.v, e.v[0], cd);
+    ce = mad_i64(t.r, e.v[0], ce);
+    cf = mad_i64(t.v, g.v[0], cf);
+    cg = mad_i64(t.r, g.v[0], cg);
+    md -= (int32_t)((pinv30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+    me -= (int32_t)((pinv30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+    cf = sgcd_sar30(cf);  // the low 30 bits are zero by construction
+    cg = sgcd_sar30(cg);
+    cd = mad_i64(p30[0], md, cd);
+    ce = mad_i64(p30[0], me, ce);
+    cd = sgcd_sar30(cd);
+    ce = sgcd_sar30(ce);
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int32_t di = d.v[i], ei = e.v[i], fi = f.v[i], gi = g.v[i];
+        cd = mad_i64(t.u, di, cd);
+        ce = mad_i64(t.q, di, ce);
+        cf = mad_i64(t.u, fi, cf);
+        cg = mad_i64(t.q, fi, cg);
+        cd = mad_i64(t.v, ei, cd);
+        ce = mad_i64(t.r, ei, ce);
+        cf = mad_i64(t.v, gi, cf);
+        cg = mad_i64(t.r, gi, cg);
+        cd = mad_i64(p30[i], md, cd);
+        ce = mad_i64(p30[i], me, ce);
+        f.v[i - 1] = (int32_t)cf & M30;
+        g.v[i - 1] = (int32_t)cg & M30;
+        cf = sgcd_sar30(cf);
+        cg = sgcd_sar30(cg);
+        d.v[i - 1] = (int32_t)cd & M30;
+        e.v[i - 1] = (int32_t)ce & M30;
+        cd = sgcd_sar30(cd);
+        ce = sgcd_sar30(ce);
+    }
+    d.v[8] = (int32_t)cd;
+    e.v[8] = (int32_t)ce;
+    f.v[8] = (int32_t)cf;
+    g.v[8] = (int32_t)cg;
+}
+
 // Variable-time batch of 30 divsteps (delta = 1 convention, eta = -delta): trailing zeros of g are consumed in one
 // go and up to 6 low bits of g are cancelled per iteration with w = g * f * (f^2 - 2) (f odd: f*(f^2-2) = -1/f mod 64).
-// Lanes iterate until their own 30 steps are used up (exec-masked loop); ~3x fewer instructions than the
-// constant-time batch.  No secrets here, data-dependent time is fine.
+// No secrets here, data-dependent time is fine.
+//
+// Round 3: one iteration is straight-line code (selects instead of the divergent swap branch: a lone wavefront pays
+// ~50 cycles for every taken branch and the old loop had three per iteration), the low-bit products are 24-bit
+// multiplications (v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate; only the low six bits of them are used), and
+// the wave leaves the loop when every lane has used up its 30 steps -- a lane that is done idles exactly: with i == 0
+// the sentinel makes `zeros` 0, the swap is masked and the cancelled-bit count is 0.  Two iterations per exit test.
+FRD uint32_t sgcd_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;  // (written out: the optimiser turns __umul24 of unmasked operands back into the quarter-rate v_mul_lo_u32)
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return (a & 0xffffffu) * (b & 0xffffffu);
+#endif
+}
+FRD bool sgcd_any_lane(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(p) != 0ull;
+#else
+    return p;
+#endif
+}
 FRD int32_t sgcd_divsteps_30_var(int32_t eta, uint32_t f0, uint32_t g0, Trans2x2& t) {
     uint32_t u = 1, v = 0, q = 0, r = 1;
     uint32_t f = f0, g = g0;
-    int i = 30;
-    for (;;) {
-        // count trailing zeros of g, but at most i (sentinel bit)
-        const uint32_t gs = g | (0xffffffffu << i);
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int zeros = __builtin_ctz(gs);
-#else
-        const int zeros = __builtin_ctz(gs);
-#endif
-        g >>= zeros;
-        u <<= zeros;
-        v <<= zeros;
-        eta -= zeros;
-        i -= zeros;
-        if (i == 0) break;
-        if (eta < 0) {  // swap roles: (f, g) <- (g, -f), matrix rows alike
-            uint32_t tmp;
-            eta = -eta;
-            tmp = f; f = g; g = 0u - tmp;
-            tmp = u; u = q; q = 0u - tmp;
-            tmp = v; v = r; r = 0u - tmp;
+    int32_t i = 30;
+    do {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            // trailing zeros of g, at most i (sentinel bit)
+            const int32_t zeros = (int32_t)__builtin_ctz(g | (0xffffffffu << i));  // (i <= 30: the shift is defined)
+            g >>= zeros;
+            u <<= zeros;
+            v <<= zeros;
+            eta -= zeros;
+            i -= zeros;
+            // swap roles where eta < 0 (and steps are left): (f, g) <- (g, -f), matrix rows alike
+            const bool sw = eta < 0 && i != 0;
+            const uint32_t nf = 0u - f, nu = 0u - u, nv = 0u - v;
+            eta = sw ? -eta : eta;
+            const uint32_t f2 = sw ? g : f, g2 = sw ? nf : g;
+            const uint32_t u2 = sw ? q : u, q2 = sw ? nu : q;
+            const uint32_t v2 = sw ? r : v, r2 = sw ? nv : r;
+            f = f2; g = g2; u = u2; q = q2; v = v2; r = r2;
+            // cancel min(eta + 1, i, 6) low bits of g
+            int32_t limit = eta + 1 < i ? eta + 1 : i;
+            limit = limit < 6 ? limit : 6;
+            limit = limit < 0 ? 0 : limit;  // (a lane that is done with eta < 0: nothing left to cancel)
+            const uint32_t w = sgcd_mul24(sgcd_mul24(g, f), sgcd_mul24(f, f) - 2u) & ((1u << limit) - 1u);
+            g += f * w;
+            q += u * w;
+            r += v * w;
         }
-        // cancel min(eta + 1, i, 6) low bits of g
-        int limit = eta + 1 > i ? i : eta + 1;
-        limit = limit > 6 ? 6 : limit;
-        const uint32_t m = (1u << limit) - 1u;
-        const uint32_t w = (g * f * (f * f - 2u)) & m;
-        g += f * w;
-        q += u * w;
-        r += v * w;
-    }
+    } while (sgcd_any_lane(i != 0));
     t.u = (int32_t)u;
     t.v = (int32_t)v;
     t.q = (int32_t)q;
@@ -478,8 +573,7 @@ FRD Fr u256_inv_mod_r(const Fr& x) {
     for (int it = 0; it < 25; ++it) {  // 25 x 30 = 750 >= the 735-divstep bound of the delta = 1 variant
         Trans2x2 t;
         eta = sgcd_divsteps_30_var(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
-        sgcd_update_de(d, e, t);
-        sgcd_update_fg(f, g, t);
+        sgcd_update_all(d, e, f, g, t);
         int32_t gz = 0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) gz |= g.v[i];

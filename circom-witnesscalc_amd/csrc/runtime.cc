@@ -260,7 +260,7 @@ double estimate_cycles(const Program& p, size_t batch) {
         const double tiles = (double)((batch + p.T - 1) / p.T);
         const double t = program_wave_cycles(p);
         double busy = 0;  // SIMDs' worth of work per tile: every stream and divider wave for the share of t it is busy
-        for (uint32_t s = 0; s < p.n_streams; ++s) busy += (p.stream_cycles[s] + 73500.0 * p.stream_div_requests[s]) / t;
+        for (uint32_t s = 0; s < p.n_streams; ++s) busy += (p.stream_cycles[s] + model_class_cycles(C_DIV) * p.stream_div_requests[s]) / t;
         const double wgs = p.divider ? tiles : std::ceil(tiles * p.n_streams / 4.0);
         const double wg_per_cu = p.divider ? (p.n_streams == 4 ? 1.0 : 3.0) : 2.0;
         const double rounds = std::max(1.0, wgs / (256.0 * wg_per_cu));

@@ -52,6 +52,29 @@ int gwb_graph_info(const gwb_graph_t *g, gwb_graph_info_t *info);
 /* Re-serialize the loaded graph (serialize_witnesscalc_graph, src/storage.rs:137-183): *out is malloc'ed. */
 int gwb_graph_serialize(const gwb_graph_t *g, void **out, size_t *out_len, gw_status_t *status);
 
+/* Graph producer: what the reference's build-circuit does with a Vec<graph::Node> (src/graph.rs:236-245),
+ * the witness list and the InputSignalsInfo map before serialize_witnesscalc_graph (src/storage.rs:137-183, node encoding
+ * :50-91).  Nodes are pushed in topological order -- every operand index is an earlier node (src/graph.rs:343-356) -- and
+ * each push returns the node's index in the file, or GWB_BUILDER_BAD after an error (errors are sticky and reported by
+ * gwb_builder_finish).  Operation codes are the wire codes of protos/messages.proto:5-35 (DuoOp 0..19: Mul, Div, Add, Sub,
+ * Pow, Idiv, Mod, Eq, Neq, Lt, Gt, Leq, Geq, Land, Lor, Shl, Shr, Bor, Band, Bxor; UnoOp 0 Neg, 1 Id; TresOp 0 TernCond). */
+typedef struct gwb_builder gwb_builder_t;
+#define GWB_BUILDER_BAD 0xffffffffu
+gwb_builder_t *gwb_builder_new(void);
+void gwb_builder_free(gwb_builder_t *b);
+uint32_t gwb_builder_input(gwb_builder_t *b, uint32_t input_index);                 /* Node::Input */
+/* Node::MontConstant: value_le = little-endian bytes of the canonical value (any length; reduced mod r as the reader does) */
+uint32_t gwb_builder_constant(gwb_builder_t *b, const void *value_le, size_t value_len);
+uint32_t gwb_builder_uno(gwb_builder_t *b, uint32_t op, uint32_t a);                /* Node::UnoOp */
+uint32_t gwb_builder_duo(gwb_builder_t *b, uint32_t op, uint32_t a, uint32_t b_idx); /* Node::Op */
+uint32_t gwb_builder_tres(gwb_builder_t *b, uint32_t op, uint32_t a, uint32_t b_idx, uint32_t c); /* Node::TresOp */
+int gwb_builder_witness(gwb_builder_t *b, uint32_t node);                           /* append to witness_signals */
+int gwb_builder_input_signal(gwb_builder_t *b, const char *name, uint32_t offset, uint32_t len); /* InputSignalsInfo entry */
+uint64_t gwb_builder_node_count(const gwb_builder_t *b);
+/* serialize_witnesscalc_graph: *out is malloc'ed (`wtns.graph.001` container, loads in gw_calc_witness / gwb_graph_load
+ * and in the reference's deserialize_witnesscalc_graph). */
+int gwb_builder_finish(const gwb_builder_t *b, void **out, size_t *out_len, gw_status_t *status);
+
 /* JSON -> one inputs row of n_inputs x 32 bytes, canonical little-endian, row[0] = 1
  * (deserialize_inputs + get_inputs_buffer + populate_inputs, src/lib.rs:195-247, 177-181, 154-168). */
 int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *row, gw_status_t *status);

@@ -60,8 +60,10 @@ def test_gw_calc_witness_argument_errors(pkg):
 
 
 def test_bin_reader_and_writer_roundtrip(pkg):
+    from tools.graphgen.pywriter import serialize_graph
     for b in (C.build_circuit1(), C.build_gadgets(), C.build_poseidon(2), C.build_random_dag(5, n_ops=200)):
-        data = b.to_bin()
+        data = b.to_bin()                                   # the product's writer, through the C-ABI producer
+        assert data == serialize_graph(*b.finalize())       # ... against the independent pure-Python writer
         g = pkg.Graph(data)
         nodes, wit, ins = model.deserialize_witnesscalc_graph(data)
         assert g.n_nodes == len(nodes) and g.n_witness == len(wit)
@@ -73,8 +75,66 @@ def test_bin_reader_and_writer_roundtrip(pkg):
     assert pkg.Graph(open(os.path.join(GOLD, "circuit1.bin"), "rb").read()).serialize() == open(os.path.join(GOLD, "circuit1.bin"), "rb").read()
 
 
+def test_c_abi_graph_producer(pkg):
+    """gwb_builder_* is the producer side of the container (what build-circuit does with its Vec<Node>,
+    reference src/storage.rs:137-183 / :50-91).  All five node variants of the reference's round-trip test
+    (src/storage.rs:344-389) through the product writer: every record's bytes are the framing vectors of SURVEY 8(a) a13
+    / the independent Python writer's, the trailing u64 points at the metadata record, the oracle's reader gets the same
+    graph back; errors are sticky and reported by finish."""
+    import ctypes
+    import json
+    import struct
+    from tools.graphgen.pywriter import serialize_graph, encode_node, _varint
+    G = pkg.graphgen.builder
+    nodes = [("Input", 0), ("Const", 1), ("Uno", "Id", 1), ("Duo", "Mul", 0, 2), ("Tres", "TernCond", 1, 2, 3),
+             ("Const", (1 << 200) + 5), ("Uno", "Neg", 5), ("Duo", "Bxor", 6, 3)]
+    wit, ins = [4, 1, 7], {"sig1": (1, 3), "sig2": (5, 1)}
+    data = G.write_bin(nodes, wit, ins)
+    assert data == serialize_graph(nodes, wit, ins)
+    got_nodes, got_wit, got_ins = model.deserialize_witnesscalc_graph(data)
+    assert [tuple(n) for n in got_nodes] == nodes and list(got_wit) == wit and dict(got_ins) == ins
+    pos = 14 + 8
+    for n in nodes:  # record by record
+        body = encode_node(n)
+        rec = _varint(len(body)) + body
+        assert data[pos:pos + len(rec)] == rec, n
+        pos += len(rec)
+    assert struct.unpack_from("<Q", data, len(data) - 8)[0] == pos  # storage.rs:448-464
+    # the framing vectors of the reference-style records (tests/golden/kat_ops.json, SURVEY 8(a) a13) through the product writer
+    kat = json.load(open(os.path.join(GOLD, "kat_ops.json")))["node_framing"]
+    named = {"Input(0)": ("Input", 0), "Input(1)": ("Input", 1), "Input(2)": ("Input", 2), "Const(2)": ("Const", 2),
+             "Mul(2,3)": ("Duo", "Mul", 2, 3), "Add(4,0)": ("Duo", "Add", 4, 0)}
+    order = ["Input(0)", "Input(1)", "Input(2)", "Const(2)", "Mul(2,3)", "Add(4,0)"]
+    out = G.write_bin([named[k] for k in order], [0], {})
+    pos = 14 + 8
+    for k in order:
+        rec = bytes.fromhex(kat[k])
+        assert out[pos:pos + len(rec)] == rec, k
+        pos += len(rec)
+    # constants are field elements: a long / large byte string is reduced as the reader reduces it (storage.rs:28)
+    big = (model.M * 3 + 9) << 8
+    out = G.write_bin([("Const", big)], [0], {})
+    assert model.deserialize_witnesscalc_graph(out)[0][0] == ("Const", big % model.M)
+    # errors: forward reference, unknown operation code, witness beyond the graph -- sticky, reported by finish
+    with pytest.raises(pkg.WitnessCalcError, match="references node 4 that is not before it"):
+        G.write_bin([("Input", 0), ("Const", 1), ("Uno", "Id", 4)], [0], {})
+    with pytest.raises(pkg.WitnessCalcError, match="witness signal references node 9"):
+        G.write_bin([("Input", 0)], [9], {})
+    L = pkg.lib()
+    b = L.gwb_builder_new()
+    try:
+        assert L.gwb_builder_input(b, 0) == 0 and L.gwb_builder_duo(b, 20, 0, 0) == 0xFFFFFFFF  # (OP_BITX is not a wire code)
+        assert L.gwb_builder_input(b, 1) == 0xFFFFFFFF and L.gwb_builder_node_count(b) == 1
+        out_p, n, st = ctypes.c_void_p(), ctypes.c_size_t(), pkg.GwStatus()
+        assert L.gwb_builder_finish(b, ctypes.byref(out_p), ctypes.byref(n), ctypes.byref(st)) == 1
+        assert b"unknown DuoOp code 20" in ctypes.string_at(st.error_msg)
+        L.gwb_free_status(ctypes.byref(st))
+    finally:
+        L.gwb_builder_free(b)
+
+
 def test_bin_reader_accepts_unpacked_witness_and_long_constants(pkg):
-    from tools.graphgen.builder import _varint, _field_bytes, _field_varint, encode_node
+    from tools.graphgen.pywriter import _varint, _field_bytes, _field_varint, encode_node
     import struct
     nodes = [("Const", 0), ("Input", 0), ("Input", 1), ("Duo", "Add", 2, 0)]
     out = bytearray(b"wtns.graph.001") + struct.pack("<Q", len(nodes))

@@ -69,7 +69,7 @@ def test_inputs_json_reference_vector():
 
 def test_node_framing_vectors():
     # reference src/storage.rs:316-342 style records; bytes from SURVEY 8(a) a13
-    from tools.graphgen.builder import encode_node, _varint
+    from tools.graphgen.pywriter import encode_node, _varint
     nodes = {"Input(0)": ("Input", 0), "Input(1)": ("Input", 1), "Input(2)": ("Input", 2), "Const(2)": ("Const", 2),
              "Mul(2,3)": ("Duo", "Mul", 2, 3), "Add(4,0)": ("Duo", "Add", 4, 0)}
     for name, hx in KAT["node_framing"].items():
