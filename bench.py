@@ -18,6 +18,7 @@ line on rank 0.  Outside `value`, the same line carries (N = 1 unless said other
   config4            (every N) the config-4 job itself: a global batch of 8192 x N sets, contiguous shards, per-set checksums
                      of all ranks hashed and compared with the same job recomputed on rank 0 alone
   json_front_end     sets/s of the batched NDJSON -> rows front-end
+  e2e_json_to_wtns   NDJSON -> `.wtns` files on tmpfs through the streaming pipeline (parse | kernels | D2H slices | writers)
   pcie_inclusive     the host-buffer entry point (never `value`)
 
 `--config 3` / `--config 4` make one of those the timed `value` instead; CWC_GRAPH_BIN=<file.bin> runs a real graph
@@ -40,9 +41,13 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SEED = 0xC1C00000      # + config number
 # One-lane Montgomery products a node costs: Mul and Fr::new 1; a conversion out of Montgomery form is the
-# reduction half alone (0.5); Div = safegcd inversion (73.5 k lone-wave cycles against 1.44 k for a product) + 2 products.
-MODMUL_EQ = {"Mul": 1.0, "Input": 1.0, "Div": 53.0, "Lt": 1.0, "Gt": 1.0, "Leq": 1.0, "Geq": 1.0, "Shl": 2.0, "Shr": 2.0,
+# reduction half alone (0.5); Div = safegcd inversion (round 3: 52.2 k lone-wave cycles against 1.44 k for a product,
+# profiles/r03_inv_bench.txt; round 2 counted 53 for the 73.5 k-cycle inversion) + 2 products.
+MODMUL_EQ = {"Mul": 1.0, "Input": 1.0, "Div": 38.0, "Lt": 1.0, "Gt": 1.0, "Leq": 1.0, "Geq": 1.0, "Shl": 2.0, "Shr": 2.0,
              "Band": 2.0, "Bor": 2.0, "Bxor": 2.0, "Idiv": 6.0, "Mod": 6.0}
+
+
+CPU_SAMPLE = 1024  # --cpu-sample (0: no CPU baselines anywhere in the line)
 
 
 def log(*a):
@@ -57,6 +62,8 @@ class Workload:
     """graph bytes + what is needed to make inputs for it and to check its witnesses"""
 
     def __init__(self, kind):
+        import cwc_import
+        pkg = cwc_import.load()
         C = pkg.graphgen.circuits
         graph_stats = pkg.graphgen.builder.graph_stats
         self.kind = kind
@@ -140,6 +147,8 @@ def main():
         args.config = 3
     if args.extra_batch == 0 and args.host_path == 0:
         args.extras = 0
+    global CPU_SAMPLE
+    CPU_SAMPLE = args.cpu_sample
     cfg = args.config
     kind = "sha256" if cfg == 3 else "bigint" if cfg == 5 else "authv2"
     B = args.batch_per_gpu or {2: 1024, 3: 4096, 4: 8192, 5: 32}[cfg]
@@ -169,8 +178,10 @@ def main():
 
     # ---- graph: built on rank 0, compiled there, the cost model's program for a B-set shard broadcast over RCCL (xGMI) ----
     wl = Workload(kind) if rank == 0 else None
+    rccl_ranks = None
     if distributed:
-        g = cdist.broadcast_graph(pkg, wl.data if rank == 0 else None, args.tile_width, src=0, device=dev, batch_per_rank=B)
+        # the program goes out through the C-ABI collective (gwb_graph_broadcast on a RCCL communicator of this job's ranks)
+        g, rccl_ranks = cdist.broadcast_graph_rccl(pkg, wl.data if rank == 0 else None, args.tile_width, src=0, device=dev, batch_per_rank=B)
     else:
         g = pkg.Graph(wl.data)
         g.set_tile_width(args.tile_width)
@@ -185,10 +196,17 @@ def main():
     d_st = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
 
     elapsed = run_steps(g, d_in, d_out, d_st, args.steps, args.warmup, distributed)
+    per_rank_ms, n1_ms = None, None
     if distributed:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        all_t = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(all_t, te)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in all_t]
+        elapsed = max(float(x.item()) for x in all_t)
+        # the N = 1 step of the same run: rank 0 alone repeats its shard while the other ranks wait at the barrier
+        if rank == 0:
+            n1_ms = run_steps(g, d_in, d_out, d_st, args.steps, 1, False) / args.steps * 1e3
+        dist.barrier()
     bad_sets = int((d_st != 0).sum().item())
     tm, interp_ms, pack_ms = kernel_times(g, args.steps)
 
@@ -200,7 +218,13 @@ def main():
         achieved = alg_bytes / avg_interp_s / 1e9
         traffic, traffic_source = committed_traffic(kind, B, tm["tile_width"])
         eq_per_set = modmul_equivalents(wl.stats["hist"], g.n_witness)
-        peak4, peak1 = pkg.ubench_modmul(4, 1000), pkg.ubench_modmul(1, 1000)
+        # the ceiling that binds: one-lane Montgomery products per second, chip-wide, with the multiplier the interpreter's
+        # full-width bundles use (fr_mul_wave, 322 issue slots; its pinned accumulators allow two waves per SIMD) -- beside it
+        # the generic 380-slot multiplier at four waves per SIMD (round 2's denominator, which flattered the fraction)
+        peak_blk2, peak_blk1 = pkg.ubench_modmul(2, 1000, block=True), pkg.ubench_modmul(1, 1000, block=True)
+        peak4 = pkg.ubench_modmul(4, 1000)
+        peak = max(peak_blk2, peak_blk1, peak4)
+        ps = g.program_stats()
         out = {
             "metric": "witnesses/sec", "value": value, "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -215,18 +239,35 @@ def main():
                        "parallelism": "contiguous shards of one global batch x%d, cost-model program broadcast over RCCL" % world if distributed
                        else "single process, 1 GPU"},
             "field_ops_per_sec": value * g.n_op,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms, "n1_ms_per_step_same_run": n1_ms,
+            "efficiency_vs_n1": ((n1_ms / (elapsed / args.steps * 1e3)) if n1_ms else None),
+            "scaling_note": "weak scaling: every rank evaluates its own 1/N shard of one global batch of B x N sets; efficiency_vs_n1 = "
+                            "the step time of rank 0 alone on its shard (same run, other ranks idle) over the slowest rank's step time with "
+                            "all ranks busy.  No scaling curve has been measured by the builder: the GPU boxes of this pool have one GPU." if distributed else None,
+            "roofline": {"binding": "valu_issue: lone-wave instruction issue along the graph's dependency chain (see `compute`); the hbm "
+                                    "figures below are SURVEY 8(d)'s algorithmic-byte model, which this kernel does not run into "
+                                    "(operands are forwarded on chip: measured traffic is a fraction of the algorithmic bytes)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_interp_s * 1e3,
                          "pack_kernel_avg_ms": float(np.mean(pack_ms)),
                          "binding_resource": "valu_issue",
-                         "note": "`bound` names the model SURVEY 8(d) prescribes (algorithmic bytes against HBM peak); the counters say the "
-                                 "kernel is bound by instruction issue along the graph's dependency chain, see `compute`",
+                         "lanes_active_mean": ps["lanes_active_mean"],
+                         "lanes_active_note": "of a wavefront's 64 lanes, the mean number that hold a node of the graph, weighted by the "
+                                              "modelled time of the bundles (program statistics): what a lone wave pays per bundle does not "
+                                              "depend on it, which is why compute.frac is what it is",
+                         "program": {"class_bundles": ps["class_bundles"], "class_nodes": ps["class_nodes"], "fused_nodes": ps["n_fused_nodes"],
+                                     "model_wave_cycles": ps["model_wave_cycles"]},
                          "compute": {"unit": "modmul-equivalents/s", "achieved": eq_per_set * B / avg_interp_s,
-                                     "peak": peak4 or None, "frac": (eq_per_set * B / avg_interp_s / peak4) if peak4 else None,
-                                     "peak_source": "gwb_ubench_modmul in this run: one-lane Montgomery products/s chip-wide, 4 waves per SIMD",
-                                     "peak_one_wave_per_simd": peak1 or None, "modmul_equivalents_per_set": eq_per_set}},
+                                     "peak": peak or None, "frac": (eq_per_set * B / avg_interp_s / peak) if peak else None,
+                                     "peak_source": "measured in this run, chip-wide one-lane Montgomery products/s: the best of the interpreter's own "
+                                                    "multiplier (fr_mul_wave, 322 issue slots) at 2 and 1 waves per SIMD and the generic 380-slot "
+                                                    "multiplier at 4 waves per SIMD",
+                                     "peak_interpreter_multiplier_2_waves_per_simd": peak_blk2 or None,
+                                     "peak_interpreter_multiplier_1_wave_per_simd": peak_blk1 or None,
+                                     "peak_generic_multiplier_4_waves_per_simd": peak4 or None,
+                                     "modmul_equivalents_per_set": eq_per_set}},
         }
         if world == 1 and args.cpu_sample > 0:
             t0 = time.perf_counter()
@@ -234,6 +275,8 @@ def main():
             log("cpu_baseline: %.1f s" % (time.perf_counter() - t0))
     if args.extras:
         extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, out)
+        if rank == 0 and isinstance(out.get("config4"), dict) and "matches_single_gpu_digest" in out["config4"]:
+            out["matches_single_gpu_digest"] = out["config4"]["matches_single_gpu_digest"]
     if rank == 0:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
@@ -250,11 +293,14 @@ def extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, o
         if cfg == 2:
             out["pcie_inclusive"] = host_path_point(pkg, g, rows, d_out)
             out["json_front_end"] = json_front_end_point(wl, g)
+            t0 = time.perf_counter()
+            out["e2e_json_to_wtns"] = e2e_json_to_wtns_point(wl, g)
+            log("e2e_json_to_wtns: %.1f s" % (time.perf_counter() - t0))
         del d_out
         torch.cuda.empty_cache()
         if cfg != 3:
             t0 = time.perf_counter()
-            out["config3"] = config3_point(pkg, dev)
+            out["config3"] = config3_point(pkg, dev, cpu_sample=min(256, CPU_SAMPLE))
             log("config3: %.1f s" % (time.perf_counter() - t0))
         if cfg != 4 and wl.kind == "authv2":
             t0 = time.perf_counter()
@@ -308,7 +354,52 @@ def json_front_end_point(wl, g, n=4096):
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     return {"value": n / best, "unit": "input sets/s", "sets": n, "text_bytes": len(text), "seconds": best,
-            "threads": os.environ.get("CWC_PARSE_THREADS") or "min(cores, 16)", "matches_source_rows": bool(np.array_equal(got, src))}
+            "threads": os.environ.get("CWC_PARSE_THREADS") or "all cores (%d)" % (os.cpu_count() or 1), "matches_source_rows": bool(np.array_equal(got, src))}
+
+
+def e2e_json_to_wtns_point(wl, g, n=8192):
+    """SURVEY 8(f) f3 end to end: NDJSON of n input objects -> `.wtns` files on a memory file system, through the streaming
+    pipeline of gwb_calc_witness_json_to_wtns (parse threads | upload + kernels | device-to-host slices | writer threads).
+    The files of a round are deleted before the next one (n x 2.4 MB would not be polite to /dev/shm); 32 of them are
+    byte-compared with the oracle's `.wtns` first."""
+    import shutil
+    import tempfile
+    from oracle import cbind
+    from tools.synth import synth_inputs
+    per_round = 2048
+    src = synth_inputs("field", g.n_inputs, per_round, SEED + 9)
+    text = rows_to_ndjson(wl.inputs, src).encode()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="cwc_e2e_", dir=base)
+    try:
+        pat = os.path.join(d, "w_%06lu.wtns")
+        total_s, rounds, stats, ok_files, bad_status = 0.0, 0, None, True, 0
+        og = cbind.Graph(wl.data)
+        for r in range(max(1, n // per_round) + 1):  # (round 0 warms the handle up: workspace, program, pinned buffers)
+            t0 = time.perf_counter()
+            st, stats = g.json_to_wtns(text, pat, first_index=0)
+            dt = time.perf_counter() - t0
+            bad_status += int((st != 0).sum())
+            if r == 0:
+                sample = [0, 1, 2, 3, 511, 512, 513, 1023, 1024, 1500, 2046, 2047] + list(range(700, 720))
+                want, wst = og.evaluate_batch(src[sample])
+                for k, s_ in enumerate(sample):
+                    got = open(pat % s_, "rb").read()
+                    ok_files = ok_files and got[76:] == want[k].tobytes() and len(got) == 76 + g.n_witness * 32 and not wst[k]
+            else:
+                total_s += dt
+                rounds += 1
+            for f in os.listdir(d):
+                os.unlink(os.path.join(d, f))
+        sets = rounds * per_round
+        return {"value": sets / total_s, "unit": "witnesses/s", "sets": sets, "seconds": total_s, "rounds_of": per_round,
+                "file_system": "tmpfs (/dev/shm)" if base else "temporary directory", "witness_bytes_per_set": g.n_witness * 32,
+                "link_rate_GBs": sets * g.n_witness * 32 / total_s / 1e9, "sub_batch": stats["sub_batch"], "parse_threads": stats["parse_threads"],
+                "write_threads": stats["write_threads"], "parse_seconds_last_round": stats["parse_seconds"],
+                "wait_for_drain_seconds_last_round": stats["wait_for_drain_seconds"], "sets_with_error_status": bad_status,
+                "files_checked_against_oracle": 32, "matches_oracle_files": bool(ok_files)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def timed_batch(g, d_in, d_out, d_st, steps=3):
@@ -324,7 +415,7 @@ def timed_batch(g, d_in, d_out, d_st, steps=3):
     return dt, tm, float(np.mean(interp_ms)), float(np.mean(pack_ms))
 
 
-def config3_point(pkg, dev, batch=4096):
+def config3_point(pkg, dev, batch=4096, cpu_sample=256):
     """BASELINE config 3: sha256_512, 4096 sets on one GPU; EVERY set's 256 output bits against hashlib (an anchor outside
     this repository's arithmetic), 8 sets against the oracle as whole witnesses."""
     from oracle import cbind
@@ -343,7 +434,14 @@ def config3_point(pkg, dev, batch=4096):
     ok = int((wit_bits == want_bits).all(axis=1).sum()) if clean else 0
     og = cbind.Graph(wl.data)
     want, st = og.evaluate_batch(rows[:8])
+    cpu = None
+    if cpu_sample > 0:  # the same port of evaluate() on this graph: one pinned core and every core, on the first sets of the batch
+        cpu = cpu_baseline(wl.data, rows, d_out, min(cpu_sample, batch))
+        cpu["gpu_over_one_core"] = (batch / dt) / cpu["value"]
+        if "all_cores" in cpu:
+            cpu["gpu_over_all_cores"] = (batch / dt) / cpu["all_cores"]["value"]
     return {"workload": "sha256_512 graph, %d input sets, 1 GPU (BASELINE config 3)" % batch, "value": batch / dt, "unit": "witnesses/s",
+            "cpu_baseline": cpu,
             "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms, "tile_width": tm["tile_width"],
             "n_op": g.n_op, "n_witness": g.n_witness, "bundles": tm["n_bundles"],
             "sets_with_error_status": int((d_st != 0).sum().item()),
@@ -382,7 +480,7 @@ def config4_job(pkg, cdist, wl, dev, rank, world, distributed, per_gpu=8192):
     if distributed:
         if rank == 0 and wl.kind != "authv2":
             wl = Workload("authv2")
-        g = cdist.broadcast_graph(pkg, wl.data if rank == 0 else None, 0, src=0, device=dev, batch_per_rank=per_gpu)
+        g, _ = cdist.broadcast_graph_rccl(pkg, wl.data if rank == 0 else None, 0, src=0, device=dev, batch_per_rank=per_gpu)
     else:
         if wl.kind != "authv2":
             wl = Workload("authv2")
@@ -460,14 +558,25 @@ def cpu_baseline(graph_data, rows, d_out, n):
     from oracle import cbind
     og = cbind.Graph(graph_data)
     og.evaluate_batch(rows[:2])  # warm caches / page in
-    t, want, st = og.time_batch(rows[:n])
-    got = d_out[:n].cpu().numpy()
-    ok = st == 0
     aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    pinned = None
+    if aff:  # the timed thread stays on ONE core of the allowed set (the last one: core 0 takes the interrupts)
+        try:
+            os.sched_setaffinity(0, {aff[-1]})
+            pinned = aff[-1]
+        except OSError:
+            pinned = None
+    try:
+        t, want, st = og.time_batch(rows[:n])
+    finally:
+        if pinned is not None:
+            os.sched_setaffinity(0, set(aff))
+    got = d_out[:n].cpu().numpy() if d_out is not None else None
+    ok = st == 0
     out = {"value": n / t, "unit": "witnesses/s", "cores": 1, "kind": "port",
-           "affinity": "one thread, not pinned: scheduled by the OS on the process's %d allowed CPUs" % len(aff) if aff else "one thread",
+           "affinity": ("one thread pinned to CPU %d of the process's %d allowed CPUs" % (pinned, len(aff))) if pinned is not None else "one thread, not pinned",
            "sample": "first %d input sets of rank 0's batch, graph parsed once outside the timed window (B1 of BASELINE.md)" % n,
-           "seconds": t, "matches_gpu": bool(np.array_equal(got[ok], want[ok]))}
+           "seconds": t, "matches_gpu": bool(np.array_equal(got[ok], want[ok])) if got is not None else None}
     # reported beside it: the reference really re-parses the .bin per call (lib.rs:129) ...
     t0 = time.perf_counter()
     for _ in range(3):

@@ -34,6 +34,21 @@ class Timing(ctypes.Structure):
                 ("divider", ctypes.c_uint32), ("streams", ctypes.c_uint32)]
 
 
+class ProgramStats(ctypes.Structure):
+    _fields_ = [("tile_width", ctypes.c_uint32), ("divider", ctypes.c_uint32), ("streams", ctypes.c_uint32), ("n_classes", ctypes.c_uint32),
+                ("n_bundles", ctypes.c_uint64), ("n_fused_nodes", ctypes.c_uint64), ("class_bundles", ctypes.c_uint64 * 16),
+                ("class_nodes", ctypes.c_uint64 * 16), ("model_wave_cycles", ctypes.c_double), ("lanes_active_mean", ctypes.c_double)]
+
+
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF"]
+
+
+class E2eStats(ctypes.Structure):
+    _fields_ = [("n_sets", ctypes.c_size_t), ("sub_batch", ctypes.c_size_t), ("parse_threads", ctypes.c_uint32), ("write_threads", ctypes.c_uint32),
+                ("parse_seconds", ctypes.c_double), ("wait_for_drain_seconds", ctypes.c_double), ("total_seconds", ctypes.c_double),
+                ("witness_bytes", ctypes.c_uint64)]
+
+
 class Handoff(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("form", ctypes.c_uint32), ("hip_stream", ctypes.c_void_p), ("done_event", ctypes.c_void_p)]
 
@@ -65,6 +80,7 @@ EXPORTED_SYMBOLS = [
     "gwb_host_alloc", "gwb_host_free", "gwb_timing_history", "gwb_calc_witness_batch_handoff", "gwb_ubench_modmul", "gwb_graph_pick_tile_width", "gwb_graph_broadcast",
     "gwb_builder_new", "gwb_builder_free", "gwb_builder_input", "gwb_builder_constant", "gwb_builder_uno", "gwb_builder_duo", "gwb_builder_tres",
     "gwb_builder_witness", "gwb_builder_input_signal", "gwb_builder_node_count", "gwb_builder_finish",
+    "gwb_ubench_modmul_block", "gwb_program_stats", "gwb_calc_witness_json_to_wtns",
 ]
 
 
@@ -122,6 +138,10 @@ def lib():
         L.gwb_calc_witness_batch_handoff.argtypes = [vp, vp, sz, vp, vp, ctypes.POINTER(Handoff), stp]
         L.gwb_ubench_modmul.restype = ctypes.c_double
         L.gwb_ubench_modmul.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.gwb_ubench_modmul_block.restype = ctypes.c_double
+        L.gwb_ubench_modmul_block.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.gwb_program_stats.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ProgramStats)]
+        L.gwb_calc_witness_json_to_wtns.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(sz), vp, sz, ctypes.POINTER(E2eStats), stp]
         L.gwb_graph_pick_tile_width.restype = ctypes.c_uint32
         L.gwb_graph_pick_tile_width.argtypes = [vp, sz]
         L.gwb_pick_tile_width.restype = ctypes.c_uint32
@@ -168,8 +188,11 @@ def wtns_save_batch(witness, path_pattern):
     _check(rc, st)
 
 
-def ubench_modmul(waves_per_simd=4, iters=2000):
-    """Chip-wide one-lane Montgomery products per second (gwb_ubench_modmul)."""
+def ubench_modmul(waves_per_simd=4, iters=2000, block=False):
+    """Chip-wide one-lane Montgomery products per second (gwb_ubench_modmul; block: the interpreter's own multiplier,
+    gwb_ubench_modmul_block, at most two waves per SIMD)."""
+    if block:
+        return float(lib().gwb_ubench_modmul_block(waves_per_simd, iters))
     return float(lib().gwb_ubench_modmul(waves_per_simd, iters))
 
 
@@ -299,6 +322,20 @@ class Graph:
         _check(rc, st)
         return rows
 
+    def json_to_wtns(self, text, path_pattern, first_index=0):
+        """End to end, streaming (gwb_calc_witness_json_to_wtns): JSON array / NDJSON text -> one `.wtns` file per input set
+        (path_pattern with one %lu).  Returns (per-set status uint32 [B], stats dict)."""
+        if isinstance(text, str):
+            text = text.encode("utf-8")
+        n = ctypes.c_size_t()
+        cap = max(1, text.count(b"\n") + 1, text.count(b"{"))
+        status = np.zeros(cap, dtype=np.uint32)
+        es, st = E2eStats(), GwStatus()
+        rc = lib().gwb_calc_witness_json_to_wtns(self._h, text, len(text), path_pattern.encode(), first_index, ctypes.byref(n), status.ctypes.data, cap,
+                                                  ctypes.byref(es), ctypes.byref(st))
+        _check(rc, st)
+        return status[:n.value], {k: getattr(es, k) for k, _ in E2eStats._fields_}
+
     def calc_witness_batch(self, inputs, out=None):
         """Host buffers: inputs uint8 [B, n_inputs, 32] -> (witness uint8 [B, W, 32], status uint32 [B]).
         `out`: optional contiguous uint8 [B, W, 32] to fill (e.g. from pinned_rows, which skips the staging copy)."""
@@ -353,18 +390,30 @@ class Graph:
     def profile_classes(self, d_inputs, d_witness, d_status):
         """Diagnostic stamped build: {class: (cycles, 0, 0, bundles)} over sampled waves, plus "_sections":
         {"MUL" / "LIN": (top + staged-operand wait, LDS reads + previous bundle's stores, staging issue, arithmetic, ring write, bundles)}."""
-        out = np.zeros(64, dtype=np.uint64)
+        out = np.zeros(72, dtype=np.uint64)
         st = GwStatus()
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),
                                        d_status.data_ptr(), out.ctypes.data, ctypes.byref(st))
         _check(rc, st)
         names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
         res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
+        res["MULF"] = tuple(int(x) for x in out[64:68])
         res["_sections"] = {"MUL": tuple(int(x) for x in out[48:54]), "LIN": tuple(int(x) for x in out[56:62])}
         n = int(out[63])
         res["_waves"] = {"n": n, "max_cycles": int(out[54]), "min_cycles": (1 << 40) - int(out[55]) if n else 0,
                          "mean_cycles": int(out[62]) // n if n else 0}
         return res
+
+    def program_stats(self, key=0):
+        """Statistics of a compiled program (0: the one the last batch call used): gwb_program_stats."""
+        ps = ProgramStats()
+        if lib().gwb_program_stats(self._h, key, ctypes.byref(ps)) != 0:
+            raise WitnessCalcError("gwb_program_stats: no such program")
+        n = ps.n_classes
+        return {"tile_width": ps.tile_width, "divider": ps.divider, "streams": ps.streams, "n_bundles": ps.n_bundles,
+                "n_fused_nodes": ps.n_fused_nodes, "model_wave_cycles": ps.model_wave_cycles, "lanes_active_mean": ps.lanes_active_mean,
+                "class_bundles": {CLASS_NAMES[c]: int(ps.class_bundles[c]) for c in range(n) if ps.class_bundles[c]},
+                "class_nodes": {CLASS_NAMES[c]: int(ps.class_nodes[c]) for c in range(n) if ps.class_nodes[c]}}
 
     def last_timing(self):
         t = Timing()

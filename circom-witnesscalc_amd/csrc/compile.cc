@@ -16,8 +16,15 @@
 
 namespace cwc {
 
+// fused nodes (N_FUSED, made by fuse_narrow_chains below): op = sq | op2 << 1 | op3 << 4
+static inline bool fused_sq(uint8_t op) { return (op & 1u) != 0; }
+static inline uint32_t fused_op2(uint8_t op) { return (op >> 1) & 7u; }
+static inline uint32_t fused_op3(uint8_t op) { return (op >> 4) & 7u; }
+static inline uint8_t fused_code(bool sq, uint32_t op2, uint32_t op3) { return (uint8_t)((sq ? 1u : 0u) | (op2 << 1) | (op3 << 4)); }
+
 static int class_of(const Node& n) {
     switch (n.kind) {
+        case N_FUSED: return C_MULF;
         case N_INPUT: return C_INPUT;
         case N_UNO: return C_LIN;
         case N_TRES: return C_TERN;
@@ -35,7 +42,11 @@ static int class_of(const Node& n) {
     return -1;
 }
 
-static int arity_of(const Node& n) { return n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0; }
+// (a fused node's operands in a, b, c: the factor(s) of its product, then the operands of its second and third stage)
+static int arity_of(const Node& n) {
+    if (n.kind == N_FUSED) return fused_sq(n.op) ? 1 + (fused_op2(n.op) ? 1 : 0) + (fused_op3(n.op) ? 1 : 0) : 3;
+    return n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0;
+}
 
 // Exact strength reduction done before scheduling: Idiv(x, 2^k) == Shr(x, k) and Mod(x, 2^k) == Band(x, 2^k - 1) on the
 // canonical integers the reference divides (src/graph.rs:112-121 vs :637-672, :674-687), for every x < r and k <= 253.
@@ -140,7 +151,7 @@ static void fuse_bit_extract(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 14};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 14, 46};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
 // The same for graphs whose linear nodes outnumber their multiplications (sha256-like: wide, LIN bundles are half of
 // the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
 // first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
@@ -149,16 +160,21 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 17
 // what a narrow bundle and a linear bundle cost (1 306 : 706 cycles in the product kernel = 26 : 14; measured best of
 // 26..40 : 14..24 on the authV2-class graph: 1024 sets 13.27 -> 12.19 ms, 256 sets 12.27 -> 10.52 ms; wider tiles, whose
 // multiplication bundles stay full-width, keep the table above: 8192 sets 32.6 ms with either, 33.4 ms with this one).
-static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 16, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 16};
-static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 47};
+static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 16, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 16, 46};
+static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 47, 46};
 // What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
 // at the end of round 1 (MUL 2 100, LIN 670, request / collect 1 300).
-static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24, 14};
+static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24, 14, 44};
 // The inversion entries of the three tables follow the cycle table (model_class_cycles(C_DIV) / 50): one number to change
 // when the inversion gets faster, and what CWC_MODEL_CYCLES overrides.
 static uint32_t div_cost50();
 static inline uint64_t cost_of(const uint32_t* table, int c) { return c == (int)C_DIV ? div_cost50() : table[c]; }
+// a fused node costs its bundle's front end and its stages (cycles / 50: 600 + 704 per product + ~280 per addition)
+static inline uint64_t fused_cost50(uint8_t op) {
+    return 12u + 15u + (fused_op2(op) == FOP_MUL ? 15u : fused_op2(op) ? 6u : 0u) + (fused_op3(op) ? 6u : 0u);
+}
+static inline uint64_t node_cost(const uint32_t* table, const Node& n) { return n.kind == N_FUSED ? fused_cost50(n.op) : cost_of(table, class_of(n)); }
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -517,13 +533,120 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
     g.nodes.swap(out);
 }
 
+// ---- fused narrow chains (round 3) --------------------------------------------------------------------------------
+// A lone wavefront pays ~600 cycles for every bundle before any arithmetic (operand / record reads, staging loads, ring
+// write), and the graphs that bound small batches are ONE dependent chain for long stretches: a Poseidon partial round
+// of a lone Merkle chain is t -> t^2 -> t^4 -> (M t) t^4 -> + side sum, four bundles of one or two nodes.  A fused node
+// keeps such a sequence in the registers of the four lanes that share its product (class C_MULF): (s * s) * m + c, or
+// a * b +- c, is one node in one bundle.  Exact in the field (the same products and sums, graph.rs:105, 110-111); only
+// Mul / Add / Sub nodes whose values are in one form are touched, nothing that can fail.  The inner nodes stay wherever
+// something else -- a witness element, another node -- reads them (the product is then computed twice: once inside the
+// fused node on the critical chain, once off it in a lane that would idle), and die otherwise.
+// Only nodes within `slack` (scheduler cost units) of the graph's critical path are fused: off the critical path a fused
+// node saves nothing and takes one of the few node slots of a narrow bundle.
+static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, const uint32_t* class_cost, uint32_t slack_permille,
+                               uint64_t& n_fused) {
+    const size_t N = g.nodes.size();
+    std::vector<uint64_t> rt(N, 0), ht(N, 0);  // earliest finish time / longest path to a sink (own cost included in both)
+    std::vector<uint32_t> n_users(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (n.kind == N_CONST) continue;
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        uint64_t t = 0;
+        for (int q = 0; q < ar; ++q) {
+            t = std::max(t, rt[ops[q]]);
+            n_users[ops[q]]++;
+        }
+        rt[i] = t + node_cost(class_cost, n);
+    }
+    uint64_t cp = 0;
+    for (size_t i = N; i-- > 0;) {
+        const Node& n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        ht[i] += node_cost(class_cost, n);
+        cp = std::max(cp, rt[i] - node_cost(class_cost, n) + ht[i]);
+        const int ar = arity_of(n);
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < ar; ++q) ht[ops[q]] = std::max(ht[ops[q]], ht[i]);
+    }
+    const uint64_t slack = cp / 1000 * slack_permille;
+    auto is_mul = [&](uint32_t i) { return g.nodes[i].kind == N_DUO && g.nodes[i].op == OP_MUL; };
+    auto critical = [&](uint32_t i) { return rt[i] - node_cost(class_cost, g.nodes[i]) + ht[i] + slack >= cp; };
+    bool any = false;
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind != N_DUO || (n.op != OP_ADD && n.op != OP_SUB) || !critical((uint32_t)i)) continue;
+        // the product side: the later of the two operands if it is a multiplication
+        const bool a_mul = is_mul(n.a), b_mul = is_mul(n.b);
+        if (!a_mul && !b_mul) continue;
+        const bool take_a = a_mul && (!b_mul || rt[n.a] >= rt[n.b]);
+        const uint32_t m1 = take_a ? n.a : n.b, c = take_a ? n.b : n.a;
+        if (rt[m1] < rt[c]) continue;  // (the sum waits for its other operand: nothing to gain)
+        const uint32_t lin = n.op == OP_ADD ? FOP_ADD : take_a ? FOP_SUB : FOP_RSUB;
+        const Node& M1 = g.nodes[m1];
+        // (s * s) * m + c: the square on the product's later side
+        const uint32_t p = rt[M1.a] >= rt[M1.b] ? M1.a : M1.b, q = p == M1.a ? M1.b : M1.a;
+        const uint8_t r = rep[i];
+        if (M1.a != M1.b && is_mul(p) && g.nodes[p].a == g.nodes[p].b && rt[p] >= rt[q] && rep[p] == rep[g.nodes[p].a] && rep[m1] == r) {
+            n = Node{N_FUSED, fused_code(true, FOP_MUL, lin), g.nodes[p].a, q, c};
+        } else if (rep[m1] == r) {
+            n = Node{N_FUSED, fused_code(false, lin, FOP_NONE), M1.a, M1.b, c};
+        } else {
+            continue;
+        }
+        any = true;
+        ++n_fused;
+    }
+    if (!any) return;
+    // drop what nothing reads any more (roots: witness elements and everything that is not a plain Add / Mul / fused node)
+    std::vector<uint8_t> live(N, 0);
+    for (uint32_t w : g.witness_signals) live[w] = 1;
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const bool pure = n.kind == N_FUSED || (n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_SUB || n.op == OP_MUL)) || n.kind == N_CONST;
+        if (!pure) live[i] = 1;
+    }
+    for (size_t i = N; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < ar; ++q) live[ops[q]] = 1;
+    }
+    std::vector<uint32_t> pos(N, 0xffffffffu);
+    std::vector<Node> kept;
+    std::vector<uint8_t> krep, kfl;
+    kept.reserve(N);
+    for (size_t i = 0; i < N; ++i) {
+        if (!live[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+        krep.push_back(rep[i]);
+        kfl.push_back(vflags[i]);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
+    rep.swap(krep);
+    vflags.swap(kfl);
+}
+
 // Lone-wave shader cycles per bundle class in the product kernel (stamped build minus its five ~40-cycle stamps,
 // profiles/r02_class_profile.txt; check: 12 953 MUL + 7 258 LIN + 265 request / collect pairs -> 32.8 M cycles = 13.7 ms
 // at 2.4 GHz against 13.6 ms measured for the round-1 program).
 // Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
 // profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
-static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900};
+static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400};
+// a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
+// the second product / without additions saves
+static const double kCyclesFusedStageMul = 760, kCyclesFusedStageLin = 300;
 // (CWC_MODEL_CYCLES="class:cycles,..." overrides entries: what-if runs of the cost model and same-box recalibration)
 struct CycleTable {
     double v[C_COUNT];
@@ -569,7 +692,7 @@ double program_wave_cycles_mul_div(const Program& p) {
         return p.stream_cycles_mul_div[m];
     }
     return kCycles[C_MUL] * (double)p.stats.class_bundles[C_MUL] + kCycles[C_MULQ] * (double)p.stats.class_bundles[C_MULQ] +
-           kCycles[C_DIV] * (double)p.stats.class_bundles[C_DIV];
+           kCycles[C_MULF] * (double)p.stats.class_bundles[C_MULF] + kCycles[C_DIV] * (double)p.stats.class_bundles[C_DIV];
 }
 
 // When a multiplication step becomes a narrow (four lanes per product) bundle: `fill` or more ready multiplications make
@@ -580,6 +703,8 @@ struct CoopPolicy {
     uint32_t fill;
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
     bool all_montgomery = false;  // no representation inference: every value in Montgomery form
+    bool witness_slots = false;   // the slots of witness elements in witness order (see the slot allocation)
+    uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused
 };
 // The rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) depends on the fusion switch and on
 // the weight table only: the schedule variants of one compile_program call share it instead of redoing it.
@@ -603,16 +728,17 @@ bool probe_graph(const Graph& g, Program& out, std::string& err) { return compil
 // up in bundles: the program is compiled with and without the bit-extract fusion, then under a few narrow-bundle
 // policies, and the cheapest schedule by the measured cycles per bundle class (program_wave_cycles) is kept -- the
 // policies are not fitted to one graph, the cost model picks per graph and tile width.
-bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams) {
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams, bool quick) {
     const uint32_t G = T ? 64 / T : 1;
     CoopPolicy base{G, ~0u};  // narrow whenever everything ready fits
     if (const char* e = getenv("CWC_COOP_FILL")) base.fill = (uint32_t)atol(e);
     if (const char* e = getenv("CWC_COOP_SLACK")) base.slack_levels = (uint32_t)atol(e);
     const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
     if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
+    if (const char* e = getenv("CWC_WITNESS_SLOTS")) base.witness_slots = atoi(e) != 0;
     RewriteCache cache;
     if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) return false;
-    if (getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;
+    if (quick || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;  // (quick: the first call on a graph runs this one schedule while the search runs in the background)
     // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
     // authV2-class graph, and slower for multi-million-node graphs)
     bool fusion = true;
@@ -637,11 +763,30 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     }
     if (base.fill == 0 || forced || g.nodes.size() > 2000000) return true;  // (huge graphs: one schedule, compile time counts)
     const CoopPolicy more[] = {{0, 0}, {std::max(12u, G * 3 / 8), 0}, {G / 2, 2}, {G * 5 / 8, 2}};
+    CoopPolicy kept = base;
     for (CoopPolicy pol : more) {
         pol.all_montgomery = base.all_montgomery;
+        pol.witness_slots = base.witness_slots;
         Program alt;
         std::string err2;
-        if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) out = std::move(alt);
+        if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
+            out = std::move(alt);
+            kept = pol;
+        }
+    }
+    // Fused narrow chains (fuse_narrow_chains): how far from the critical path a chain is still fused is a policy too --
+    // only the critical chain, chains within a few percent of it, every chain -- and the cost model picks
+    // (CWC_FUSE=<thousandths + 1> forces one, CWC_NO_FUSE=1 none).
+    if (T <= COOP_FUSE_MAX_T && kept.fill && !getenv("CWC_NO_FUSE")) {
+        std::vector<uint32_t> tries = {1, 11, 101, 1001};
+        if (const char* e = getenv("CWC_FUSE")) tries.assign(1, (uint32_t)atoi(e));
+        for (uint32_t f : tries) {
+            CoopPolicy pol = kept;
+            pol.fuse = f;
+            Program alt;
+            std::string err2;
+            if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && (getenv("CWC_FUSE") || program_wave_cycles(alt) < program_wave_cycles(out))) out = std::move(alt);
+        }
     }
     return true;
 }
@@ -815,6 +960,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery);
     N = g.nodes.size();
     phase("representation inference");
+    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1) {
+        fuse_narrow_chains(g, node_rep, node_vflags, class_cost, policy.fuse - 1, st.n_fused_nodes);
+        N = g.nodes.size();
+        phase("fused narrow chains");
+    }
     // ---- constants -> table (Montgomery form), node -> ref ----
     std::vector<uint32_t> ref(N, 0);  // for consts: REF_CONST|idx ; for others: slot (filled later)
     for (size_t i = 0; i < N; ++i)
@@ -833,6 +983,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         if (is_integer_class(c)) return q < 2 && !(n.op == OP_BITX && q == 1);
         if (c == C_CMPZ) return (n.op == OP_EQ || n.op == OP_NEQ) && (node_vflags[i] & VF_A_CANON);
         if (c == C_LIN) return node_rep[i] == REP_C;
+        if (c == C_MULF) {  // the operand of an addition stage follows the node's form; a factor of a product is a Montgomery constant
+            const bool lin_operand = fused_sq(n.op) ? (q == 1 ? fused_op2(n.op) > FOP_MUL : q == 2) : (q == 2 && fused_op2(n.op) > FOP_MUL);
+            return lin_operand && node_rep[i] == REP_C;
+        }
         if (c == C_TERN) return q >= 1 && node_rep[i] == REP_C;
         return false;  // Mul / Div: Montgomery form
     };
@@ -909,7 +1063,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             if (g.nodes[i].kind == N_CONST) continue;
             uint64_t h = 0;
             for (uint32_t u : users[i]) h = std::max(h, height[u]);
-            height[i] = h + cost_of(class_cost, class_of(g.nodes[i]));
+            height[i] = h + node_cost(class_cost, g.nodes[i]);
         }
         if (getenv("CWC_DEBUG_CRITICAL_PATH")) {  // diagnostic: class composition of the cost-weighted critical path
             uint32_t cur = 0xffffffffu;
@@ -999,6 +1153,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 if (hc == C_BIT) hc += (int)C_COUNT * (1 + node_vflags[i] + 8 * (g.nodes[i].op == OP_SHR || g.nodes[i].op == OP_BAND ? 1 : 0));  // (bundles of Shr / Band nodes take a straight path)
                 else if (is_integer_class(hc)) hc += (int)C_COUNT * (1 + node_vflags[i]);
                 else if (hc == C_CMPZ) hc += (int)C_COUNT * (1 + (node_vflags[i] & VF_OUT_CANON));
+                else if (hc == C_MULF) {  // fused nodes: one heap per combination of stages (a bundle runs every stage one of its nodes has)
+                    const uint8_t op = g.nodes[i].op;
+                    hc += (int)C_COUNT * (1 + ((fused_op2(op) == FOP_MUL ? 1 : 0) | (fused_op2(op) > FOP_MUL ? 2 : 0) | (fused_op3(op) ? 4 : 0)));
+                }
                 auto& h = heap[hc];
                 h.push_back(Key(height[i] + (prologue[i] ? kPrologueBoost : 0ull), tie_reverse ? i : ~i));
                 std::push_heap(h.begin(), h.end());
@@ -1012,12 +1170,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             uint64_t clock = 0;
             std::vector<uint32_t> in_flight;  // nodes of the pending request
             uint64_t in_flight_ready = 0;
-            auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, bool coop = false, uint32_t sync_flags = 0) {
+            // coop: 0 full-width, 1 narrow multiplication bundle (C_MULQ), 2 fused narrow bundle (C_MULF)
+            auto emit_bundle = [&](const std::vector<uint32_t>& nodes, bool request, bool collect, int coop = 0, uint32_t sync_flags = 0) {
                 const uint32_t b = (uint32_t)ss.bundle_start.size();
                 ss.bundle_start.push_back((uint32_t)ss.order.size());
-                ss.bundle_coop.push_back(coop ? 1 : 0);
+                ss.bundle_coop.push_back((uint8_t)coop);
                 ss.bundle_flags.push_back(sync_flags);
-                const int cl = sync_flags ? (int)C_SYNC : request ? (int)C_DIVREQ : collect && divider ? (int)C_DIVGET : coop ? (int)C_MULQ : nodes.empty() ? (int)C_LIN : class_of(g.nodes[nodes[0]]);
+                const int cl = sync_flags ? (int)C_SYNC : request ? (int)C_DIVREQ : collect && divider ? (int)C_DIVGET : coop == 2 ? (int)C_MULF : coop ? (int)C_MULQ : nodes.empty() ? (int)C_LIN : class_of(g.nodes[nodes[0]]);
                 if ((unsigned)cl < (unsigned)C_COUNT) ss.class_bundles[cl]++;
                 (void)b;
                 for (uint32_t i : nodes) {
@@ -1041,13 +1200,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             };
             if (s != 0) {  // the wait for stream 0's post (the prologue's values), then two idle bundles: the staging loads of
                            // bundles 0 and 1 are issued before the loop and those of bundle 2 in front of the wait
-                emit_bundle(picked, false, false, false, HDR_WAIT);
+                emit_bundle(picked, false, false, 0, HDR_WAIT);
                 emit_bundle(picked, false, false);
                 emit_bundle(picked, false, false);
             }
             while (remaining) {
                 if (!posted && prologue_left == 0 && in_flight.empty()) {  // (the post's vmcnt(0) covers every store issued so far)
-                    emit_bundle(std::vector<uint32_t>(), false, false, false, HDR_POST);
+                    emit_bundle(std::vector<uint32_t>(), false, false, 0, HDR_POST);
                     posted = true;
                     continue;
                 }
@@ -1096,7 +1255,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 picked.clear();
                 auto& h = heap[best];
                 // a request must fit the interpreter's mailbox (mbox_lanes active lanes = node slots x T)
-                const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : G;
+                const bool fused = best >= (int)C_COUNT && best % (int)C_COUNT == (int)C_MULF;  // fused narrow bundle: at most coop_nodes(T) nodes
+                const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : fused ? (size_t)coop_nodes(T) : G;
                 bool coop = false;
                 if (best == C_MUL && coop_cap) {
                     // Narrow or full-width?  The ready multiplications in priority order; the ones within `coop_slack` of the
@@ -1129,6 +1289,17 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     h.pop_back();
                 }
                 std::sort(picked.begin(), picked.end());
+                if (fused && picked.size() < cap && !heap[C_MUL].empty()) {  // free groups of a fused bundle take ready plain multiplications
+                    auto& hm = heap[C_MUL];
+                    std::vector<uint32_t> extra;
+                    while (!hm.empty() && picked.size() + extra.size() < cap) {
+                        std::pop_heap(hm.begin(), hm.end());
+                        extra.push_back(tie_reverse ? hm.back().second : ~hm.back().second);
+                        hm.pop_back();
+                    }
+                    std::sort(extra.begin(), extra.end());
+                    picked.insert(picked.end(), extra.begin(), extra.end());
+                }
                 // A wave's time is the sum of its bundles and a multiplication bundle costs the same however few of its
                 // node slots are used: ready Add/Sub nodes ride in its free slots (the kernel then also runs the ~40-slot
                 // linear body, header bits) instead of asking for a bundle of their own later.
@@ -1150,11 +1321,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     clock += kClockCost[C_DIVREQ];
                     in_flight_ready = clock + div_cost50();
                 } else {
-                    emit_bundle(picked, false, false, coop);
+                    emit_bundle(picked, false, false, fused ? 2 : coop ? 1 : 0);
                     clock += cost_of(kClockCost, coop ? (int)C_MULQ : best % (int)C_COUNT);
                 }
             }
-            if (!posted) emit_bundle(std::vector<uint32_t>(), false, false, false, HDR_POST);
+            if (!posted) emit_bundle(std::vector<uint32_t>(), false, false, 0, HDR_POST);
             return true;
         };
 
@@ -1174,6 +1345,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             const bool narrow = coop_cap != 0;
             auto node_cycles = [&](int c) -> double {
                 if (c == C_MUL) return narrow ? kCycles[C_MULQ] : kCycles[C_MUL];
+                if (c == C_MULF) return kCycles[C_MULF];
                 if (c == C_DIV && divider) return kCycles[C_DIV] + kCycles[C_DIVREQ] + kCycles[C_DIVGET];
                 return kCycles[c];
             };
@@ -1216,7 +1388,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 }
                 Comp& co = comps[it->second];
                 co.cp = std::max(co.cp, cp[i]);
-                const double cap = c == C_MUL && narrow ? (double)coop_cap : c == C_DIV && divider ? std::max(1.0, (double)mbox_lanes(divider) / T) : (double)G;
+                const double cap = ((c == C_MUL && narrow) || c == C_MULF) ? (double)std::max<size_t>(1, coop_cap) : c == C_DIV && divider ? std::max(1.0, (double)mbox_lanes(divider) / T) : (double)G;
                 co.work += node_cycles(c) / cap;
                 co.nodes++;
             }
@@ -1318,7 +1490,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k] & ~REQ_FLAG] = k - bundle_start[b];
     enum { SRC_MEM = 0, SRC_RING = 1 };
     auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
-        if (q >= 2 || g.nodes[producer].kind == N_CONST) return SRC_MEM;
+        if ((q >= 2 && g.nodes[consumer].kind != N_FUSED) || g.nodes[producer].kind == N_CONST) return SRC_MEM;  // (TernCond reads its third operand in place)
         if (stream_of[producer] != stream_of[consumer]) return SRC_MEM;  // (another wave's ring)
         const uint32_t d = use_bundle_of[consumer] - bundle_of[producer];
         return (d >= 1 && d <= RING_BUNDLES) ? SRC_RING : SRC_MEM;
@@ -1361,6 +1533,18 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     double stream_form_saved[MAX_STREAMS] = {0, 0, 0, 0};
     std::vector<uint32_t> dying;  // nodes whose slot is released after the current bundle
     uint32_t n_slots = 0;
+    // Witness-ordered slots (policy.witness_slots): the pinned slot of a witness element is its rank among the witness
+    // list's distinct nodes, so the output gather (pack kernel) reads consecutive memory and every 128-byte line it
+    // fetches is used whole (tiles of one or two sets have 32- / 64-byte slots: with slots in schedule order the two
+    // halves of a line are fetched at different times, 1.56 x the algorithmic read volume measured in round 2).  The
+    // interpreter's stores / staging loads of such values then scatter: fine where it is bound by instruction issue,
+    // 15 % slower on the wide, memory-heavier sha256 graph (round 1) -- hence a policy.
+    std::vector<uint32_t> witness_rank;
+    if (policy.witness_slots) {
+        witness_rank.assign(N, 0xffffffffu);
+        for (uint32_t w : g.witness_signals)
+            if (g.nodes[w].kind != N_CONST && witness_rank[w] == 0xffffffffu) witness_rank[w] = n_slots++;
+    }
     const uint32_t zero_off = (uint32_t)((uint64_t)zero_const * slot_bytes);
     auto mem_off = [&](uint32_t producer) -> uint64_t {
         if (g.nodes[producer].kind == N_CONST) return (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes;
@@ -1383,9 +1567,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
         const bool idle = cnt == 0;  // (programs of several streams: padding around the posts and waits; an Add of zeros into the trash slot)
         const bool request = !idle && (order[k0] & REQ_FLAG) != 0, collect = !idle && is_collect(order[k0]);
-        const bool coop = bundle_coop[b] != 0;
-        const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ node's record is written COOP_LANES times (positions 4j .. 4j+3)
-        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
+        const bool coop = bundle_coop[b] != 0, fusedb = bundle_coop[b] == 2;
+        const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ / C_MULF node's records take COOP_LANES positions (4j .. 4j+3)
+        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : fusedb ? (int)C_MULF : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
         uint32_t stream = 0;
         while (stream + 1 < P && b >= s_first[stream + 1]) ++stream;
         if (b == s_first[stream]) free_slots.clear();  // a slot is reused inside the stream that freed it only (the others run at their own pace)
@@ -1420,7 +1604,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             const uint32_t js = k - k0;  // node slot
             uint32_t slot = 0xffffffffu;
             if (needs_slot[i] && !request) {
-                if (!free_slots.empty()) {
+                if (policy.witness_slots && witness_rank[i] != 0xffffffffu) {
+                    slot = witness_rank[i];
+                } else if (!free_slots.empty()) {
                     slot = free_slots.back();
                     free_slots.pop_back();
                 } else {
@@ -1432,15 +1618,45 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             // default: both operands unused -> staging loads of the zero constant, LDS reads of the own stage cells
             uint32_t off[2] = {zero_off, zero_off};
             uint32_t lds[2] = {stage + js * rep * T * 16u, stage + 2u * LDS_HALF_BYTES + js * rep * T * 16u};  // (C_MULQ: value t + T * js is loaded by lane 4 * T * js + t)
-            auto enc_operand = [&](uint32_t producer, int q) {
+            // operand `producer` (operand number q of the node): its ring cell, or its slot for the staging load into the own stage cell
+            auto enc_to = [&](uint32_t producer, int q, uint32_t& off_out, uint32_t& lds_out) {
                 if (route(producer, i, q) == SRC_RING) {
-                    lds[q] = LDS_RING_OFF + (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
+                    lds_out = LDS_RING_OFF + (bundle_of[producer] % RING_BUNDLES) * RING_SLOT_BYTES + pos_in_bundle[producer] * T * 16u;
                 } else {
                     const uint64_t o = g.nodes[producer].kind == N_CONST && reads_canonical_constants(i, q) ? (uint64_t)canon_const[producer] * slot_bytes : mem_off(producer);
-                    off[q] = (uint32_t)o;
+                    off_out = (uint32_t)o;
                 }
             };
+            auto enc_operand = [&](uint32_t producer, int q) { enc_to(producer, q, off[q], lds[q]); };
             uint32_t ctrl = CTRL_ACTIVE;
+            if (fusedb) {
+                // main record (positions 4j, 4j+2): the product's factors, destination, op2; extra record (4j+1, 4j+3): the
+                // operands of the second and third stage, op3.  A plain multiplication rides with op2 = op3 = none.
+                const bool is_f = n.kind == N_FUSED, sq = is_f && fused_sq(n.op);
+                const uint32_t op2 = is_f ? fused_op2(n.op) : FOP_NONE, op3 = is_f ? fused_op3(n.op) : FOP_NONE;
+                const uint32_t px = js * rep + 1u;  // the extra record's position: its own stage cells
+                uint32_t xoff[2] = {zero_off, zero_off};
+                uint32_t xlds[2] = {stage + px * T * 16u, stage + 2u * LDS_HALF_BYTES + px * T * 16u};
+                enc_to(n.a, 0, off[0], lds[0]);
+                if (sq) {
+                    enc_to(n.a, 0, off[1], lds[1]);
+                    if (op2) enc_to(n.b, 1, xoff[0], xlds[0]);
+                    if (op3) enc_to(n.c, 2, xoff[1], xlds[1]);
+                } else {
+                    enc_to(n.b, 1, off[1], lds[1]);
+                    if (op2) enc_to(n.c, 2, xoff[0], xlds[0]);
+                }
+                const uint32_t rm[4] = {off[0], off[1], slot, lds[0] | (lds[1] << 16)};
+                const uint32_t rx[4] = {xoff[0], xoff[1], 0xffffffffu, xlds[0] | (xlds[1] << 16)};
+                for (uint32_t x = 0; x < rep; ++x) {
+                    memcpy(&out.recs[((size_t)b * G + js * rep + x) * 4], (x & 1u) ? rx : rm, sizeof rm);
+                    ctrl_of[(size_t)b * G + js * rep + x] = (uint8_t)(CTRL_ACTIVE | ((x & 1u) ? op3 : op2));
+                }
+                const uint32_t fops[3] = {n.a, n.b, n.c};
+                for (int q = 0; q < arity_of(n); ++q)
+                    if (needs_slot[fops[q]] == 1 && last_mem_use[fops[q]] == b) dying.push_back(fops[q]);
+                continue;
+            }
             if (!collect)
             switch (n.kind) {
                 case N_INPUT:
@@ -1484,6 +1700,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             }
         }
         uint32_t lin_bits = 0;
+        if (cl == C_MULF) {  // which stages any node of the bundle has (the kernel runs those for every group)
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t op2 = ctrl_of[(size_t)b * G + (k - k0) * rep] & CTRL_SUB_MASK, op3 = ctrl_of[(size_t)b * G + (k - k0) * rep + 1] & CTRL_SUB_MASK;
+                lin_bits |= (op2 == FOP_MUL ? HDR_F_S2MUL : op2 ? HDR_F_S2LIN : 0u) | (op3 ? HDR_F_S3LIN : 0u);
+            }
+            form_saved = (lin_bits & HDR_F_S2MUL ? 0.0 : kCyclesFusedStageMul) + ((lin_bits & (HDR_F_S2LIN | HDR_F_S3LIN)) ? 0.0 : kCyclesFusedStageLin);
+        }
         if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {
                 const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0) * rep] & CTRL_SUB_MASK;
@@ -1548,7 +1771,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (uint32_t q = cnt; q < G; ++q) {  // inactive node slots: harmless operands, store -> trash, not ACTIVE
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
             r[0] = r[1] = zero_off;
-            r[2] = trash_off | (ctrl_of[(size_t)b * G] & CTRL_SUB_MASK);
+            r[2] = trash_off | (bundle_coop[b] == 2 ? 0u : ctrl_of[(size_t)b * G] & CTRL_SUB_MASK);  // (fused bundles: idle groups have no second / third stage)
             const uint32_t cell = (q / rep) * rep * T * 16u;  // (C_MULQ: the four positions of an idle group read one zero cell)
             r[3] = (stage + cell) | ((stage + 2u * LDS_HALF_BYTES + cell) << 16);
         }
@@ -1564,7 +1787,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         double c = 0, heavy = 0;
         for (int k = 0; k < (int)C_COUNT; ++k) c += kCycles[k] * (double)stream_class_bundles[s][k];
         c += kCyclesCoopRiders * (double)stream_riders[s] - (kCycles[C_BIT] - kCyclesBitx) * (double)stream_bitx[s] - stream_form_saved[s];
-        for (int k : {(int)C_MUL, (int)C_MULQ, (int)C_DIV}) heavy += kCycles[k] * (double)stream_class_bundles[s][k];
+        for (int k : {(int)C_MUL, (int)C_MULQ, (int)C_MULF, (int)C_DIV}) heavy += kCycles[k] * (double)stream_class_bundles[s][k];
         out.stream_cycles[s] = c;
         out.stream_chain_cycles[s] = s_chain[s];
         out.stream_cycles_mul_div[s] = heavy;
@@ -1635,8 +1858,9 @@ bool validate_program(const Program& p, std::string& err) {
         if (NS > 1 && stream != 0 && executed && (b == p.stream_first[stream] + 1 || b == p.stream_first[stream] + 2) && cnt != 0) return bad("bundle " + std::to_string(b) + ": work right behind a wait");
         if ((h & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
         if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ)) return bad("bundle " + std::to_string(b) + ": result form bit");
-        const uint32_t rep = cls == C_MULQ ? COOP_LANES : 1u;
+        const uint32_t rep = cls == C_MULQ || cls == C_MULF ? COOP_LANES : 1u;
         if ((cnt == 0 && cls != C_LIN && cls != C_SYNC) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
+        if (cls == C_MULF && T > COOP_FUSE_MAX_T) return bad("bundle " + std::to_string(b) + ": fused bundle at this tile width");
         if (!executed && cnt != 0) return bad("bundle " + std::to_string(b) + ": outside every stream");
         if (cls == C_MULQ && T > COOP_MAX_T) return bad("bundle " + std::to_string(b) + ": narrow bundle at this tile width");
         if ((cls == C_DIVREQ || cls == C_DIVGET) && !p.divider) return bad("bundle " + std::to_string(b) + ": request / collect without a divider");
@@ -1657,6 +1881,11 @@ bool validate_program(const Program& p, std::string& err) {
             // staging loads: 16 bytes per lane at off + 16 t and at off + HI + 16 t
             for (int k = 0; k < 2; ++k)
                 if ((r[k] % slot_bytes) != 0 || (uint64_t)r[k] + slot_bytes > tile_bytes) return bad("bundle " + std::to_string(b) + ": operand offset");
+            if (cls == C_MULF) {  // stage codes: op2 in the main records (even positions), op3 (additions only) in the extra records
+                const uint32_t code = r[2] & CTRL_SUB_MASK;
+                if ((q & 1u) ? (code == FOP_MUL || code > FOP_RSUB || (r[2] & ~CTRL_MASK) != trash_off) : code > FOP_RSUB) return bad("bundle " + std::to_string(b) + ": fused stage code");
+                if ((code == FOP_MUL && !(h & HDR_F_S2MUL)) || (code > FOP_MUL && !(h & ((q & 1u) ? HDR_F_S3LIN : HDR_F_S2LIN)))) return bad("bundle " + std::to_string(b) + ": fused stage bits");
+            }
             const uint32_t dst = r[2] & ~CTRL_MASK;
             if ((dst % slot_bytes) != 0 || dst < (uint64_t)p.n_const * slot_bytes || dst > trash_off) return bad("bundle " + std::to_string(b) + ": destination");
             const uint32_t la = r[3] & 0xffffu, lb = r[3] >> 16;
@@ -1696,7 +1925,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 12;
+    h.version = 13;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -1717,7 +1946,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 12 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 13 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

@@ -252,6 +252,16 @@ __device__ __forceinline__ void fr_mul_coop4r(const Fr& a, uint32_t aq0, uint32_
     out[0] = out[1] = 0;
 #endif
 }
+// (a + b) mod r (sub = 0) / (a - b) mod r (sub = 1) per group of four lanes, operands and result in the lane layout of the
+// cooperative product (lane 4v + q: limbs 2q, 2q+1): the later stages of a fused narrow bundle (class C_MULF).  60 issue slots.
+__device__ __forceinline__ void fr_addsub_coop4(uint32_t aq0, uint32_t aq1, uint32_t b0, uint32_t b1, uint32_t n0, uint32_t n1, uint32_t sub, uint32_t* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fr_addsub_coop4_gfx950.inc"
+#else
+    (void)aq0; (void)aq1; (void)b0; (void)b1; (void)n0; (void)n1; (void)sub;
+    out[0] = out[1] = 0;
+#endif
+}
 #endif
 FRD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 

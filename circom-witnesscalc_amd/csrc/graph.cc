@@ -3,6 +3,8 @@
 
 #include <string.h>
 
+#include <thread>
+
 #include <algorithm>
 
 namespace cwc {
@@ -367,29 +369,47 @@ size_t inputs_buffer_size(const Graph& g) {
 // inputs JSON (lib.rs:195-247).  A small strict JSON reader: the reference parses the whole document
 // with serde_json first (invalid JSON -> panic there, error here), then classifies the values.
 // ---------------------------------------------------------------------------------------------
-bool u256_parse_dec(const std::string& s, Fr& out, std::string& err) {
-    // U256::from_str_radix(s, 10) [ext: ruint 1.12]: digits (underscores skipped), must fit 256 bits.
+// U256::from_str_radix(s, 10) [ext: ruint 1.12]: digits (underscores skipped), must fit 256 bits.  Nine digits per
+// multiply-add pass over the limbs (the batched JSON front-end parses ~10^5 such numbers per thousand input sets).
+bool u256_parse_dec_span(const char* s, size_t n, Fr& out, std::string& err) {
+    static const uint32_t kPow10[10] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u, 1000000000u};
     Fr acc = fr_zero();
-    for (char ch : s) {
+    uint32_t chunk = 0, digits = 0;
+    auto flush = [&]() -> bool {
+        uint64_t c = chunk;
+        const uint64_t m = kPow10[digits];
+        for (int i = 0; i < 8; ++i) {
+            c += (uint64_t)acc.v[i] * m;
+            acc.v[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        chunk = 0;
+        digits = 0;
+        return c == 0;
+    };
+    for (size_t k = 0; k < n; ++k) {
+        const char ch = s[k];
         if (ch == '_') continue;
         if (ch < '0' || ch > '9') {
             err = std::string("InputFieldNumberParseError(InvalidDigit('") + ch + "'))";
             return false;
         }
-        uint64_t c = (uint64_t)(ch - '0');
-        for (int i = 0; i < 8; ++i) {
-            c += (uint64_t)acc.v[i] * 10u;
-            acc.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        if (c) {
+        chunk = chunk * 10u + (uint32_t)(ch - '0');
+        if (++digits == 9 && !flush()) {
+            // (which of two errors in ONE string is named can differ from a digit-serial parser when an invalid character
+            // follows the overflowing digit inside the same group of nine; either way the input is refused)
             err = "InputFieldNumberParseError(BaseOverflow)";
             return false;
         }
     }
+    if (digits && !flush()) {
+        err = "InputFieldNumberParseError(BaseOverflow)";
+        return false;
+    }
     out = acc;
     return true;
 }
+bool u256_parse_dec(const std::string& s, Fr& out, std::string& err) { return u256_parse_dec_span(s.data(), s.size(), out, err); }
 
 namespace {
 struct Json {
@@ -580,10 +600,18 @@ bool deserialize_inputs(const char* json, size_t len, InputList& out, std::strin
         auto scalar = [&](bool in_array) -> bool {
             char c2 = j.p[j.pos];
             if (c2 == '"') {
-                std::string s;
-                j.string(s);
+                // a string without escapes (every decimal number is one) is parsed where it stands
+                size_t e = j.pos + 1;
+                while (e < j.len && j.p[e] != '"' && j.p[e] != '\\') ++e;
                 Fr v;
-                if (!u256_parse_dec(s, v, err)) return false;  // lib.rs:208,223
+                if (e < j.len && j.p[e] == '"') {
+                    if (!u256_parse_dec_span(j.p + j.pos + 1, e - j.pos - 1, v, err)) return false;  // lib.rs:208,223
+                    j.pos = e + 1;
+                } else {
+                    std::string s;
+                    j.string(s);
+                    if (!u256_parse_dec(s, v, err)) return false;
+                }
                 vals.push_back(v);
                 return true;
             }
@@ -629,10 +657,81 @@ bool deserialize_inputs(const char* json, size_t len, InputList& out, std::strin
     return true;
 }
 
+namespace {
+// [p, p + n) (no leading / trailing whitespace) is exactly one bracketed JSON value as far as brackets and strings go: the
+// depth returns to zero at the last character and not before.  (What is inside is validated by deserialize_inputs.)
+bool line_is_one_object(const char* p, size_t n) {
+    if (n < 2 || p[0] != '{' || p[n - 1] != '}') return false;
+    size_t depth = 0;
+    bool in_str = false;
+    for (size_t i = 0; i < n; ++i) {
+        const char c = p[i];
+        if (in_str) {
+            if (c == '\\') ++i;
+            else if (c == '"') in_str = false;
+            continue;
+        }
+        if (c == '"') in_str = true;
+        else if (c == '{' || c == '[') ++depth;
+        else if (c == '}' || c == ']') {
+            if (depth == 0) return false;
+            if (--depth == 0 && i + 1 != n) return false;
+        }
+    }
+    return depth == 0 && !in_str;
+}
+}  // namespace
+
 bool split_inputs_batch(const char* text, size_t len, std::vector<std::pair<size_t, size_t>>& spans, std::string& err) {
     spans.clear();
     Json j{text, len, 0, ""};
     j.ws();
+    // NDJSON as everybody writes it -- one object per line -- is split at the newlines (a raw newline is never inside a JSON
+    // string) and the lines are checked in parallel; anything else (objects over several lines, several per line) takes
+    // the serial scanner below.  (The serial scan of a 57 MB batch was most of the front-end's time on a 256-core host.)
+    if (j.pos < len && text[j.pos] == '{' && len >= (1u << 16)) {
+        std::vector<std::pair<size_t, size_t>> lines;
+        size_t b = j.pos;
+        while (b < len) {
+            const char* nl = (const char*)memchr(text + b, '\n', len - b);
+            size_t e = nl ? (size_t)(nl - text) : len, lo = b, hi = e;
+            while (lo < hi && (text[lo] == ' ' || text[lo] == '\t' || text[lo] == '\r')) ++lo;
+            while (hi > lo && (text[hi - 1] == ' ' || text[hi - 1] == '\t' || text[hi - 1] == '\r')) --hi;
+            if (hi > lo) lines.emplace_back(lo, hi);
+            b = e + 1;
+        }
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt > 64) nt = 64;
+        if (nt > lines.size() / 64 + 1) nt = (unsigned)(lines.size() / 64 + 1);
+        if (nt < 1) nt = 1;
+        std::vector<char> okv(nt, 1);
+        auto work = [&](unsigned w) {
+            for (size_t i = lines.size() * w / nt; i < lines.size() * (w + 1) / nt; ++i)
+                if (!line_is_one_object(text + lines[i].first, lines[i].second - lines[i].first)) {
+                    okv[w] = 0;
+                    return;
+                }
+        };
+        bool threads_ok = true;
+        {
+            std::vector<std::thread> th;
+            unsigned started = 1;
+            try {
+                for (; started < nt; ++started) th.emplace_back(work, started);
+            } catch (...) {
+                threads_ok = true;  // (the ranges of threads that could not be started are checked here)
+            }
+            work(0);
+            for (unsigned w = started; w < nt; ++w) work(w);
+            for (auto& t : th) t.join();
+        }
+        bool all = threads_ok && !lines.empty();
+        for (char c : okv) all = all && c;
+        if (all) {
+            spans.swap(lines);
+            return true;
+        }
+    }
     if (j.pos < len && text[j.pos] == '[') {  // JSON array of objects
         ++j.pos;
         j.ws();

@@ -16,7 +16,11 @@
 
 namespace cwc {
 
-enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES = 4 };
+enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES = 4,
+                          // compiler-internal, never in a file: a fused chain of a product and up to two more steps
+                          // (compile.cc fuse_narrow_chains).  op = sq | op2 << 1 | op3 << 4 (FusedOp codes);
+                          // sq: (a * a) op2 b op3 c, else (a * b) op2 c
+                          N_FUSED = 5 };
 
 // graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into
 // Graph::const_values (canonical value, already reduced mod r as storage.rs:28 does on load).

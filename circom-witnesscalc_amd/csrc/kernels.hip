@@ -83,7 +83,10 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t byte
 // interpreter waves (W = 0), or PACK x (W interpreters + their divider) with the interpreters first.  The waves of a
 // workgroup are dealt round the CU's four SIMDs, so four-wave workgroups put one wave on every SIMD where single-wave
 // (or two-wave) workgroups land unevenly: 1024 tiles without dividers take 23.2 ms as 256 x 4 waves, 31.4 ms as 1024 x 1.
-template <int T, bool PROF, int W, int PACK>
+// FUSED: the program has fused narrow bundles (class C_MULF).  Their path is compiled into instances of their own: inside the
+// one interpreter loop it cost every other program 5 % (register allocation and layout of the hot paths; same-box A/B on
+// the authV2-class graph, 1024 sets: 12.55 against 11.93 ms, profiles/r03_regress_ab.txt).
+template <int T, bool PROF, int W, int PACK, bool FUSED = false>
 __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
                                                     const uint32_t* __restrict__ crefs, InterpDims p, WsTable wst,
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
@@ -241,6 +244,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const uint32_t trash_doff = (p.n_const + p.n_slots) * 2u * HI | t16;
     constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
     unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
+    unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67])
     if (PROF) {
 #pragma unroll
         for (int c = 0; c < C_PROF; ++c) pf[c][0] = pf[c][1] = 0;
@@ -277,6 +281,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         if constexpr (COOP) {
             uint32_t cls_q = h & HDR_CLASS_MASK;
             asm volatile("" : "+s"(cls_q));
+            static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_COUNT == 14, "one compare (class >= C_MULQ) leads to both narrow classes");
+            if (cls_q >= C_MULQ) {
             if (cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
                 // (laid out behind the loop's main line: a taken branch costs a lone wave ~50 cycles, and two of three bundles are not narrow)
                 const uint32_t la = rec_hi.y + (t16c | (t16c << 16));
@@ -325,6 +331,69 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 }
                 continue;
             }
+            if constexpr (FUSED && (uint32_t)T <= COOP_FUSE_MAX_T) {
+            if (cls_q == C_MULF) {  // fused narrow bundle: (a * b) op2 x2 op3 x3 in the registers of the node's four lanes (program_dev.h)
+                // lane l holds record l / T: the group's main record (even positions) and extra record (odd positions) by DPP
+                constexpr int QP_MAIN = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x00 /* [0,0,0,0] */, QP_EXTRA = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xAA /* [2,2,2,2] */;
+                const uint32_t mx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.x, QP_MAIN, 0xf, 0xf, false);
+                const uint32_t my = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.y, QP_MAIN, 0xf, 0xf, false);
+                const uint32_t xx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.x, QP_EXTRA, 0xf, 0xf, false);
+                const uint32_t xy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.y, QP_EXTRA, 0xf, 0xf, false);
+                const uint32_t la = my + (t16c | (t16c << 16)), lx = xy + (t16c | (t16c << 16));
+                const Fr a_op = ld_lds(la & 0xffffu);
+                const uint2 bq = *reinterpret_cast<const uint2*>(ldsb + (la >> 16) + coop_chunk);
+                const Fr x2_full = ld_lds(lx & 0xffffu);                                                    // second stage: a product ...
+                const uint2 x2q = *reinterpret_cast<const uint2*>(ldsb + (lx & 0xffffu) + coop_chunk);      // ... or an addition
+                const uint2 x3q = *reinterpret_cast<const uint2*>(ldsb + (lx >> 16) + coop_chunk);          // third stage: an addition
+                const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
+                const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
+                uint32_t h_n2;
+                asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+                hdr_off_n2 += 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(x2_full.v[0]), "v"(x2_full.v[4]), "v"(x2q.x), "v"(x3q.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                stage_operands(b + 2, rec_n2);
+                stage_rec(b + 4);
+                uint32_t out[2];
+                fr_mul_coop4(a_op, bq.x, bq.y, nq0, nq1, out);
+                const uint32_t op2 = mx & CTRL_SUB_MASK, op3 = xx & CTRL_SUB_MASK;
+                if (h & HDR_F_S2MUL) {  // graph.rs:105 on the running value: the other factor in full, the value as the lanes hold it
+                    uint32_t o2[2];
+                    fr_mul_coop4(x2_full, out[0], out[1], nq0, nq1, o2);
+                    out[0] = op2 == FOP_MUL ? o2[0] : out[0];
+                    out[1] = op2 == FOP_MUL ? o2[1] : out[1];
+                }
+                auto lin_stage = [&](uint32_t op, const uint2& xq) {  // graph.rs:110-111: acc + x, acc - x, x - acc
+                    const bool rs = op == FOP_RSUB;
+                    uint32_t o[2];
+                    fr_addsub_coop4(rs ? xq.x : out[0], rs ? xq.y : out[1], rs ? out[0] : xq.x, rs ? out[1] : xq.y, nq0, nq1, op == FOP_ADD ? 0u : 1u, o);
+                    out[0] = op >= FOP_ADD ? o[0] : out[0];
+                    out[1] = op >= FOP_ADD ? o[1] : out[1];
+                };
+                if (h & HDR_F_S2LIN) lin_stage(op2, x2q);
+                if (h & HDR_F_S3LIN) lin_stage(op3, x3q);
+                *reinterpret_cast<uint2*>(ldsb + LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES + coop_ring_off) = make_uint2(out[0], out[1]);
+                {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{out[0], out[1]}, rsrc, (int)((mx & ~CTRL_MASK) + coop_dst_off), 0, 0);
+                }
+                doff_prev = trash_doff;
+                rec_hi = rec_hi_n1;
+                rec_hi_n1 = rec_hi_n2;
+                h_cur = h_n1;
+                h_n1 = h_n2;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (PROF) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+                    pf_fused[0] += t_now - st0;
+                    pf_fused[1] += 1;
+                }
+                continue;
+            }
+            }
+            }  // (C_SYNC: the main path)
         }
         const uint32_t ctrl = rec_hi.x & CTRL_MASK;
         const uint32_t doff = (rec_hi.x & ~CTRL_MASK) | t16;
@@ -617,6 +686,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             atomicAdd(&prof[c * 4 + 0], pf[c][0]);
             atomicAdd(&prof[c * 4 + 3], pf[c][1]);
         }
+        atomicAdd(&prof[64], pf_fused[0]);
+        atomicAdd(&prof[67], pf_fused[1]);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -694,6 +765,32 @@ __global__ __launch_bounds__(256) void pack_kernel(ProgramDev p, WsTable wst, ui
     }
 }
 
+// Round 3: one thread = one (witness index, set) pair, the T sets of a slot in ADJACENT lanes: a wave's load instruction
+// touches 64 / T slots, each in runs of 16 T contiguous bytes (the thread-per-slot shape above makes every lane fetch a
+// different line: 64 lines per instruction at T = 4), and a wave's stores are 64 / T consecutive rows of 32 bytes per set.
+template <bool MONT, int TT>
+__global__ __launch_bounds__(256) void pack_kernel_v3(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch) {
+    constexpr uint32_t T = TT, WPB = 256u / T;
+    const uint32_t t = threadIdx.x % T, w = blockIdx.x * WPB + threadIdx.x / T;
+    if (w >= p.n_witness) return;
+    const uint32_t ref_raw = p.witness_refs[w];
+    const bool canon = (ref_raw & REF_CANON) != 0;
+    const uint32_t ref = ref_raw & ~REF_CANON;
+    const uint32_t n_tiles = (batch + T - 1) / T;
+    const uint64_t tile_bytes = ws_tile_bytes(p.n_const, p.n_slots, T);
+    const uint32_t slot = (ref & REF_CONST) ? (ref & ~REF_CONST) : p.n_const + ref;
+    for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+        const uint32_t set = tile * T + t;
+        if (set >= batch) continue;
+        const char* tb = reinterpret_cast<const char*>(wst.base[tile / wst.tiles_per_chunk]) + (uint64_t)(tile % wst.tiles_per_chunk) * tile_bytes;
+        const uint4* q = reinterpret_cast<const uint4*>(tb) + (size_t)slot * (2 * T);
+        const Fr c = pack_form<MONT>(fr_from_u4(q[t], q[T + t]), canon);
+        uint4* o = out + ((size_t)set * p.n_witness + w) * 2;
+        o[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+        o[1] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
+    }
+}
+
 // (round-1 shape: block = 64 witness indices x min(T, 4) sets of one tile; what tiles wider than 4 sets use)
 template <bool MONT>
 __global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst, uint4* __restrict__ out, uint32_t batch, uint32_t T) {
@@ -741,7 +838,17 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
         dims.stream_div_requests[0] = n_div_requests;
     }
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-#define CWC_LAUNCH3(TT, PP, WW, KK) interp_kernel<TT, PP, WW, KK><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof)
+    const bool fused = p.has_fused != 0;
+    if (fused && T > COOP_FUSE_MAX_T) return hipErrorInvalidValue;
+#define CWC_LAUNCH3(TT, PP, WW, KK)                                                                                                     \
+    do {                                                                                                                                \
+        if constexpr ((uint32_t)(TT) <= COOP_FUSE_MAX_T) {                                                                              \
+            if (fused) interp_kernel<TT, PP, WW, KK, true><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
+            else interp_kernel<TT, PP, WW, KK, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);     \
+        } else {                                                                                                                        \
+            interp_kernel<TT, PP, WW, KK, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);          \
+        }                                                                                                                               \
+    } while (0)
 #define CWC_LAUNCH2(TT, PP)                                  \
     if (W == 0 && pack == 1) CWC_LAUNCH3(TT, PP, 0, 1);      \
     else if (W == 0 && pack == 4) CWC_LAUNCH3(TT, PP, 0, 4); \
@@ -789,6 +896,18 @@ hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void
         else pack_kernel_v1<false><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T);
         return hipGetLastError();
     }
+    static const int pack_shape = getenv("CWC_PACK") ? atoi(getenv("CWC_PACK")) : 3;  // (2: one thread per slot, the round-2 shape, for A/B)
+    if (pack_shape == 3 && T >= 2) {  // (T = 1: the two shapes are the same kernel)
+        dim3 grid3((p.n_witness + 256 / T - 1) / (256 / T), n_tiles < 32768u ? n_tiles : 32768u), block3(256);
+#define CWC_PACK3(MM, TT) pack_kernel_v3<MM, TT><<<grid3, block3, 0, stream>>>(p, wst, (uint4*)out, batch)
+        if (montgomery) {
+            if (T == 2) CWC_PACK3(true, 2); else CWC_PACK3(true, 4);
+        } else {
+            if (T == 2) CWC_PACK3(false, 2); else CWC_PACK3(false, 4);
+        }
+#undef CWC_PACK3
+        return hipGetLastError();
+    }
     dim3 grid((p.n_witness + 255) / 256, n_tiles < 32768u ? n_tiles : 32768u), block(256);
 #define CWC_PACK(MM, TT) pack_kernel<MM, TT><<<grid, block, 0, stream>>>(p, wst, (uint4*)out, batch, T)
     if (montgomery) {
@@ -813,8 +932,26 @@ __global__ __launch_bounds__(1024) void modmul_ubench_kernel(uint32_t* sink, uin
     }
     if (a.v[0] == 0x1234567u && b.v[3] == 7u) sink[0] = a.v[1];
 }
-hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream) {
-    modmul_ubench_kernel<<<n_cus, 256 * waves_per_simd, 0, stream>>>(sink, iters);
+// The same with the multiplier the interpreter's full-width bundles use (fr_mul_wave: one asm block, 322 issue slots,
+// accumulators pinned in v160-v167, so at most two waves per SIMD fit the register file).
+__global__ __launch_bounds__(512) void modmul_block_ubench_kernel(uint32_t* sink, uint32_t iters) {
+    Fr a = fr_r2(), b = fr_one(), pv = fr_p();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pv.v[i]));
+    a.v[0] ^= threadIdx.x + blockIdx.x * 977u;
+    for (uint32_t it = 0; it < iters; ++it) {
+        a = fr_mul_wave(a, b, pv);
+        b = fr_mul_wave(b, a, pv);
+    }
+    if (a.v[0] == 0x1234567u && b.v[3] == 7u) sink[0] = a.v[1];
+}
+hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream, bool block_multiplier) {
+    if (block_multiplier) {
+        if (waves_per_simd > 2) return hipErrorInvalidValue;
+        modmul_block_ubench_kernel<<<n_cus, 256 * waves_per_simd, 0, stream>>>(sink, iters);
+    } else {
+        modmul_ubench_kernel<<<n_cus, 256 * waves_per_simd, 0, stream>>>(sink, iters);
+    }
     return hipGetLastError();
 }
 

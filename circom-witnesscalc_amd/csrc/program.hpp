@@ -28,6 +28,7 @@ struct ProgramStats {
     uint64_t n_coop_rider_bundles = 0;  // narrow multiplication bundles that carry linear riders
     uint64_t n_conversions = 0, n_canonical = 0, form_cycles_saved = 0;  // representation inference: inserted conversions, operations whose value is kept as a canonical integer
     uint64_t n_folded = 0, n_numbered = 0, n_shaken = 0;  // load-time optimiser: operations folded to constants / aliases, nodes merged by value numbering, unused nodes dropped
+    uint64_t n_fused_nodes = 0;         // fused narrow chains made by the compiler (class C_MULF)
 };
 
 struct Program {
@@ -56,7 +57,9 @@ struct Program {
 // 4, T < 64 only).
 // streams = 2 or 4: the graph's independent parts are spread over that many wavefronts per tile (fewer when it has fewer
 // parts; divider 0 or 1 only).
-bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams = 1);
+// quick: one schedule (the base policy) instead of the search over schedule variants: a tenth of the compile time, a few percent
+// more cycles.
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams = 1, bool quick = false);
 // Validation and statistics of a loaded graph without compiling a program: out.stats, out.n_inputs, out.n_witness.
 bool probe_graph(const Graph& g, Program& out, std::string& err);
 // "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER | KEY_GROUP

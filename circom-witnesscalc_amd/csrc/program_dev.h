@@ -37,9 +37,21 @@ enum BundleClass : uint32_t {
     // the wave posts -- every result of its earlier bundles is in memory -- and / or waits: a stream other than 0 for stream
     // 0's next post, stream 0 for the next post of every other stream (header bits HDR_POST / HDR_WAIT)
     C_SYNC = 12,
-    C_COUNT = 13
+    // fused narrow bundle (round 3, tile widths up to COOP_FUSE_MAX_T): every node is a short dependent sequence that stays
+    // in the registers of its four lanes -- stage 1 a product a * b (lane layout of C_MULQ), stage 2 `op2` with a third
+    // operand x2 (another product, or + / - ), stage 3 `op3` with a fourth operand x3 (+ / -): (s * s) * m + c is one node
+    // where the unfused graph needs three bundles on its critical chain.  The compiler makes such nodes from Mul / Add / Sub
+    // nodes of the graph (exact in the field, graph.rs:105, 110-111; compile.cc fuse_narrow_chains).  Records: positions
+    // 4j, 4j+2 = {a_off, b_off, dst | ACTIVE | op2, a_lds | b_lds << 16}, positions 4j+1, 4j+3 = {x2_off, x3_off,
+    // trash | op3, x2_lds | x3_lds << 16}; header bits HDR_F_* say which stages any node of the bundle has.  Plain
+    // multiplications ride as nodes with op2 = op3 = none.
+    C_MULF = 13,
+    C_COUNT = 14
 };
-static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4;
+static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4, COOP_FUSE_MAX_T = 2;
+// stage codes of a fused node (C_MULF): op2 in the low three bits of the main record's ctrl, op3 in the extra record's
+enum FusedOp : uint32_t { FOP_NONE = 0, FOP_MUL = 1, FOP_ADD = 2, FOP_SUB = 3 /* acc - x */, FOP_RSUB = 4 /* x - acc */ };
+static const uint32_t HDR_F_S2MUL = 1u << 11, HDR_F_S2LIN = 1u << 12, HDR_F_S3LIN = 1u << 13;  // C_MULF: stages present in the bundle
 CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_LANES * T) : 0u; }  // nodes of a C_MULQ bundle
 
 // Program format v4 -- every operand of a bundle is read from the wave's LDS at a host-computed address, and the
@@ -124,6 +136,7 @@ struct ProgramDev {
     const uint32_t* witness_refs;  // [n_witness]
     const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
+    uint32_t has_fused;            // the program has C_MULF bundles (the interpreter instance with their path is launched)
     uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4], stream_cref_first[4];  // (program.hpp; MAX_STREAMS entries)
 };
 

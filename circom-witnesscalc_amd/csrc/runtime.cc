@@ -2,12 +2,17 @@
 // (include/graph_witness_batch.h).  Everything numeric runs in the HIP kernels of kernels.hip; this file
 // parses, compiles, moves buffers and launches.  There is deliberately no CPU evaluation path.
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -28,7 +33,7 @@ namespace cwc {
 hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p,
                          const WsTable& wst, const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof);
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream, bool montgomery);
-hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream);
+hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream, bool block_multiplier);
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
 }  // namespace cwc
 
@@ -109,6 +114,7 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_inputs = p.n_inputs;
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
+    dp.dev.has_fused = p.stats.class_bundles[C_MULF] ? 1u : 0u;
     dp.dev.n_streams = p.n_streams;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dp.dev.stream_first[s] = p.stream_first[s];
@@ -153,6 +159,43 @@ struct gwb_graph {
     std::map<uint32_t, std::unique_ptr<Program>> compiled;  // compiled for the cost model, not uploaded (yet)
     std::map<size_t, uint32_t> chosen;                       // batch size -> program key picked by the cost model
     uint32_t forced_T = 0;
+    uint32_t last_key = 0;  // program key of the last batch call (gwb_program_stats)
+    // Small batches (the single-shot entry point above all): the first call compiles ONE program with one schedule and
+    // runs it, while a background task does what every other batch size waits for -- all candidate programs, the search
+    // over schedule variants, the cost model's choice; the next call that finds the task finished switches over.
+    struct Refined {
+        uint32_t best = 0;
+        std::map<uint32_t, std::unique_ptr<Program>> programs;
+    };
+    std::map<size_t, std::future<Refined>> refining;  // by batch size
+    std::map<size_t, uint32_t> provisional;            // batch size -> the quick program's key while the task runs
+    bool cache_written = false;                        // single-shot entry point: the refined program went to the on-disk cache
+    // buffers of the streaming end-to-end entry point (gwb_calc_witness_json_to_wtns), kept between calls: pinned input rows,
+    // device rows in / out / status (double-buffered), pinned staging of the witness copy, streams and events
+    struct E2eBufs {
+        void* h_rows[2] = {nullptr, nullptr};
+        void* d_in[2] = {nullptr, nullptr};
+        void* d_out[2] = {nullptr, nullptr};
+        void* d_st[2] = {nullptr, nullptr};
+        void* stage[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+        hipStream_t compute = nullptr, copy[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        size_t in_bytes = 0, out_bytes = 0, st_bytes = 0, stage_bytes = 0;
+        void release() {
+            for (int i = 0; i < 2; ++i) {
+                if (h_rows[i]) (void)hipHostFree(h_rows[i]);
+                if (d_in[i]) (void)hipFree(d_in[i]);
+                if (d_out[i]) (void)hipFree(d_out[i]);
+                if (d_st[i]) (void)hipFree(d_st[i]);
+                h_rows[i] = d_in[i] = d_out[i] = d_st[i] = nullptr;
+                for (int b = 0; b < 3; ++b) {
+                    if (stage[i][b]) (void)hipHostFree(stage[i][b]);
+                    stage[i][b] = nullptr;
+                }
+            }
+            in_bytes = out_bytes = st_bytes = stage_bytes = 0;
+        }
+    } e2e;
     // value workspaces ("chunks"): separately allocated groups of tiles (CWC_WORKSPACE_GB each), all covered by ONE
     // launch (the kernel picks the chunk per tile; every tile has its own 32-bit buffer window)
     static const int kMaxLanes = (int)WS_MAX_CHUNKS;
@@ -204,6 +247,12 @@ struct gwb_graph {
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (last_done) (void)hipEventDestroy(last_done);
+        e2e.release();
+        for (int i = 0; i < 2; ++i) {
+            if (e2e.copy[i]) (void)hipStreamDestroy(e2e.copy[i]);
+            if (e2e.done[i]) (void)hipEventDestroy(e2e.done[i]);
+        }
+        if (e2e.compute) (void)hipStreamDestroy(e2e.compute);
     }
 };
 
@@ -282,6 +331,59 @@ double estimate_cycles(const Program& p, size_t batch) {
     return per_wave * crowd * rounds;
 }
 
+// candidate program keys for a batch (the static rule's tile width and its neighbours, the divider / stream modes that fit)
+std::vector<uint32_t> candidate_keys(const ProgramStats& stats, size_t batch, uint32_t rule, uint32_t min_t) {
+    size_t divider_tiles = 1024;
+    if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
+    const bool has_div = stats.class_nodes[C_DIV] > 0;
+    const uint32_t t0 = rule & ~KEY_MODE_MASK;
+    std::vector<uint32_t> keys;
+    for (uint32_t t = std::max(min_t, t0 >= 4 ? t0 / 4 : 1u); t <= t0 * 2 && t <= 32 && (batch >= 64 || t == t0); t *= 2)  // (tiny batches: one tile either way)
+        for (uint32_t mode : {0u, KEY_DIVIDER, KEY_TRIPLE, KEY_GROUP}) {
+            const size_t tiles = (batch + t - 1) / t;
+            if (tiles > 4 * 2048) continue;
+            // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
+            // workgroup per CU covers more than half of the batch at once
+            const bool divider_fits = has_div && tiles <= divider_tiles;
+            if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
+            if (mode == KEY_DIVIDER && !divider_fits) continue;
+            if (mode == KEY_TRIPLE && !(has_div && tiles > 512 && tiles <= 768 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
+            if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
+            keys.push_back(t | mode);
+            // the graph's independent parts on wavefronts of their own (streams): while every stream of every tile has
+            // a SIMD to itself (small batches, the single-shot entry point)
+            if ((mode == 0 || mode == KEY_DIVIDER) && t < 64 && !getenv("CWC_NO_STREAMS")) {
+                if (tiles <= 256) keys.push_back(t | mode | KEY_STREAMS4);
+                else if (tiles <= 340) keys.push_back(t | mode | KEY_STREAMS2);
+            }
+        }
+    return keys;
+}
+
+// the full choice for a batch size, on a thread of its own (reads the graph only): every candidate compiled with the
+// search over schedule variants, priced by the cost model
+gwb_graph::Refined refine_choice(const Graph& graph, const ProgramStats& stats, size_t batch, uint32_t rule, uint32_t min_t) {
+    gwb_graph::Refined r;
+    try {
+        double best_cost = -1;
+        for (uint32_t key : candidate_keys(stats, batch, rule, min_t)) {
+            std::unique_ptr<Program> p(new Program());
+            std::string err;
+            if (!compile_program(graph, key & ~KEY_MODE_MASK, key_divider_waves(key), *p, err, key_streams(key))) continue;
+            const double cost = estimate_cycles(*p, batch);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                r.best = key;
+            }
+            r.programs[key] = std::move(p);
+        }
+    } catch (...) {
+        r.best = 0;
+        r.programs.clear();
+    }
+    return r;
+}
+
 // The program key for a batch: forced / environment override, else the static rule's width and its neighbours
 // compiled (host only) and priced with the cost model; the choice is remembered per batch size.
 uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
@@ -307,33 +409,50 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph) return rule;
     auto hit = g->chosen.find(batch);
     if (hit != g->chosen.end()) return hit->second;
-    size_t divider_tiles = 1024;
-    if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
+    // ---- small batches: quick program first, the full choice in the background (see gwb_graph::refining) ----
+    if (batch < 64 && !getenv("CWC_NO_QUICK_FIRST_CALL")) {
+        auto job = g->refining.find(batch);
+        if (job != g->refining.end()) {
+            if (job->second.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return g->provisional[batch];
+            gwb_graph::Refined r = job->second.get();
+            g->refining.erase(job);
+            const uint32_t quick_key = g->provisional[batch];
+            g->provisional.erase(batch);
+            if (r.best == 0) {  // (nothing compiled in the background: keep what runs)
+                g->chosen[batch] = quick_key;
+                return quick_key;
+            }
+            // the refined programs replace the quick one (also when it was uploaded: its device copy is freed, hipFree waits for the device)
+            for (auto& kv : r.programs) {
+                if (g->progs.count(kv.first)) {
+                    if (g->filled_prog == g->progs[kv.first].get()) g->filled_prog = nullptr;
+                    g->progs.erase(kv.first);
+                }
+                g->compiled[kv.first] = std::move(kv.second);
+            }
+            g->chosen[batch] = r.best;
+            return r.best;
+        }
+        const bool has_div0 = g->stats.class_nodes[C_DIV] > 0;
+        const uint32_t t1 = std::max(1u, min_t);
+        const uint32_t quick_key = t1 | (has_div0 && t1 < 64 ? KEY_DIVIDER : 0u) | (t1 < 64 && !getenv("CWC_NO_STREAMS") ? KEY_STREAMS4 : 0u);
+        if (!g->progs.count(quick_key) && !g->compiled.count(quick_key)) {
+            std::unique_ptr<Program> p(new Program());
+            std::string err;
+            if (compile_program(g->graph, quick_key & ~KEY_MODE_MASK, key_divider_waves(quick_key), *p, err, key_streams(quick_key), true)) g->compiled[quick_key] = std::move(p);
+        }
+        if (g->progs.count(quick_key) || g->compiled.count(quick_key)) {
+            const Graph* graph = &g->graph;
+            const ProgramStats stats = g->stats;
+            g->provisional[batch] = quick_key;
+            g->refining[batch] = std::async(std::launch::async, [graph, stats, batch, rule, min_t]() { return refine_choice(*graph, stats, batch, rule, min_t); });
+            return quick_key;
+        }
+    }
     const bool debug = getenv("CWC_DEBUG_COST") != nullptr;
-    const bool has_div = g->stats.class_nodes[C_DIV] > 0;
-    const uint32_t t0 = rule & ~KEY_MODE_MASK;
     uint32_t best = rule;
     double best_cost = -1;
-    std::vector<uint32_t> keys;
-    for (uint32_t t = std::max(min_t, t0 >= 4 ? t0 / 4 : 1u); t <= t0 * 2 && t <= 32 && (batch >= 64 || t == t0); t *= 2)  // (tiny batches: one tile either way)
-        for (uint32_t mode : {0u, KEY_DIVIDER, KEY_TRIPLE, KEY_GROUP}) {
-            const size_t tiles = (batch + t - 1) / t;
-            if (tiles > 4 * 2048) continue;
-            // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
-            // workgroup per CU covers more than half of the batch at once
-            const bool divider_fits = has_div && tiles <= divider_tiles;
-            if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
-            if (mode == KEY_DIVIDER && !divider_fits) continue;
-            if (mode == KEY_TRIPLE && !(has_div && tiles > 512 && tiles <= 768 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
-            if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
-            keys.push_back(t | mode);
-            // the graph's independent parts on wavefronts of their own (streams): while every stream of every tile has
-            // a SIMD to itself (small batches, the single-shot entry point)
-            if ((mode == 0 || mode == KEY_DIVIDER) && t < 64 && !getenv("CWC_NO_STREAMS")) {
-                if (tiles <= 256) keys.push_back(t | mode | KEY_STREAMS4);
-                else if (tiles <= 340) keys.push_back(t | mode | KEY_STREAMS2);
-            }
-        }
+    const std::vector<uint32_t> keys = candidate_keys(g->stats, batch, rule, min_t);
     // the candidates that are not compiled yet, each on a thread of its own (the compiler only reads the graph)
     std::vector<std::pair<uint32_t, std::future<std::unique_ptr<Program>>>> jobs;
     for (uint32_t key : keys)
@@ -401,6 +520,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     DeviceProgram* dp = nullptr;
     std::string err = get_program(g, key, &dp);
     if (!err.empty()) return err;
+    g->last_key = (key & ~KEY_MODE_MASK) == 64 ? 64u : key;
     const Program& p = dp->host;
     const uint32_t T = p.T;
     if (!g->last_done) HIP_TRY(hipEventCreateWithFlags(&g->last_done, hipEventDisableTiming));
@@ -517,6 +637,16 @@ bool is_pinned_host(const void* p) {
         return false;
     }
     return a.type == hipMemoryTypeHost;
+}
+
+unsigned env_threads(const char* name, unsigned cap) {
+    long v = 0;
+    if (const char* e = getenv(name)) v = atol(e);
+    if (v <= 0) {
+        v = (long)std::thread::hardware_concurrency();
+        if (cap && v > (long)cap) v = cap;
+    }
+    return v < 1 ? 1u : (unsigned)v;
 }
 
 unsigned copy_threads() {
@@ -674,6 +804,96 @@ uint64_t sampled_fingerprint(const uint8_t* p, size_t n) {
     return h;
 }
 
+// SHA-256 (FIPS 180-4) of the graph image: the key of the on-disk program cache
+std::string sha256_hex(const uint8_t* p, size_t n) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74,
+        0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d,
+        0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e,
+        0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5,
+        0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    auto rotr = [](uint32_t x, int k) { return (x >> k) | (x << (32 - k)); };
+    auto block = [&](const uint8_t* b) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & bb) ^ (a & c) ^ (bb & c), t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    };
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) block(p + i);
+    uint8_t tail[128] = {0};
+    const size_t rem = n - i;
+    memcpy(tail, p + i, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem + 9 <= 64 ? 64 : 128;
+    const uint64_t bits = (uint64_t)n * 8;
+    for (int k = 0; k < 8; ++k) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    block(tail);
+    if (tl == 128) block(tail + 64);
+    char out[65];
+    for (int k = 0; k < 8; ++k) snprintf(out + 8 * k, 9, "%08x", h[k]);
+    return std::string(out, 64);
+}
+
+// On-disk cache of the single-shot entry point's compiled program: a process that has never seen a graph image finds the
+// program an earlier process compiled for it (the first call otherwise parses, compiles and searches schedules).  One file
+// per (SHA-256 of the image, library build): <dir>/<sha256>-<build>.cwcprog = the blob of gwb_graph_export (checksummed,
+// structurally validated on import: a damaged or stale file is ignored and rewritten).  CWC_PROGRAM_CACHE=<dir> names the
+// directory, CWC_PROGRAM_CACHE=0 turns the cache off; default $XDG_CACHE_HOME or ~/.cache, /circom-witnesscalc-amd.
+std::string program_cache_file(const void* graph_data, size_t len) {
+    std::string dir;
+    if (const char* e = getenv("CWC_PROGRAM_CACHE")) {
+        if (!*e || !strcmp(e, "0") || !strcmp(e, "off")) return "";
+        dir = e;
+    } else if (const char* x = getenv("XDG_CACHE_HOME")) {
+        if (*x) dir = std::string(x) + "/circom-witnesscalc-amd";
+    }
+    if (dir.empty()) {
+        const char* home = getenv("HOME");
+        if (!home || !*home) return "";
+        dir = std::string(home) + "/.cache/circom-witnesscalc-amd";
+    }
+    static const std::string build = sha256_hex((const uint8_t*)(__DATE__ " " __TIME__ " format 13"), sizeof(__DATE__ " " __TIME__ " format 13") - 1).substr(0, 12);
+    return dir + "/" + sha256_hex((const uint8_t*)graph_data, len) + "-" + build + ".cwcprog";
+}
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = fseek(f, 0, SEEK_END) == 0;
+    const long n = ok ? ftell(f) : -1;
+    ok = ok && n >= 0 && n < (1l << 31) && fseek(f, 0, SEEK_SET) == 0;
+    if (ok) {
+        out.resize((size_t)n);
+        ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    }
+    fclose(f);
+    return ok;
+}
+void write_file_atomically(const std::string& path, const void* data, size_t n) {
+    const size_t slash = path.rfind('/');
+    if (slash != std::string::npos) {  // mkdir -p of the directory (two levels are enough for the default)
+        const std::string dir = path.substr(0, slash);
+        const size_t up = dir.rfind('/');
+        if (up != std::string::npos && up > 0) (void)mkdir(dir.substr(0, up).c_str(), 0700);
+        (void)mkdir(dir.c_str(), 0700);
+    }
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(data, 1, n, f) == n;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
 int load_graph(const void* data, size_t len, gwb_graph** out, std::string& err) {
     std::unique_ptr<gwb_graph> g(new gwb_graph());
     if (!deserialize_witnesscalc_graph((const uint8_t*)data, len, g->graph, err)) return 1;
@@ -782,13 +1002,10 @@ int gwb_inputs_from_json_batch(const gwb_graph_t* g, const char* text, size_t te
     Graph meta;
     meta.inputs = g->inputs;
     meta.input_index = g->input_index;
-    // the input sets are independent: parsed on CWC_PARSE_THREADS host threads (default min(cores, 16)), contiguous
+    // the input sets are independent: parsed on CWC_PARSE_THREADS host threads (default: every core), contiguous
     // ranges each; the error of the lowest failing set is reported, as a sequential loop would
-    unsigned n_threads = copy_threads();
-    if (const char* e = getenv("CWC_PARSE_THREADS")) {
-        const long v = atol(e);
-        if (v >= 1) n_threads = (unsigned)v;
-    }
+    unsigned n_threads = env_threads("CWC_PARSE_THREADS", 0);  // (round 2 capped this at 16 threads: 27 k sets/s on a 256-core host)
+    if (n_threads > spans.size() / 16 + 1) n_threads = (unsigned)(spans.size() / 16 + 1);
     if (spans.size() < 64) n_threads = 1;
     if (n_threads > spans.size()) n_threads = (unsigned)spans.size();
     std::vector<std::string> errs(n_threads ? n_threads : 1);
@@ -864,6 +1081,286 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
     });
 }
 
+// ---- end to end, streaming: JSON text -> rows -> HBM -> kernels -> pinned staging -> `.wtns` files ----------
+// Sub-batches of CWC_E2E_SUBBATCH input sets (default 512) move through a three-stage pipeline: the calling thread parses
+// sub-batch k + 1 on the parse threads and enqueues its upload and kernels, while a drain thread copies the witness rows of
+// sub-batch k out of HBM in slices of whole sets (copy stream, pinned staging buffers) and a pool of writer threads frames
+// every set of a finished slice as its own `.wtns` file (76-byte header + row, lib.rs:114-123).  The interpreter's value
+// workspace is shared, the output rows are double-buffered.  The rate is the PCIe link's: 2.4 MB of witness per authV2 set.
+namespace {
+struct WriterPool {
+    struct Task {
+        const uint8_t* row;
+        size_t index;
+        std::atomic<int>* pending;  // of the staging buffer the row lives in
+    };
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::deque<Task> q;
+    bool stop = false;
+    std::string err;
+    std::vector<std::thread> th;
+    std::string pattern;
+    size_t n_witness = 0;
+    std::vector<uint8_t> hdr;
+    void start(unsigned n, const char* pat, size_t nw) {
+        pattern = pat;
+        n_witness = nw;
+        hdr.resize(76);
+        wtns_write_header(hdr.data(), nw);
+        for (unsigned i = 0; i < n; ++i) th.emplace_back([this]() { run(); });
+    }
+    void run() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return stop || !q.empty(); });
+                if (q.empty()) return;
+                t = q.front();
+                q.pop_front();
+            }
+            char path[4096];
+            std::string e;
+            const int n = snprintf(path, sizeof path, pattern.c_str(), (unsigned long)t.index);
+            if (n <= 0 || (size_t)n >= sizeof path) {
+                e = "bad path pattern";
+            } else {
+                FILE* f = fopen(path, "wb");
+                if (!f) {
+                    e = std::string("cannot open ") + path;
+                } else {
+                    const bool ok = fwrite(hdr.data(), 1, 76, f) == 76 && fwrite(t.row, 1, n_witness * 32, f) == n_witness * 32;
+                    if (fclose(f) != 0 || !ok) e = std::string("short write to ") + path;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!e.empty() && err.empty()) err = e;
+                t.pending->fetch_sub(1, std::memory_order_release);
+            }
+            cv_done.notify_all();
+        }
+    }
+    void push(const Task& t) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(t);
+        }
+        cv.notify_one();
+    }
+    void wait_zero(std::atomic<int>& c) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&]() { return c.load(std::memory_order_acquire) == 0; });
+    }
+    void finish() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+    ~WriterPool() { finish(); }
+};
+}  // namespace
+
+extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, size_t text_len, const char* path_pattern, size_t first_index,
+                                             size_t* n_sets, uint32_t* set_status_out, size_t max_sets, gwb_e2e_stats_t* stats, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
+    if (!g || !text || !path_pattern || !n_sets) return fail(status, "null argument");
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    std::vector<std::pair<size_t, size_t>> spans;
+    std::string err;
+    if (!split_inputs_batch(text, text_len, spans, err)) return fail(status, "Failed to calculate witness: " + err);
+    *n_sets = spans.size();
+    if (set_status_out && spans.size() > max_sets) return fail(status, "status buffer too small: " + std::to_string(spans.size()) + " input sets");
+    if (spans.empty()) {
+        set_status(status, OK, "");
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g->mu);
+    err = check_device();
+    if (!err.empty()) return fail(status, err);
+    const size_t B = spans.size(), NI = g->n_inputs, NW = g->n_witness, row_b = NW * 32;
+    size_t S = 512;
+    if (const char* e = getenv("CWC_E2E_SUBBATCH")) {
+        const long v = atol(e);
+        if (v >= 1) S = (size_t)v;
+    }
+    if (S > B) S = B;
+    const size_t K = (B + S - 1) / S;
+    // slices of whole sets, ~24 MB each, three staging buffers per drain
+    size_t slice_sets = row_b ? std::max<size_t>(1, (24u << 20) / row_b) : 1;
+    if (slice_sets > S) slice_sets = S;
+    const int kStage = 3;
+    gwb_graph::E2eBufs& bf = g->e2e;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipSuccess;
+    };
+    struct SyncOnExit {  // nothing of this call is in flight when it returns (the buffers stay on the handle)
+        ~SyncOnExit() { (void)hipDeviceSynchronize(); }
+    } sync_on_exit;
+    bool ok = true;
+    if (!bf.compute) ok = hip_ok(hipStreamCreateWithFlags(&bf.compute, hipStreamNonBlocking), "hipStreamCreate");
+    for (int i = 0; ok && i < 2; ++i) {
+        if (!bf.copy[i]) ok = hip_ok(hipStreamCreateWithFlags(&bf.copy[i], hipStreamNonBlocking), "hipStreamCreate");
+        if (ok && !bf.done[i]) ok = hip_ok(hipEventCreateWithFlags(&bf.done[i], hipEventDisableTiming), "hipEventCreate");
+    }
+    const size_t need_in = std::max<size_t>(32, S * NI * 32), need_out = std::max<size_t>(32, S * row_b), need_st = S * 4, need_stage = std::max<size_t>(32, slice_sets * row_b);
+    if (ok && (need_in > bf.in_bytes || need_out > bf.out_bytes || need_st > bf.st_bytes || need_stage > bf.stage_bytes)) {
+        (void)hipDeviceSynchronize();
+        bf.release();
+        for (int i = 0; ok && i < 2; ++i) {
+            ok = hip_ok(hipHostMalloc(&bf.h_rows[i], need_in, hipHostMallocDefault), "hipHostMalloc") && hip_ok(hipMalloc(&bf.d_in[i], need_in), "hipMalloc") &&
+                 hip_ok(hipMalloc(&bf.d_out[i], need_out), "hipMalloc") && hip_ok(hipMalloc(&bf.d_st[i], need_st), "hipMalloc");
+            for (int b = 0; ok && b < kStage; ++b) ok = hip_ok(hipHostMalloc(&bf.stage[i][b], need_stage, hipHostMallocDefault), "hipHostMalloc");
+        }
+        if (ok) {
+            bf.in_bytes = need_in;
+            bf.out_bytes = need_out;
+            bf.st_bytes = need_st;
+            bf.stage_bytes = need_stage;
+        } else {
+            bf.release();
+        }
+    }
+    if (!ok) return fail(status, err);
+    Graph meta;
+    meta.inputs = g->inputs;
+    meta.input_index = g->input_index;
+    const unsigned n_parse = env_threads("CWC_PARSE_THREADS", 0), n_write = env_threads("CWC_WRITE_THREADS", 32);
+    WriterPool pool;
+    pool.start(n_write, path_pattern, NW);
+    std::atomic<int> pending[2][3];
+    for (auto& a : pending)
+        for (auto& x : a) x.store(0);
+    double parse_s = 0;
+    std::mutex err_mu;
+    std::string drain_err, parse_err;
+    size_t parse_bad = (size_t)-1;
+    std::vector<uint32_t> st_host(B, 0);
+    std::thread drains[2];
+    auto drain = [&](size_t k) {  // witness rows of sub-batch k: HBM -> staging -> files
+        const int par = (int)(k & 1);
+        const size_t lo = k * S, n = std::min(S, B - lo);
+        if (hipEventSynchronize(bf.done[par]) != hipSuccess) {
+            std::lock_guard<std::mutex> l2(err_mu);
+            if (drain_err.empty()) drain_err = "hipEventSynchronize failed";
+            return;
+        }
+        (void)hipMemcpy(st_host.data() + lo, bf.d_st[par], n * 4, hipMemcpyDeviceToHost);
+        int b = 0;
+        for (size_t s0 = 0; s0 < n; s0 += slice_sets, b = (b + 1) % kStage) {
+            const size_t m = std::min(slice_sets, n - s0);
+            pool.wait_zero(pending[par][b]);  // the writers are done with what this buffer held
+            if (hipMemcpyAsync(bf.stage[par][b], (const char*)bf.d_out[par] + s0 * row_b, m * row_b, hipMemcpyDeviceToHost, bf.copy[par]) != hipSuccess ||
+                hipStreamSynchronize(bf.copy[par]) != hipSuccess) {
+                std::lock_guard<std::mutex> l2(err_mu);
+                if (drain_err.empty()) drain_err = "device-to-host copy of the witness rows failed";
+                return;
+            }
+            pending[par][b].store((int)m, std::memory_order_release);
+            for (size_t i = 0; i < m; ++i)
+                pool.push(WriterPool::Task{(const uint8_t*)bf.stage[par][b] + i * row_b, first_index + lo + s0 + i, &pending[par][b]});
+        }
+        for (int q = 0; q < kStage; ++q) pool.wait_zero(pending[par][q]);
+    };
+    double compute_wait_s = 0;
+    for (size_t k = 0; k < K && err.empty(); ++k) {
+        const int par = (int)(k & 1);
+        const size_t lo = k * S, n = std::min(S, B - lo);
+        if (drains[par].joinable()) {  // sub-batch k - 2 used these buffers
+            const auto t0 = std::chrono::steady_clock::now();
+            drains[par].join();
+            compute_wait_s += since(t0);
+        }
+        // parse sub-batch k (contiguous ranges per thread; the lowest failing set is reported)
+        const auto tp = std::chrono::steady_clock::now();
+        {
+            unsigned nt = n_parse;
+            if (n < 64) nt = 1;
+            if (nt > n) nt = (unsigned)n;
+            std::vector<std::string> errs(nt);
+            std::vector<size_t> bad(nt, (size_t)-1);
+            auto work = [&](unsigned w) {
+                const size_t a = n * w / nt, bnd = n * (w + 1) / nt;
+                size_t i = a;
+                try {
+                    InputList list;
+                    for (; i < bnd; ++i) {
+                        std::string e;
+                        const auto& sp = spans[lo + i];
+                        if (!deserialize_inputs(text + sp.first, sp.second - sp.first, list, e) ||
+                            !populate_inputs(list, meta, (uint8_t*)bf.h_rows[par] + i * NI * 32, NI, e)) {
+                            errs[w] = e;
+                            bad[w] = lo + i;
+                            return;
+                        }
+                    }
+                } catch (...) {
+                    errs[w] = "out of memory";
+                    bad[w] = lo + i;
+                }
+            };
+            std::vector<std::thread> th;
+            unsigned started = 1;
+            try {
+                for (; started < nt; ++started) th.emplace_back(work, started);
+            } catch (...) {
+            }
+            work(0);
+            for (unsigned w = started; w < nt; ++w) work(w);
+            for (auto& t : th) t.join();
+            for (unsigned w = 0; w < nt; ++w)
+                if (bad[w] != (size_t)-1 && bad[w] < parse_bad) {
+                    parse_bad = bad[w];
+                    parse_err = errs[w];
+                }
+        }
+        parse_s += since(tp);
+        if (parse_bad != (size_t)-1) {
+            err = "Failed to calculate witness: input set " + std::to_string(parse_bad) + ": " + parse_err;
+            break;
+        }
+        if (hipMemcpyAsync(bf.d_in[par], bf.h_rows[par], n * NI * 32, hipMemcpyHostToDevice, bf.compute) != hipSuccess) {
+            err = "host-to-device copy of the input rows failed";
+            break;
+        }
+        err = run_device(g, bf.d_in[par], n, bf.d_out[par], (uint32_t*)bf.d_st[par], bf.compute);
+        if (!err.empty()) break;
+        if (hipEventRecord(bf.done[par], bf.compute) != hipSuccess) {
+            err = "hipEventRecord failed";
+            break;
+        }
+        drains[par] = std::thread(drain, k);
+    }
+    for (auto& d : drains)
+        if (d.joinable()) d.join();
+    pool.finish();
+    if (err.empty()) err = drain_err;
+    if (err.empty()) err = pool.err;
+    if (!err.empty()) return fail(status, err);
+    if (set_status_out) memcpy(set_status_out, st_host.data(), B * 4);
+    if (stats) {
+        stats->n_sets = B;
+        stats->sub_batch = S;
+        stats->parse_threads = n_parse;
+        stats->write_threads = n_write;
+        stats->parse_seconds = parse_s;
+        stats->wait_for_drain_seconds = compute_wait_s;
+        stats->total_seconds = since(t_start);
+        stats->witness_bytes = (uint64_t)B * row_b;
+    }
+    set_status(status, OK, "");
+    return 0;
+    });
+}
+
 int gwb_set_tile_width(gwb_graph_t* g, uint32_t key) {
     const uint32_t T = key & ~KEY_MODE_MASK;
     const uint32_t mode = key & (KEY_DIVIDER | KEY_GROUP | KEY_TRIPLE), smode = key & (KEY_STREAMS2 | KEY_STREAMS4);
@@ -914,11 +1411,14 @@ int gwb_calc_witness_batch_handoff(gwb_graph_t* g, const void* d_inputs, size_t 
     });
 }
 
-double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters) {
+static double ubench_modmul(uint32_t waves_per_simd, uint32_t iters, bool block_multiplier);
+double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters) { return ubench_modmul(waves_per_simd, iters, false); }
+double gwb_ubench_modmul_block(uint32_t waves_per_simd, uint32_t iters) { return ubench_modmul(waves_per_simd, iters, true); }
+static double ubench_modmul(uint32_t waves_per_simd, uint32_t iters, bool block_multiplier) {
     // chip-wide one-lane Montgomery products per second with `waves_per_simd` waves on every SIMD (bench.py's compute
     // ceiling, measured in the same run); 0 on failure
     try {
-        if (!check_device().empty() || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return 0.0;
+        if (!check_device().empty() || waves_per_simd < 1 || waves_per_simd > (block_multiplier ? 2u : 4u) || iters == 0) return 0.0;
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0.0;
@@ -927,8 +1427,8 @@ double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters) {
         double rate = 0.0;
         if (hipMalloc(&sink, 64) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             const uint32_t cus = (uint32_t)prop.multiProcessorCount;
-            bool ok = launch_modmul_ubench(cus, waves_per_simd, iters, sink, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // warm-up
-            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess && launch_modmul_ubench(cus, waves_per_simd, iters, sink, nullptr) == hipSuccess &&
+            bool ok = launch_modmul_ubench(cus, waves_per_simd, iters, sink, nullptr, block_multiplier) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // warm-up
+            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess && launch_modmul_ubench(cus, waves_per_simd, iters, sink, nullptr, block_multiplier) == hipSuccess &&
                  hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
             float ms = 0.f;
             if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
@@ -991,6 +1491,44 @@ int gwb_last_timing(gwb_graph_t* g, gwb_timing_t* t) {
     return 0;
 }
 
+int gwb_program_stats(gwb_graph_t* g, uint32_t program_key, gwb_program_stats_t* out) {
+    // statistics of the compiled program for `program_key` (0: the one the last batch call used): bundles and nodes per
+    // class, the cost model's lone-wave cycles, and the mean share of a wave's 64 lanes that hold a node of the graph,
+    // weighted by the modelled time of the bundles -- the number behind a low instruction-issue efficiency
+    if (!g || !out) return 1;
+    try {
+        std::lock_guard<std::mutex> lk(g->mu);
+        const Program* p = nullptr;
+        if (program_key == 0) program_key = g->last_key;
+        auto it = g->progs.find(program_key);
+        if (it != g->progs.end()) p = &it->second->host;
+        auto pre = g->compiled.find(program_key);
+        if (!p && pre != g->compiled.end()) p = pre->second.get();
+        if (!p) return 1;
+        memset(out, 0, sizeof *out);
+        out->tile_width = p->T;
+        out->divider = p->divider;
+        out->streams = p->n_streams;
+        out->n_bundles = p->n_bundles;
+        out->n_classes = C_COUNT;
+        double wsum = 0, lsum = 0;
+        for (uint32_t c = 0; c < C_COUNT && c < 16; ++c) {
+            out->class_bundles[c] = p->stats.class_bundles[c];
+            out->class_nodes[c] = p->stats.class_nodes[c];
+            const double cyc = model_class_cycles((int)c) * (double)p->stats.class_bundles[c];
+            const double lanes = (double)p->stats.class_nodes[c] * p->T * ((c == C_MULQ || c == C_MULF) ? (double)COOP_LANES : 1.0);
+            wsum += cyc;
+            lsum += p->stats.class_bundles[c] ? cyc * lanes / (double)p->stats.class_bundles[c] : 0.0;
+        }
+        out->model_wave_cycles = program_wave_cycles(*p);
+        out->lanes_active_mean = wsum > 0 ? lsum / wsum : 0.0;
+        out->n_fused_nodes = p->stats.n_fused_nodes;
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
 int gwb_timing_history(gwb_graph_t* g, size_t max_launches, float* interp_ms, float* pack_ms, size_t* n_out) {
     if (!g || !n_out || (max_launches && (!interp_ms || !pack_ms))) return 1;
     std::lock_guard<std::mutex> lk(g->mu);
@@ -1015,12 +1553,12 @@ int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void
     std::string err = check_device();
     if (!err.empty()) return fail(status, err);
     unsigned long long* d = nullptr;
-    if (hipMalloc(&d, 64 * 8) != hipSuccess || hipMemset(d, 0, 64 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
+    if (hipMalloc(&d, 72 * 8) != hipSuccess || hipMemset(d, 0, 72 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
     g->d_prof = d;
     err = run_device(g, d_inputs, batch, d_witness, d_set_status, nullptr);
     g->d_prof = nullptr;
     if (err.empty() && hipDeviceSynchronize() != hipSuccess) err = "hipDeviceSynchronize failed";
-    if (err.empty() && hipMemcpy(out36, d, 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
+    if (err.empty() && hipMemcpy(out36, d, 72 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
     (void)hipFree(d);
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");
@@ -1045,8 +1583,11 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
     if ((T & ~KEY_MODE_MASK) == 64) T = 64;
     auto it = g->progs.find(T);
     std::string err;
+    auto pre = g->compiled.find(T);
     if (it != g->progs.end()) {
         p = &it->second->host;
+    } else if (pre != g->compiled.end()) {  // compiled for the cost model, not uploaded yet
+        p = pre->second.get();
     } else {
         if (!g->has_graph) return fail(status, "imported handle has no program for that tile width");
         if (!compile_program(g->graph, T & ~KEY_MODE_MASK, key_divider_waves(T), tmp, err, key_streams(T))) return fail(status, err);
@@ -1249,16 +1790,34 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         for (auto& e : g_cache)
             if (e.hash == h && e.bytes.size() == graph_data_len && memcmp(e.bytes.data(), graph_data, graph_data_len) == 0) g = e.g;
     }
+    std::string cache_file;  // non-empty: this call computed a program worth writing to the on-disk cache
     if (!g) {
-        gwb_graph* raw = nullptr;
-        if (load_graph(graph_data, graph_data_len, &raw, err)) return fail(status, "Failed to calculate witness: " + err);
-        g.reset(raw);
+        const std::string cf = program_cache_file(graph_data, graph_data_len);
+        std::vector<uint8_t> blob;
+        if (!cf.empty() && read_file(cf, blob) && check_device().empty()) {  // a program an earlier process compiled for this very image
+            gwb_graph_t* imported = nullptr;
+            gw_status_t st2{OK, nullptr};
+            if (gwb_graph_import(blob.data(), blob.size(), &imported, &st2) == 0) g.reset(imported);
+            if (getenv("CWC_DEBUG_CACHE")) fprintf(stderr, "program cache: %s %s%s%s\n", g ? "hit" : "ignored", cf.c_str(), g ? "" : ": ", g ? "" : (st2.error_msg ? st2.error_msg : "?"));
+            gwb_free_status(&st2);  // (a damaged / stale file: fall through to the compiler, the file is rewritten)
+        }
+        if (!g) {
+            gwb_graph* raw = nullptr;
+            if (load_graph(graph_data, graph_data_len, &raw, err)) return fail(status, "Failed to calculate witness: " + err);
+            g.reset(raw);
+            cache_file = cf;
+        }
         std::lock_guard<std::mutex> lk(g_cache_mu);
         if (g_cache.size() >= 4) g_cache.erase(g_cache.begin());
         g_cache.push_back(CacheEntry{h, std::vector<uint8_t>((const uint8_t*)graph_data, (const uint8_t*)graph_data + graph_data_len), g});
     }
     std::vector<uint8_t> row((size_t)g->n_inputs * 32), wit((size_t)g->n_witness * 32);
-    if (!populate_inputs(list, g->graph, row.data(), g->n_inputs, err)) return fail(status, "Failed to calculate witness: " + err);
+    {
+        Graph meta;  // populate_inputs only needs the input map (a handle imported from the cache holds no graph)
+        meta.inputs = g->inputs;
+        meta.input_index = g->input_index;
+        if (!populate_inputs(list, meta, row.data(), g->n_inputs, err)) return fail(status, "Failed to calculate witness: " + err);
+    }
     if (quirks())
         for (const auto& kv : list) {
             const InputSignal& s = g->inputs[g->input_index.at(kv.first)];
@@ -1271,6 +1830,31 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         if (err.empty()) err = run_host(g.get(), row.data(), 1, wit.data(), &st);
     }
     if (!err.empty()) return fail(status, "Failed to calculate witness: " + err);
+    // The program for the on-disk cache: the one the background search settled on (the quick first program is not worth
+    // keeping).  Written by whichever call first finds the search finished.
+    if (!cache_file.empty() || (g->has_graph && !g->cache_written)) {
+        const std::string cf = !cache_file.empty() ? cache_file : program_cache_file(graph_data, graph_data_len);
+        uint32_t key = 0;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            auto it = g->chosen.find(1);
+            if (it != g->chosen.end() && !g->refining.count(1)) key = it->second;
+        }
+        if (!cf.empty() && key) {
+            void* blob = nullptr;
+            size_t blob_len = 0;
+            gw_status_t st2{OK, nullptr};
+            if (gwb_graph_export(g.get(), key, &blob, &blob_len, &st2) == 0) {
+                write_file_atomically(cf, blob, blob_len);
+                if (getenv("CWC_DEBUG_CACHE")) fprintf(stderr, "program cache: wrote %s (program key %#x, %zu bytes)\n", cf.c_str(), key, blob_len);
+            }
+            gwb_free_status(&st2);
+            free(blob);
+            g->cache_written = true;
+        } else if (cf.empty()) {
+            g->cache_written = true;
+        }
+    }
     if (st) return fail(status, "Failed to calculate witness: " + set_status_text(st));
     const size_t n = wtns_size(g->n_witness);
     void* buf = malloc(n);

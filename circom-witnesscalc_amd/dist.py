@@ -53,6 +53,99 @@ def broadcast_graph(pkg, graph_data, tile_width=0, src=0, device=None, batch_per
     return g
 
 
+class RcclComm:
+    """A RCCL communicator of this process group's ranks, made for the library's own collective (gwb_graph_broadcast takes an
+    ncclComm_t; torch does not hand out the one it uses).  rank `src` draws the unique id (ncclGetUniqueId), torch.distributed
+    carries its 128 bytes to the other ranks, every rank joins with ncclCommInitRank.  RCCL is the copy torch has already
+    loaded (librccl.so in torch/lib), resolved through the process's global symbols."""
+
+    def __init__(self, device, src=0):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        self._ct = ctypes
+        # the copy torch itself uses comes first (by path: dlopen then returns that instance and makes its symbols global, which
+        # is where gwb_graph_broadcast looks ncclBroadcast up), then the system's
+        import os
+        L = None
+        for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"):
+            try:
+                cand = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                cand.ncclGetUniqueId
+                L = cand
+                break
+            except (OSError, AttributeError):
+                continue
+        if L is None:
+            raise RuntimeError("RCCL not found (librccl.so)")
+        self.L = L
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_ubyte * 128)]  # (c_char would cut the id at its first zero byte when read back)
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        L.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = UniqueId()
+        if rank == src and L.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == src else bytes(128)), dtype=torch.uint8).clone().to(device)
+        dist.broadcast(t, src=src)
+        raw = t.cpu().numpy().tobytes()
+        ctypes.memmove(ctypes.byref(uid), raw, 128)
+        self.comm = ctypes.c_void_p()
+        torch.cuda.set_device(device)
+        rc = L.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank)
+        if rc != 0:
+            L.ncclGetErrorString.restype = ctypes.c_char_p
+            raise RuntimeError("ncclCommInitRank failed: %s" % L.ncclGetErrorString(rc).decode())
+        n = ctypes.c_int(0)
+        L.ncclCommCount(self.comm, ctypes.byref(n))
+        self.n_ranks = n.value
+
+    def close(self):
+        if getattr(self, "comm", None) and self.comm.value:
+            self.L.ncclCommDestroy(self.comm)
+            self.comm = self._ct.c_void_p()
+
+
+def broadcast_graph_rccl(pkg, graph_data, tile_width=0, src=0, device=None, batch_per_rank=0, comm=None):
+    """The same exchange through the C-ABI collective gwb_graph_broadcast (RCCL over xGMI): rank `src` loads the graph, the
+    library asks its cost model (tile_width = 0), exports the program and broadcasts it on a RCCL communicator, every other
+    rank imports it.  Returns (pkg.Graph, number of ranks of the communicator the broadcast ran on)."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    own = comm is None
+    if own:
+        comm = RcclComm(device, src)
+    try:
+        g = pkg.Graph(graph_data) if rank == src else None
+        out, st = ctypes.c_void_p(), pkg.GwStatus()
+        L = pkg.lib()
+        L.gwb_graph_broadcast.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(pkg.GwStatus)]
+        stream = torch.cuda.current_stream(device)
+        rc = L.gwb_graph_broadcast(g._h if g is not None else None, tile_width, batch_per_rank or 0, src, rank, comm.comm, stream.cuda_stream, ctypes.byref(out),
+                                   ctypes.byref(st))
+        msg = ctypes.string_at(st.error_msg).decode("utf-8", "replace") if st.error_msg else ""
+        L.gwb_free_status(ctypes.byref(st))
+        if rc != 0:
+            raise pkg.WitnessCalcError(msg or "gwb_graph_broadcast failed")
+        if rank != src:
+            g = pkg.Graph(_handle=out)
+        elif not tile_width:
+            tile_width = g.pick_tile_width(batch_per_rank)
+        if rank == src:
+            g.set_tile_width(tile_width)
+        return g, comm.n_ranks
+    finally:
+        if own:
+            comm.close()
+
+
 def set_checksums(d_witness, chunk=256):
     """64-bit checksum per input set of device witness rows [B, W, 32] (torch uint8 cuda/cpu tensor): the row's int64
     words times fixed odd weights, summed with wrap-around.  Independent of how the batch was sharded, so the list of

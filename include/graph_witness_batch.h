@@ -81,12 +81,29 @@ int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *ro
 
 /* Batched front-end: `text` is a JSON array of input objects or NDJSON (one object per line); fills up to max_rows
  * rows of n_inputs x 32 bytes, *n_rows = number of input sets found (also set when the buffer is too small).  The input
- * sets are parsed on CWC_PARSE_THREADS host threads (default min(cores, 16)). */
+ * sets are parsed on CWC_PARSE_THREADS host threads (default: every core). */
 int gwb_inputs_from_json_batch(const gwb_graph_t *g, const char *text, size_t text_len, void *rows, size_t max_rows,
                                size_t *n_rows, gw_status_t *status);
 /* Write one `.wtns` file per input set (76-byte header + row, src/lib.rs:114-123); path_pattern takes the set index
  * through one %lu conversion, e.g. "out/witness_%05lu.wtns". */
 int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, const char *path_pattern, gw_status_t *status);
+
+/* End to end and streaming: `text` (a JSON array of input objects or NDJSON) -> one `.wtns` file per input
+ * set, path_pattern with one %lu conversion for first_index + the set's position.  Sub-batches move through a pipeline: the
+ * next one is parsed (host threads) and evaluated while the witness rows of the previous one leave HBM in slices through
+ * pinned staging and writer threads frame them as files (lib.rs:114-123).  *n_sets = input sets found; set_status (NULL or
+ * max_sets words) takes the per-set status words.  CWC_E2E_SUBBATCH (default 512), CWC_PARSE_THREADS (default all cores),
+ * CWC_WRITE_THREADS (default min(cores, 32)) tune it. */
+typedef struct {
+  size_t n_sets, sub_batch;
+  uint32_t parse_threads, write_threads;
+  double parse_seconds;            /* summed over the sub-batches (overlapped with kernels and copies of the previous one) */
+  double wait_for_drain_seconds;   /* the calling thread waiting for copies / file writes before it could reuse buffers */
+  double total_seconds;
+  uint64_t witness_bytes;
+} gwb_e2e_stats_t;
+int gwb_calc_witness_json_to_wtns(gwb_graph_t *g, const char *text, size_t text_len, const char *path_pattern, size_t first_index,
+                                  size_t *n_sets, uint32_t *set_status, size_t max_sets, gwb_e2e_stats_t *stats, gw_status_t *status);
 
 /* Wherever this API takes or returns a tile width it is a "program key": the width (input sets per wavefront, a power
  * of two in 1..64), optionally OR'ed with GWB_TILE_ASYNC_DIVIDER = programs for the asynchronous divider wave (one
@@ -161,7 +178,7 @@ int gwb_timing_history(gwb_graph_t *g, size_t max_launches, float *interp_ms, fl
  * bundles out64[48 + 8*k + {0: loop top + wait for staged operands, 1: LDS operand reads with the previous bundle's
  * stores issued behind them, 2: issuing the staging loads, 3: dispatch + arithmetic, 4: ring write, 5: bundles}];
  * over all interpreter waves: out64[54] = longest run time of the loop, out64[55] = 2^40 - shortest, out64[62] = sum,
- * out64[63] = waves.  out64 must hold 64 words. */
+ * out64[63] = waves; out64[64] / out64[67] = cycles / bundles of the fused narrow bundles (class 13).  out64 must hold 72 words. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out64, gw_status_t *status);
 
@@ -169,6 +186,21 @@ int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void
  * lane running a dependent chain of 2 * iters products (the compute ceiling bench.py reports beside the HBM model);
  * 0.0 on failure. */
 double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters);
+
+/* ... and with the multiplier of the interpreter's full-width bundles (one asm block, 322 issue slots, pinned accumulators:
+ * waves_per_simd 1 or 2): the denominator of bench.py's `roofline.compute`. */
+double gwb_ubench_modmul_block(uint32_t waves_per_simd, uint32_t iters);
+
+/* Statistics of a compiled program (program_key 0: the program the last batch call on this handle used). */
+typedef struct {
+  uint32_t tile_width, divider, streams, n_classes;
+  uint64_t n_bundles, n_fused_nodes;
+  uint64_t class_bundles[16];   /* per bundle class (program_dev.h BundleClass) */
+  uint64_t class_nodes[16];
+  double model_wave_cycles;     /* the cost model's lone-wave cycles for one tile */
+  double lanes_active_mean;     /* of a wave's 64 lanes: mean number holding a node's work, weighted by the bundles' modelled time */
+} gwb_program_stats_t;
+int gwb_program_stats(gwb_graph_t *g, uint32_t program_key, gwb_program_stats_t *out);
 
 /* `.wtns` framing of one witness row (wtns_from_witness, src/lib.rs:114-123): out holds gwb_wtns_size bytes. */
 size_t gwb_wtns_size(size_t n_witness);

@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the single-shot entry point's on-disk program cache stays out of the tests (the test of the cache itself names a directory)
+os.environ.setdefault("CWC_PROGRAM_CACHE", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -21,10 +21,14 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d43Q"
+HDR_FMT = "<12I12I6I12d46Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF"]
+N_CLASSES = len(CLASS_NAMES)
+FOP_NONE, FOP_MUL, FOP_ADD, FOP_SUB, FOP_RSUB = range(5)  # stage codes of a fused node (class MULF)
+HDR_F_S2MUL, HDR_F_S2LIN, HDR_F_S3LIN = 1 << 11, 1 << 12, 1 << 13
+COOP_FUSE_MAX_T = 2
 COOP_LANES, COOP_MAX_T = 4, 4
 
 
@@ -40,8 +44,9 @@ class Blob:
         assert sum(self.stream_div_requests[:self.n_streams]) == self.n_div_requests
         assert self.n_streams == 1 or self.divider in (0, 1), "streams have a divider wave each, or none"
         st = h[42:]
+        c0, c1, c2 = 6, 6 + N_CLASSES, 6 + 2 * N_CLASSES
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[6:19], class_bundles=st[19:32], n_op_compiled=st[32], n_bitx_bundles=st[33], n_bitx_nodes=st[34], algorithmic_bytes_per_set=st[35], n_coop_rider_bundles=st[36], n_conversions=st[37], n_canonical=st[38], form_cycles_saved=st[39], n_folded=st[40], n_numbered=st[41], n_shaken=st[42])
+                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -133,11 +138,13 @@ def run(blob: Blob, inputs_row):
         assert not (h & HDR_POST) or (stream == 0 and blob.n_streams > 1)
         # narrow multiplication bundle: four lanes per product, a node's record sits at positions 4j .. 4j+3 and its
         # value t + T * j is staged by lane 4 * T * j + t
-        rep = COOP_LANES if name == "MULQ" else 1
+        rep = COOP_LANES if name in ("MULQ", "MULF") else 1
         assert name != "MULQ" or (T <= COOP_MAX_T and cnt * rep <= G)
+        assert name != "MULF" or (T <= COOP_FUSE_MAX_T and cnt * rep <= G)
         stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES
         results = []
         lin_seen = 0
+        fused_bits = 0
         if name == "DIVREQ":
             assert blob.divider and mailbox is None, "one division request in flight at a time"
             request = {}
@@ -146,6 +153,10 @@ def run(blob: Blob, inputs_row):
         for pos in range(G):
             j = pos // rep
             a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
+            if name == "MULF" and pos % rep:
+                # positions 4j+1 / 4j+3: the extra record (operands of the second / third stage, op3), 4j+2: the main record again
+                assert blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4] == blob.recs[(b * G + j * rep + (pos & 1)) * 4:(b * G + j * rep + (pos & 1)) * 4 + 4], "a fused node's records alternate main / extra"
+                continue
             if pos % rep:
                 assert blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4] == blob.recs[(b * G + j * rep) * 4:(b * G + j * rep) * 4 + 4], "the lanes of a product share one record"
                 continue
@@ -153,25 +164,54 @@ def run(blob: Blob, inputs_row):
             assert bool(ctrl & CTRL_ACTIVE) == (j < cnt)
             ops = []
             bitx = name == "BIT" and (ctrl & CTRL_SUB_MASK) == 5 and j < cnt  # (a >> k) & 1 with k = b_lds / 16
+
+            def fetch(off, la, q, rec_pos):
+                """operand q (0: a fields, 1: b fields) of the record at position rec_pos: its own stage cell or a ring cell"""
+                own_cell = stage + 2 * q * LDS_HALF_BYTES + rec_pos * T * 16
+                if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
+                    return mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD)
+                assert off == zero_off, "ring operand must stage the zero constant"
+                rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
+                assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
+                wb, val = ring[(rs, rem // (16 * T))]
+                assert 1 <= b - wb <= RING_BUNDLES, "ring cell too old"
+                return val
             for q, (off, la) in enumerate(((a_off, lds & 0xFFFF), (b_off, lds >> 16))):
                 if bitx and q == 1:
                     assert off == zero_off and la % 16 == 0 and la // 16 < 254
                     ops.append(la // 16)
                     continue
-                own_cell = stage + 2 * q * LDS_HALF_BYTES + j * rep * T * 16
-                if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
-                    ops.append(mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD))
-                else:
-                    assert off == zero_off, "ring operand must stage the zero constant"
-                    rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
-                    assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
-                    wb, val = ring[(rs, rem // (16 * T))]
-                    assert 1 <= b - wb <= RING_BUNDLES, "ring cell too old"
-                    ops.append(val)
+                ops.append(fetch(off, la, q, j * rep))
             if j >= cnt:  # padding: harmless operands, store to the trash slot
                 assert dst == trash and a_off == zero_off and b_off == zero_off
+                if name == "MULF":
+                    assert (ctrl & CTRL_SUB_MASK) == 0 and (blob.recs[(b * G + pos + 1) * 4 + 2] & CTRL_SUB_MASK) == 0, "idle groups of a fused bundle have no later stage"
                 continue
             sub = ctrl & CTRL_SUB_MASK
+            if name == "MULF":
+                # (a * b) op2 x2 op3 x3 on the stored words: the same Montgomery products / modular sums as the unfused nodes
+                xa_off, xb_off, xdctl, xlds = blob.recs[(b * G + pos + 1) * 4:(b * G + pos + 1) * 4 + 4]
+                op2, op3 = sub, xdctl & CTRL_SUB_MASK
+                assert op2 <= FOP_RSUB and op3 in (FOP_NONE, FOP_ADD, FOP_SUB, FOP_RSUB) and (xdctl & ~CTRL_MASK) == trash and (xdctl & CTRL_ACTIVE)
+                fused_bits |= (HDR_F_S2MUL if op2 == FOP_MUL else HDR_F_S2LIN if op2 else 0) | (HDR_F_S3LIN if op3 else 0)
+                acc = ops[0] * ops[1] * R_INV % model.M
+
+                def stage_op(code, acc, x):
+                    if code == FOP_MUL:
+                        return acc * x * R_INV % model.M
+                    if code == FOP_ADD:
+                        return (acc + x) % model.M
+                    return (acc - x) % model.M if code == FOP_SUB else (x - acc) % model.M
+                if op2:
+                    acc = stage_op(op2, acc, fetch(xa_off, xlds & 0xFFFF, 0, j * rep + 1))
+                else:
+                    assert xa_off == zero_off
+                if op3:
+                    acc = stage_op(op3, acc, fetch(xb_off, xlds >> 16, 1, j * rep + 1))
+                else:
+                    assert xb_off == zero_off
+                results.append((dst, acc))
+                continue
 
             def mont_div(x, y):  # fr_inv: Montgomery in, Montgomery out; b == 0 -> 0 (graph.rs:109)
                 return x * pow(y, -1, model.M) * R_MONT % model.M if y % model.M else 0
@@ -221,7 +261,9 @@ def run(blob: Blob, inputs_row):
             mailbox = None
         else:
             assert name != "DIV" or not blob.divider
-        if name == "BIT":
+        if name == "MULF":
+            pass
+        elif name == "BIT":
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
             assert ((h >> 13) & 1) == (1 if all_x else 0), "BITX header bit must describe the records"
             subs = [blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK for jj in range(cnt)]
@@ -229,7 +271,10 @@ def run(blob: Blob, inputs_row):
             lin_seen = 0 if not limb else (1 << 11) if 1 in subs else (1 << 12)
         else:
             assert ((h >> 13) & 1) == 0
-        assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
+        if name == "MULF":
+            assert (h & (HDR_F_S2MUL | HDR_F_S2LIN | HDR_F_S3LIN)) == fused_bits, "stage bits of a fused bundle must describe its records"
+        else:
+            assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
         for d, v in results:

@@ -6,6 +6,7 @@ import json
 import os
 import random
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ from tools.graphgen.builder import Builder
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M = model.M
 EDGE = [0, 1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 253, 254, 255, 256, M - 1, M - 2, M // 2,
         M // 2 + 1, M // 2 + 2, 1 << 253, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 200, M & ((1 << 253) - 1),
@@ -609,6 +611,43 @@ def test_json_to_wtns_end_to_end_on_the_gpu(pkg, tmp_path):
     assert not st2.any() and np.array_equal(set_checksums(torch.from_numpy(got2)).numpy(), set_checksums(d_out[1000:1256]).cpu().numpy())
 
 
+@pytest.mark.gpu
+def test_streaming_json_to_wtns_pipeline(pkg, tmp_path, monkeypatch):
+    """The streaming end-to-end entry point (gwb_calc_witness_json_to_wtns): sub-batches parsed on host threads and evaluated
+    while the previous one's witness rows leave HBM in slices and writer threads frame them as `.wtns` files.  Ragged sizes
+    (a last sub-batch of 3 sets, a last slice of one set), a JSON array instead of NDJSON, a set that panics in the
+    reference (status word, file still written), an unparsable set (the call fails and names it); every file byte-equal
+    to the oracle's `.wtns`."""
+    bld = C.build_gadgets()
+    nodes, wit, inputs = bld.finalize()
+    data = bld.to_bin()
+    g = pkg.Graph(data)
+    og = cbind.Graph(data)
+    rnd = random.Random(9)
+    B = 131
+    rows = [_rand_row(rnd, g.n_inputs) for _ in range(B)]
+
+    def obj(r):
+        return {name: [str(v) for v in r[off:off + n]] for name, (off, n) in inputs.items()}
+    want, wst = og.evaluate_batch(cbind.ints_to_array(rows))
+    for sub, text in (("64", "\n".join(json.dumps(obj(r)) for r in rows)), ("7", json.dumps([obj(r) for r in rows])), ("1000", "\n\n".join(json.dumps(obj(r)) for r in rows))):
+        monkeypatch.setenv("CWC_E2E_SUBBATCH", sub)
+        d = tmp_path / ("out" + sub)
+        d.mkdir()
+        st, stats = g.json_to_wtns(text, str(d / "w_%05lu.wtns"), first_index=40)
+        assert len(st) == B and stats["n_sets"] == B and np.array_equal(st != 0, wst != 0)
+        assert sorted(os.listdir(d)) == ["w_%05d.wtns" % (40 + i) for i in range(B)]
+        for i in range(B):
+            if not wst[i]:
+                assert (d / ("w_%05d.wtns" % (40 + i))).read_bytes() == model.wtns_from_witness(cbind.array_to_ints(want[i])), (sub, i)
+    bad = [json.dumps(obj(r)) for r in rows[:20]]
+    bad[13] = '{"x": -5}'
+    with pytest.raises(pkg.WitnessCalcError, match="input set 13"):
+        g.json_to_wtns("\n".join(bad), str(tmp_path / "bad_%lu.wtns"))
+    with pytest.raises(pkg.WitnessCalcError, match="cannot open"):
+        g.json_to_wtns(json.dumps(obj(rows[0])), str(tmp_path / "no_such_dir" / "w_%lu.wtns"))
+
+
 def test_bin_writer_round_trip_on_the_gpu(pkg):
     """SURVEY 8(f) f1, against the ORACLE: generator -> product writer (C-ABI producer gwb_builder_* ->
     serialize_witnesscalc_graph, storage.rs:137-183) -> bytes equal to the independent pure-Python writer -> loaded by the
@@ -699,6 +738,66 @@ def test_single_shot_cache_distinguishes_graphs_of_equal_length(pkg):
     for _ in range(2):
         assert pkg.calc_witness('{"x": "7"}', d1)[1] == 1049
         assert pkg.calc_witness('{"x": "7"}', d2)[1] == 2049
+
+
+@pytest.mark.gpu
+def test_single_shot_quick_first_call_background_search_and_disk_cache(pkg, tmp_path):
+    """gw_calc_witness on a graph it has never seen runs ONE quickly compiled program at once and lets the search over
+    candidate programs / schedule variants finish in the background; the refined program replaces the quick one and is
+    written to the on-disk cache (CWC_PROGRAM_CACHE), where the next PROCESS finds it.  Every call gives the oracle's
+    bytes: the quick program, the refined one, the one imported from the cache; a damaged or truncated cache file is
+    ignored (checksum / structural validation of the blob) and rewritten."""
+    import subprocess
+    import time
+    data = C.build_authv2_class(scale=0.12).to_bin()
+    gpath, ipath = tmp_path / "g.bin", tmp_path / "in.json"
+    gpath.write_bytes(data)
+    ins = C.authv2_reference_inputs()
+    ipath.write_text(json.dumps({k: [str(x) for x in v] for k, v in ins.items()}))
+    nodes, wit, in_map = model.deserialize_witnesscalc_graph(data)
+    row = [1] + [0] * (model.get_inputs_size(nodes) - 1)
+    for k, v in ins.items():
+        off, n = in_map[k]
+        row[off:off + n] = v[:n]
+    want = model.wtns_from_witness(model.evaluate(nodes, row, wit))
+    cache = tmp_path / "cache"
+    script = (
+        "import sys, time, hashlib\n"
+        "sys.path.insert(0, %r)\n"
+        "import cwc_import; pkg = cwc_import.load()\n"
+        "data = open(%r, 'rb').read(); js = open(%r).read()\n"
+        "out = []\n"
+        "for i in range(int(sys.argv[1])):\n"
+        "    t0 = time.perf_counter(); w = pkg.calc_witness_wtns(js, data); out.append((time.perf_counter() - t0, hashlib.sha256(w).hexdigest()))\n"
+        "    time.sleep(float(sys.argv[2]))\n"
+        "print('TIMES', ' '.join('%%.4f' %% t for t, _ in out)); print('DIGESTS', ' '.join(sorted(set(d for _, d in out))))\n"
+    ) % (ROOT, str(gpath), str(ipath))
+    env = dict(os.environ, CWC_PROGRAM_CACHE=str(cache), CWC_DEBUG_CACHE="1")
+
+    def run(calls, pause):
+        r = subprocess.run([sys.executable, "-c", script, str(calls), str(pause)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGESTS")][0].split()[1:]
+        assert digests == [hashlib.sha256(want).hexdigest()], (digests, r.stderr[-500:])
+        return r.stderr
+
+    # process 1: quick program first, the background search finishes within the run, the refined program goes to the cache
+    err1 = run(12, 0.5)
+    files = list(cache.glob("*.cwcprog"))
+    assert "program cache: wrote" in err1 and len(files) == 1, err1[-800:]
+    # process 2: served from the cache
+    err2 = run(2, 0.0)
+    assert "program cache: hit" in err2 and "wrote" not in err2, err2[-800:]
+    # a damaged file, then a truncated one: ignored, compiled again, rewritten
+    blob = bytearray(files[0].read_bytes())
+    blob[len(blob) // 2] ^= 0x40
+    files[0].write_bytes(bytes(blob))
+    err3 = run(12, 0.5)
+    assert "program cache: ignored" in err3 and "program cache: wrote" in err3, err3[-800:]
+    files[0].write_bytes(files[0].read_bytes()[:1000])
+    err4 = run(12, 0.5)
+    assert "program cache: ignored" in err4 and "program cache: wrote" in err4, err4[-800:]
+    assert "program cache: hit" in run(1, 0.0)
 
 
 STREAMS2, STREAMS4 = 0x800, 0x1000  # GWB_TILE_STREAMS2 / GWB_TILE_STREAMS4

@@ -255,6 +255,33 @@ def test_graph_compiler_emulated(pkg, tile):
             assert st == 0 and got == want
 
 
+def test_fused_narrow_chains_are_exact(pkg, monkeypatch):
+    """Round 3: the compiler fuses (s * s) * m + c and a * b +- c chains near the critical path into single nodes of narrow
+    bundles (class MULF; compile.cc fuse_narrow_chains).  With the fusion forced for every eligible chain (CWC_FUSE=1001)
+    the emulator -- which computes on the stored words, Montgomery or canonical -- gives the reference's witnesses, for
+    tile widths 1 and 2, with divider waves and as stream programs; the additions of canonical-form values read the
+    canonical copies of their constants (the bug the first GPU soak of this class found)."""
+    monkeypatch.setenv("CWC_FUSE", "1001")
+    rnd = random.Random(11)
+    total_fused = 0
+    cases = [C.build_poseidon(2), C.build_chain_heavy(3), C.build_chain_heavy(9, n_chains=16), C.build_bigint_class(k=3, rounds=2)] + \
+            [C.build_random_dag(s, n_ops=220, panic_free=True, parts=1 + s % 3) for s in range(8)]
+    for b in cases:
+        data = b.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        g = pkg.Graph(data)
+        for key in (1, 2, 1 | DIVIDER, 2 | STREAMS4):
+            blob = pe.Blob(g.export_blob(key))
+            total_fused += blob.stats["n_fused_nodes"]
+            assert (blob.stats["class_bundles"][13] > 0) == (blob.stats["n_fused_nodes"] > 0)
+            row = [1] + [rnd.randrange(model.M) if rnd.random() < 0.6 else rnd.randrange(1 << 10) for _ in range(blob.n_inputs - 1)]
+            got, st = pe.run(blob, row)
+            assert st == 0 and got == model.evaluate(nodes, row, wit)
+    assert total_fused > 200
+    # wider tiles have no fused bundles (the lane layout is that of the four-lane product, tile widths 1 and 2)
+    assert pe.Blob(pkg.Graph(C.build_poseidon(2).to_bin()).export_blob(4)).stats["n_fused_nodes"] == 0
+
+
 def test_slot_reuse_keeps_workspace_small(pkg):
     b = C.build_poseidon(2)
     g = pkg.Graph(b.to_bin())
@@ -450,21 +477,17 @@ def test_schedule_quality_guard(pkg):
     """The schedule of the bench workloads must not silently regress.  A wave's time is the sum of its bundles, priced per
     class with the cycles measured on MI355X (compile.cc kCycles): authV2-class at T = 2 with the divider wave 30.5 M
     cycles in round 2 (narrow four-lane multiplication bundles; 33.0 M without them), sha256_512 at T = 1: 5 399 bundles."""
-    import struct
-    cyc = dict(INPUT=4000, MUL=2015, LIN=706, DIV=73500, CMPZ=1000, CMPS=4700, BIT=2200, IDIVMOD=8500, TERN=1450, DIVREQ=1490, DIVGET=3700, MULQ=1306, SYNC=900)
+    cyc = dict(INPUT=4000, MUL=2015, LIN=706, DIV=73500, CMPZ=1000, CMPS=4700, BIT=2200, IDIVMOD=8500, TERN=1450, DIVREQ=1490, DIVGET=3700, MULQ=1306, SYNC=900, MULF=2400)
     g = pkg.Graph(C.build_authv2_class().to_bin())
-    blob = g.export_blob(2 | DIVIDER)
-    h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[42:][19:32]))
+    bl = pe.Blob(g.export_blob(2 | DIVIDER))
+    cb = dict(zip(pe.CLASS_NAMES, bl.stats["class_bundles"]))
     est = sum(cyc[k] * v for k, v in cb.items())
-    assert est <= 31.5e6 and cb["MULQ"] >= 3000 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0, (est, cb)
-    blob = g.export_blob(4)
-    h = struct.unpack_from(pe.HDR_FMT, blob, 0)
-    cb = dict(zip(pe.CLASS_NAMES, h[42:][19:32]))
-    assert h[4] <= 27500 and cb["DIV"] <= 275
+    assert est <= 31.5e6 and cb["MULQ"] + cb["MULF"] >= 3000 and cb["DIVREQ"] == cb["DIVGET"] <= 275 and cb["DIV"] == 0, (est, cb)
+    bl = pe.Blob(g.export_blob(4))
+    cb = dict(zip(pe.CLASS_NAMES, bl.stats["class_bundles"]))
+    assert bl.n_bundles <= 27500 and cb["DIV"] <= 275
     g = pkg.Graph(C.build_sha256(512).to_bin())
-    h = struct.unpack_from(pe.HDR_FMT, g.export_blob(1), 0)
-    assert h[4] <= 5600
+    assert pe.Blob(g.export_blob(1)).n_bundles <= 5600
 
 
 def test_load_time_optimiser_is_exact(pkg):

@@ -354,7 +354,7 @@ def shalf(s, h):
 
 
 # ---- the multiplier ---------------------------------------------------------------------------------------------------
-def make(K, vbase=168, sbase=88, riders=False):
+def make(K, vbase=168, sbase=88, riders=False, lin_only=False):
     """Instruction list for lane groups of K.  Inputs: %[a0..a7] (all of a, every lane), %[b0..b(L-1)] / %[n0..n(L-1)]
     (this lane's limbs of b / of the modulus), %[inv] (scalar -r^-1), %[top] (mask of every group's top lane).
     Outputs: %[r0..r(L-1)].  Temporaries are physical VGPRs from vbase and SGPR pairs from sbase (clobbered).
@@ -397,8 +397,11 @@ def make(K, vbase=168, sbase=88, riders=False):
         up = ("quad_perm", [1, 0, 3, 2])
     else:
         raise ValueError(K)
+    if lin_only:   # (a +- b) mod r alone, in the lane layout of the products (fused stages of a narrow bundle): riders only
+        assert riders
     inc, zero = newpair()   # (incoming word, 0): the 64-bit addend of a fresh top column
-    p.mov(zero, 0)
+    if not lin_only:
+        p.mov(zero, 0)
     mreg, mb = newv(), newv()
     # column accumulators: pair (w0, w1) + third word w2 that only collects carries
     cols = [{"pair": newpair(), "w2": newv(), "has2": False} for _ in range(L)]
@@ -416,7 +419,7 @@ def make(K, vbase=168, sbase=88, riders=False):
         else:
             p.addc(c["w2"], cy, 0, 0, cy)
             c["has2"] = True
-    for i in range(8):
+    for i in range(0 if lin_only else 8):
         # (1) C_j += a_i * b_j
         for j in range(L):
             c = cols[j]
@@ -458,7 +461,9 @@ def make(K, vbase=168, sbase=88, riders=False):
             cols.append(old0)
     # ---- normalisation: words W[0..L-1] + a small overflow into the next lane ----------------------------------------
     k = nextc()
-    if L == 1:
+    if lin_only:
+        W, ov = None, None
+    elif L == 1:
         W = [cols[0]["pair"][0]]
         ov = cols[0]["pair"][1]
     elif L == 2:
@@ -487,7 +492,8 @@ def make(K, vbase=168, sbase=88, riders=False):
         aq = ["%%[aq%d]" % j for j in range(L)]
         sub = "%[sub]"
         Madd, Msub = "%[sma]", "%[sms]"
-        p.cmp_eq(Madd, sub, 0)
+        if not lin_only:
+            p.cmp_eq(Madd, sub, 0)
         p.cmp_eq(Msub, sub, 1)
         mneg = newv()
         p.cndmask(mneg, 0, -1, Msub)          # all ones in subtracting lanes
@@ -506,10 +512,13 @@ def make(K, vbase=168, sbase=88, riders=False):
             p.addc(u[j], c2, u[j], bx[j], c2)
         p.addc(uov, c1, 0, 0, c1)
         p.addc(uov, c2, uov, 0, c2)
-        p.s_op("or", Madd, Madd, Msub)          # rider lanes
-        for j in range(L):
-            p.cndmask(W[j], W[j], u[j], Madd)
-        p.cndmask(ov, ov, uov, Madd)
+        if lin_only:
+            W, ov = u, uov
+        else:
+            p.s_op("or", Madd, Madd, Msub)          # rider lanes
+            for j in range(L):
+                p.cndmask(W[j], W[j], u[j], Madd)
+            p.cndmask(ov, ov, uov, Madd)
         p.cndmask(ov, ov, 0, "%[top]")          # the 2^256 of a subtraction leaves at the group's top lane
     # + overflow of the previous lane (a group's top overflow is zero: the result is below 2r < 2^255)
     ovin = newv()
@@ -572,9 +581,9 @@ def top_mask(K):
 
 
 # ---- emulation against big integers ------------------------------------------------------------------------------------
-def check(K, rounds=200, seed=1, riders=False):
+def check(K, rounds=200, seed=1, riders=False, lin_only=False):
     L = 8 // K
-    p, vend, send = make(K, riders=riders)
+    p, vend, send = make(K, riders=riders, lin_only=lin_only)
     p.schedule()
     rnd = random.Random(seed + K)
     Rinv = pow(1 << 256, -1, P_INT)
@@ -603,7 +612,7 @@ def check(K, rounds=200, seed=1, riders=False):
         st.s["%[top]"] = top_mask(K)
         subs = [2] * groups
         if riders:
-            subs = [rnd.choice([0, 1, 2]) for _ in range(groups)]
+            subs = [rnd.choice([0, 1] if lin_only else [0, 1, 2]) for _ in range(groups)]
             if it % 5 == 0:   # (a - a, a + (r - a), 0 - b: the edges of the correction)
                 B = [A[g_] if subs[g_] == 1 else (P_INT - A[g_]) % P_INT if subs[g_] == 0 else B[g_] for g_ in range(groups)]
                 for j in range(L):
@@ -624,17 +633,17 @@ def check(K, rounds=200, seed=1, riders=False):
     return len(lines) - sum(l.startswith("s_nop") for l in lines) + n_nop, n_nop, vend, send
 
 
-def emit(K, path, vbase=168, sbase=88, riders=False):
+def emit(K, path, vbase=168, sbase=88, riders=False, lin_only=False):
     L = 8 // K
-    p, vend, send = make(K, vbase, sbase, riders)
+    p, vend, send = make(K, vbase, sbase, riders, lin_only)
     lines, n_nop = p.lines()
-    scal = ["sc0", "sc1", "sc2", "sc3", "sp", "sb"] + (["sma", "sms"] if riders else [])
+    scal = ["sc0", "sc1", "sc2", "sc3", "sp", "sb"] + (["sms"] if lin_only else ["sma", "sms"] if riders else [])
     outs = ", ".join(['[r%d] "=&v"(r%d)' % (j, j) for j in range(L)] + ['[%s] "=&s"(%s)' % (x, x) for x in scal])
-    ins = ", ".join(['[a%d] "v"(a.v[%d])' % (i, i) for i in range(8)] + ['[b%d] "v"(b%d)' % (j, j) for j in range(L)]
-                    + ['[n%d] "v"(n%d)' % (j, j) for j in range(L)] + ['[inv] "s"(inv32)', '[top] "s"(top)']
+    ins = ", ".join(([] if lin_only else ['[a%d] "v"(a.v[%d])' % (i, i) for i in range(8)]) + ['[b%d] "v"(b%d)' % (j, j) for j in range(L)]
+                    + ['[n%d] "v"(n%d)' % (j, j) for j in range(L)] + ([] if lin_only else ['[inv] "s"(inv32)']) + ['[top] "s"(top)']
                     + (['[aq%d] "v"(aq%d)' % (j, j) for j in range(L)] + ['[sub] "v"(sub)', '[lane0] "s"(lane0)'] if riders else []))
     clob = ", ".join(['"v%d"' % r for r in range(vbase, vend)] + ['"s%d"' % r for r in range(sbase, send)] + ['"vcc"', '"scc"'])
-    text = ["// GENERATED by tools/codegen/gen_fr_mul_coop.py -- do not edit.  Lane-cooperative Montgomery product, groups of %d lanes" % K,
+    text = ["// GENERATED by tools/codegen/gen_fr_mul_coop.py -- do not edit.  Lane-cooperative %s, groups of %d lanes" % ("(a + b) / (a - b) mod r in the lane layout of the products" if lin_only else "Montgomery product", K),
             "// (%d limbs of b and of the modulus per lane, all of a in every lane)%s: %d issue slots, %d of them wait states; clobbers v%d-v%d, s%d-s%d."
             % (L, ", groups with sub = 0 / 1 add / subtract instead" if riders else "", len(lines) - sum(l.startswith("s_nop") for l in lines) + n_nop, n_nop, vbase, vend - 1, sbase, send - 1),
             "{",
@@ -658,10 +667,10 @@ if __name__ == "__main__":
     dst = os.path.join(here, "..", "..", "circom-witnesscalc_amd", "csrc")
     # K = 4 is what the interpreter uses (class C_MULQ), with and without linear riders; K = 8 and K = 2 are kept for the
     # microbenchmark (tools/ubench/coop_mul.hip: 624 / 704 / 1220 cycles per dependent product against 1436 for one lane)
-    for K, riders in ((4, False), (4, True), (8, False), (2, False)):
-        slots, nops, vend, send = check(K, rounds=60 if "--check" not in sys.argv else 400, riders=riders)
-        print("K=%d%s: emulation ok, %d issue slots (%d wait states), VGPR temps up to v%d, SGPR up to s%d" % (K, " + riders" if riders else "", slots, nops, vend - 1, send - 1))
+    for K, riders, lin_only in ((4, False, False), (4, True, False), (4, True, True), (8, False, False), (2, False, False)):
+        slots, nops, vend, send = check(K, rounds=60 if "--check" not in sys.argv else 400, riders=riders, lin_only=lin_only)
+        print("K=%d%s: emulation ok, %d issue slots (%d wait states), VGPR temps up to v%d, SGPR up to s%d" % (K, " add/sub only" if lin_only else " + riders" if riders else "", slots, nops, vend - 1, send - 1))
         if "--check" not in sys.argv:
-            path = os.path.normpath(os.path.join(dst, "fr_mul_coop%d%s_gfx950.inc" % (K, "r" if riders else "")))
-            emit(K, path, riders=riders)
+            path = os.path.normpath(os.path.join(dst, "fr_addsub_coop%d_gfx950.inc" % K if lin_only else "fr_mul_coop%d%s_gfx950.inc" % (K, "r" if riders else "")))
+            emit(K, path, riders=riders, lin_only=lin_only)
             print("wrote", path)
