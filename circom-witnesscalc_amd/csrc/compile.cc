@@ -545,7 +545,7 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
 // Only nodes within `slack` (scheduler cost units) of the graph's critical path are fused: off the critical path a fused
 // node saves nothing and takes one of the few node slots of a narrow bundle.
 static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, const uint32_t* class_cost, uint32_t slack_permille,
-                               uint64_t& n_fused) {
+                               bool two_stage_only, uint64_t& n_fused) {
     const size_t N = g.nodes.size();
     std::vector<uint64_t> rt(N, 0), ht(N, 0);  // earliest finish time / longest path to a sink (own cost included in both)
     std::vector<uint32_t> n_users(N, 0);
@@ -589,7 +589,9 @@ static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<
         // (s * s) * m + c: the square on the product's later side
         const uint32_t p = rt[M1.a] >= rt[M1.b] ? M1.a : M1.b, q = p == M1.a ? M1.b : M1.a;
         const uint8_t r = rep[i];
-        if (M1.a != M1.b && is_mul(p) && g.nodes[p].a == g.nodes[p].b && rt[p] >= rt[q] && rep[p] == rep[g.nodes[p].a] && rep[m1] == r) {
+        // (the three-stage form wants its last operand before the bundle starts; where that operand is a side sum that is
+        // ready only by the time the products are -- Poseidon's partial rounds -- product + sum alone is the better node)
+        if (!two_stage_only && M1.a != M1.b && is_mul(p) && g.nodes[p].a == g.nodes[p].b && rt[p] >= rt[q] && rep[p] == rep[g.nodes[p].a] && rep[m1] == r) {
             n = Node{N_FUSED, fused_code(true, FOP_MUL, lin), g.nodes[p].a, q, c};
         } else if (rep[m1] == r) {
             n = Node{N_FUSED, fused_code(false, lin, FOP_NONE), M1.a, M1.b, c};
@@ -704,7 +706,7 @@ struct CoopPolicy {
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
     bool all_montgomery = false;  // no representation inference: every value in Montgomery form
     bool witness_slots = false;   // the slots of witness elements in witness order (see the slot allocation)
-    uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused
+    uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused; + 0x10000: product + sum nodes only
 };
 // The rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) depends on the fusion switch and on
 // the weight table only: the schedule variants of one compile_program call share it instead of redoing it.
@@ -778,7 +780,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     // only the critical chain, chains within a few percent of it, every chain -- and the cost model picks
     // (CWC_FUSE=<thousandths + 1> forces one, CWC_NO_FUSE=1 none).
     if (T <= COOP_FUSE_MAX_T && kept.fill && !getenv("CWC_NO_FUSE")) {
-        std::vector<uint32_t> tries = {1, 11, 101, 1001};
+        std::vector<uint32_t> tries = {1, 11, 101, 1001, 0x10001, 0x1000b, 0x10065, 0x103e9};
         if (const char* e = getenv("CWC_FUSE")) tries.assign(1, (uint32_t)atoi(e));
         for (uint32_t f : tries) {
             CoopPolicy pol = kept;
@@ -961,7 +963,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     N = g.nodes.size();
     phase("representation inference");
     if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1) {
-        fuse_narrow_chains(g, node_rep, node_vflags, class_cost, policy.fuse - 1, st.n_fused_nodes);
+        fuse_narrow_chains(g, node_rep, node_vflags, class_cost, (policy.fuse & 0xffffu) - 1, (policy.fuse & 0x10000u) != 0, st.n_fused_nodes);
         N = g.nodes.size();
         phase("fused narrow chains");
     }

@@ -179,7 +179,7 @@ struct gwb_graph {
         void* d_st[2] = {nullptr, nullptr};
         void* stage[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
         hipStream_t compute = nullptr, copy[2] = {nullptr, nullptr};
-        hipEvent_t done[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr}, slice_done[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
         size_t in_bytes = 0, out_bytes = 0, st_bytes = 0, stage_bytes = 0;
         void release() {
             for (int i = 0; i < 2; ++i) {
@@ -251,6 +251,8 @@ struct gwb_graph {
         for (int i = 0; i < 2; ++i) {
             if (e2e.copy[i]) (void)hipStreamDestroy(e2e.copy[i]);
             if (e2e.done[i]) (void)hipEventDestroy(e2e.done[i]);
+            for (int b = 0; b < 3; ++b)
+                if (e2e.slice_done[i][b]) (void)hipEventDestroy(e2e.slice_done[i][b]);
         }
         if (e2e.compute) (void)hipStreamDestroy(e2e.compute);
     }
@@ -410,7 +412,8 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     auto hit = g->chosen.find(batch);
     if (hit != g->chosen.end()) return hit->second;
     // ---- small batches: quick program first, the full choice in the background (see gwb_graph::refining) ----
-    if (batch < 64 && !getenv("CWC_NO_QUICK_FIRST_CALL")) {
+    // (graphs beyond two million nodes have one schedule anyway: nothing for the background to search)
+    if (batch < 64 && g->graph.nodes.size() <= 2000000 && !getenv("CWC_NO_QUICK_FIRST_CALL")) {
         auto job = g->refining.find(batch);
         if (job != g->refining.end()) {
             if (job->second.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return g->provisional[batch];
@@ -1082,7 +1085,7 @@ int gwb_wtns_save_batch(const void* witness, size_t n_witness, size_t batch, con
 }
 
 // ---- end to end, streaming: JSON text -> rows -> HBM -> kernels -> pinned staging -> `.wtns` files ----------
-// Sub-batches of CWC_E2E_SUBBATCH input sets (default 512) move through a three-stage pipeline: the calling thread parses
+// Sub-batches of CWC_E2E_SUBBATCH input sets (default 1024) move through a three-stage pipeline: the calling thread parses
 // sub-batch k + 1 on the parse threads and enqueues its upload and kernels, while a drain thread copies the witness rows of
 // sub-batch k out of HBM in slices of whole sets (copy stream, pinned staging buffers) and a pool of writer threads frames
 // every set of a finished slice as its own `.wtns` file (76-byte header + row, lib.rs:114-123).  The interpreter's value
@@ -1186,7 +1189,7 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
     err = check_device();
     if (!err.empty()) return fail(status, err);
     const size_t B = spans.size(), NI = g->n_inputs, NW = g->n_witness, row_b = NW * 32;
-    size_t S = 512;
+    size_t S = 1024;  // (measured on MI355X, authV2-class: 256 -> 10.6 k, 512 -> 14.1 k, 1024 -> 14.3 k witnesses/s; profiles/r03_e2e_ab.txt)
     if (const char* e = getenv("CWC_E2E_SUBBATCH")) {
         const long v = atol(e);
         if (v >= 1) S = (size_t)v;
@@ -1210,7 +1213,10 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
     for (int i = 0; ok && i < 2; ++i) {
         if (!bf.copy[i]) ok = hip_ok(hipStreamCreateWithFlags(&bf.copy[i], hipStreamNonBlocking), "hipStreamCreate");
         if (ok && !bf.done[i]) ok = hip_ok(hipEventCreateWithFlags(&bf.done[i], hipEventDisableTiming), "hipEventCreate");
+        for (int b = 0; ok && b < kStage; ++b)
+            if (!bf.slice_done[i][b]) ok = hip_ok(hipEventCreateWithFlags(&bf.slice_done[i][b], hipEventDisableTiming), "hipEventCreate");
     }
+    auto& slice_done = bf.slice_done;
     const size_t need_in = std::max<size_t>(32, S * NI * 32), need_out = std::max<size_t>(32, S * row_b), need_st = S * 4, need_stage = std::max<size_t>(32, slice_sets * row_b);
     if (ok && (need_in > bf.in_bytes || need_out > bf.out_bytes || need_st > bf.st_bytes || need_stage > bf.stage_bytes)) {
         (void)hipDeviceSynchronize();
@@ -1254,19 +1260,31 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
             return;
         }
         (void)hipMemcpy(st_host.data() + lo, bf.d_st[par], n * 4, hipMemcpyDeviceToHost);
-        int b = 0;
-        for (size_t s0 = 0; s0 < n; s0 += slice_sets, b = (b + 1) % kStage) {
-            const size_t m = std::min(slice_sets, n - s0);
-            pool.wait_zero(pending[par][b]);  // the writers are done with what this buffer held
-            if (hipMemcpyAsync(bf.stage[par][b], (const char*)bf.d_out[par] + s0 * row_b, m * row_b, hipMemcpyDeviceToHost, bf.copy[par]) != hipSuccess ||
-                hipStreamSynchronize(bf.copy[par]) != hipSuccess) {
-                std::lock_guard<std::mutex> l2(err_mu);
-                if (drain_err.empty()) drain_err = "device-to-host copy of the witness rows failed";
-                return;
-            }
-            pending[par][b].store((int)m, std::memory_order_release);
-            for (size_t i = 0; i < m; ++i)
-                pool.push(WriterPool::Task{(const uint8_t*)bf.stage[par][b] + i * row_b, first_index + lo + s0 + i, &pending[par][b]});
+        // the copy of slice i + 1 is enqueued before the host waits for slice i: the copy engine never idles between slices
+        const size_t n_slices = (n + slice_sets - 1) / slice_sets;
+        auto issue = [&](size_t i) -> bool {
+            const int bb = (int)(i % kStage);
+            const size_t s0 = i * slice_sets, m = std::min(slice_sets, n - s0);
+            pool.wait_zero(pending[par][bb]);  // the writers are done with what this buffer held
+            return hipMemcpyAsync(bf.stage[par][bb], (const char*)bf.d_out[par] + s0 * row_b, m * row_b, hipMemcpyDeviceToHost, bf.copy[par]) == hipSuccess &&
+                   hipEventRecord(slice_done[par][bb], bf.copy[par]) == hipSuccess;
+        };
+        bool okc = issue(0);
+        for (size_t i = 0; okc && i < n_slices; ++i) {
+            if (i + 1 < n_slices) okc = issue(i + 1);
+            const int bb = (int)(i % kStage);
+            const size_t s0 = i * slice_sets, m = std::min(slice_sets, n - s0);
+            okc = okc && hipEventSynchronize(slice_done[par][bb]) == hipSuccess;
+            if (!okc) break;
+            pending[par][bb].store((int)m, std::memory_order_release);
+            for (size_t q = 0; q < m; ++q)
+                pool.push(WriterPool::Task{(const uint8_t*)bf.stage[par][bb] + q * row_b, first_index + lo + s0 + q, &pending[par][bb]});
+        }
+        if (!okc) {
+            (void)hipStreamSynchronize(bf.copy[par]);
+            std::lock_guard<std::mutex> l2(err_mu);
+            if (drain_err.empty()) drain_err = "device-to-host copy of the witness rows failed";
+            return;
         }
         for (int q = 0; q < kStage; ++q) pool.wait_zero(pending[par][q]);
     };

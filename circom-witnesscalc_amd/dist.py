@@ -59,23 +59,29 @@ class RcclComm:
     carries its 128 bytes to the other ranks, every rank joins with ncclCommInitRank.  RCCL is the copy torch has already
     loaded (librccl.so in torch/lib), resolved through the process's global symbols."""
 
-    def __init__(self, device, src=0):
+    @staticmethod
+    def load_library():
+        """the RCCL copy torch itself uses first (by path: dlopen then returns that instance and makes its symbols global, which
+        is where gwb_graph_broadcast looks ncclBroadcast up), then the system's; None when there is none"""
+        import ctypes
+        import os
+        import torch
+        for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"):
+            try:
+                cand = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommCount", "ncclCommDestroy", "ncclBroadcast", "ncclGetErrorString"):
+                    getattr(cand, sym)
+                return cand
+            except (OSError, AttributeError):
+                continue
+        return None
+
+    def __init__(self, device, src=0, library=None):
         import ctypes
         import torch
         import torch.distributed as dist
         self._ct = ctypes
-        # the copy torch itself uses comes first (by path: dlopen then returns that instance and makes its symbols global, which
-        # is where gwb_graph_broadcast looks ncclBroadcast up), then the system's
-        import os
-        L = None
-        for name in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"):
-            try:
-                cand = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
-                cand.ncclGetUniqueId
-                L = cand
-                break
-            except (OSError, AttributeError):
-                continue
+        L = library or RcclComm.load_library()
         if L is None:
             raise RuntimeError("RCCL not found (librccl.so)")
         self.L = L
@@ -120,7 +126,14 @@ def broadcast_graph_rccl(pkg, graph_data, tile_width=0, src=0, device=None, batc
     rank = dist.get_rank()
     own = comm is None
     if own:
-        comm = RcclComm(device, src)
+        # every rank must take the same road: whether RCCL can be driven from here is agreed on first (a rank that could not
+        # would otherwise leave the others waiting in ncclCommInitRank); if not, torch.distributed carries the program
+        lib_ = RcclComm.load_library()
+        flag = torch.tensor([1 if lib_ is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return broadcast_graph(pkg, graph_data, tile_width, src=src, device=device, batch_per_rank=batch_per_rank), 0
+        comm = RcclComm(device, src, library=lib_)
     try:
         g = pkg.Graph(graph_data) if rank == src else None
         out, st = ctypes.c_void_p(), pkg.GwStatus()

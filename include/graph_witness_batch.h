@@ -92,7 +92,7 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
  * set, path_pattern with one %lu conversion for first_index + the set's position.  Sub-batches move through a pipeline: the
  * next one is parsed (host threads) and evaluated while the witness rows of the previous one leave HBM in slices through
  * pinned staging and writer threads frame them as files (lib.rs:114-123).  *n_sets = input sets found; set_status (NULL or
- * max_sets words) takes the per-set status words.  CWC_E2E_SUBBATCH (default 512), CWC_PARSE_THREADS (default all cores),
+ * max_sets words) takes the per-set status words.  CWC_E2E_SUBBATCH (default 1024), CWC_PARSE_THREADS (default all cores),
  * CWC_WRITE_THREADS (default min(cores, 32)) tune it. */
 typedef struct {
   size_t n_sets, sub_batch;

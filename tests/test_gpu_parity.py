@@ -612,6 +612,35 @@ def test_json_to_wtns_end_to_end_on_the_gpu(pkg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_load_time_optimiser_on_and_off_on_the_gpu(pkg, monkeypatch):
+    """SURVEY 8(f) f2 on the device: the fold-heavy graphs of the emulator test (constant operations over edge values incl.
+    the ones the reference panics on, identities, duplicated subexpressions, dead and dead-but-fallible code) evaluated by
+    the HIP path with the load-time optimiser (default) and without it (CWC_NO_LOAD_OPTIMIZE) -- both against the oracle
+    on the graph as written, status words included."""
+    from tests.test_host_formats import fold_heavy_builder
+    rnd = random.Random(12)
+    for variant in range(4):
+        data = fold_heavy_builder(variant, rnd).to_bin()
+        rows = cbind.ints_to_array([[1, 0, 0], [1, 5, 5], [1, M - 1, 3], [1, 1 << 200, 2], [1, 3, 200]] + [_rand_row(rnd, 3) for _ in range(45)])
+        want, wst = cbind.Graph(data).evaluate_batch(rows)
+        ok = wst == 0
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("CWC_NO_LOAD_OPTIMIZE", "1")
+            else:
+                monkeypatch.delenv("CWC_NO_LOAD_OPTIMIZE", raising=False)
+            g = pkg.Graph(data)
+            for key in (0, 1, 4, 64, 2 | DIVIDER):
+                g.set_tile_width(key)
+                got, st = g.calc_witness_batch(rows)
+                assert np.array_equal(st != 0, wst != 0), (variant, off, key)
+                assert np.array_equal(got[ok], want[ok]), (variant, off, key)
+        if variant == 0:
+            assert wst.all()  # (the constant operations that panic in the reference report on every row, folded or not)
+    monkeypatch.delenv("CWC_NO_LOAD_OPTIMIZE", raising=False)
+
+
+@pytest.mark.gpu
 def test_streaming_json_to_wtns_pipeline(pkg, tmp_path, monkeypatch):
     """The streaming end-to-end entry point (gwb_calc_witness_json_to_wtns): sub-batches parsed on host threads and evaluated
     while the previous one's witness rows leave HBM in slices and writer threads frame them as `.wtns` files.  Ragged sizes

@@ -490,46 +490,55 @@ def test_schedule_quality_guard(pkg):
     assert pe.Blob(g.export_blob(1)).n_bundles <= 5600
 
 
+def fold_heavy_builder(variant, rnd):
+    """A graph built to fold: every operator on CONSTANT operands over a grid of edge values (variant 0 keeps the ones the
+    reference panics on), same-operand forms, field identities, duplicated subexpressions, dead code (also fallible dead
+    code).  Shared by the emulator test below and the GPU on / off test of the load-time optimiser."""
+    from tools.graphgen.builder import Builder
+    M = model.M
+    edge = [0, 1, 2, 5, 253, 254, 255, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
+    duo = ["Mul", "Div", "Add", "Sub", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land", "Lor", "Shl", "Shr", "Bor", "Band", "Bxor"]
+    b = Builder(dedup_consts=(variant % 2 == 0))
+    x, y = b.input("x")[0], b.input("y")[0]
+    outs = []
+    pairs = [(rnd.choice(edge), rnd.choice(edge)) for _ in range(40)]
+    for op in duo:
+        for va, vb in pairs[:12 if variant else 40]:
+            if variant:  # variants 1..3: only constant operations the reference can evaluate (their VALUES are compared);
+                try:     # variant 0 keeps the ones that panic there: they must survive the pass and report on every row
+                    model.eval_duo(op, va, vb)
+                except model.ReferencePanic:
+                    continue
+            outs.append(b.op(op, b.const(va), b.const(vb)))
+        outs.append(b.op(op, x, x))                                     # same operand
+        outs.append(b.op(op, x, b.const(0)))
+        outs.append(b.op(op, b.const(0), x))
+        outs.append(b.op(op, x, b.const(1)))
+        outs.append(b.op(op, b.const(1), y))
+        outs.append(b.op(op, b.op(op, x, y), b.op(op, x, y)))         # duplicated subexpression
+        outs.append(b.op(op, b.op("Add", x, y), b.op("Add", y, x)))     # ... up to commutation
+    for v in edge[:6]:
+        outs.append(b.neg(b.const(v)))
+        outs.append(b.tern(b.const(v), x, y))
+        outs.append(b.tern(x, b.const(v), b.const(v)))
+    dead = b.mul(b.add(x, y), b.const(77))                              # unused: shaken
+    dead_fallible = b.op("Shl", x, y)                                   # unused but can fail: kept, still reports
+    assert dead and dead_fallible
+    for o in outs[::2] if variant == 3 else outs:
+        b.signal(o)
+    return b
+
+
 def test_load_time_optimiser_is_exact(pkg):
     """SURVEY 8(f) f2 (optimize.cc; the reference's build-time passes src/graph.rs:358-619 as exact load-time rewrites):
     every operator applied to CONSTANT operands over a grid of edge values -- folded with eval_fr semantics unless the
     reference would panic, in which case the node must survive and still report --, same-operand comparisons, the field
     identities, duplicated subexpressions and dead code.  The optimised program (emulated) against the big-int model on
     the graph as written, with and without the pass."""
-    from tools.graphgen.builder import Builder
     M = model.M
-    edge = [0, 1, 2, 5, 253, 254, 255, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
-    duo = ["Mul", "Div", "Add", "Sub", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land", "Lor", "Shl", "Shr", "Bor", "Band", "Bxor"]
     rnd = random.Random(12)
     for variant in range(4):
-        b = Builder(dedup_consts=(variant % 2 == 0))
-        x, y = b.input("x")[0], b.input("y")[0]
-        outs = []
-        pairs = [(rnd.choice(edge), rnd.choice(edge)) for _ in range(40)]
-        for op in duo:
-            for va, vb in pairs[:12 if variant else 40]:
-                if variant:  # variants 1..3: only constant operations the reference can evaluate (their VALUES are compared);
-                    try:     # variant 0 keeps the ones that panic there: they must survive the pass and report on every row
-                        model.eval_duo(op, va, vb)
-                    except model.ReferencePanic:
-                        continue
-                outs.append(b.op(op, b.const(va), b.const(vb)))
-            outs.append(b.op(op, x, x))                                     # same operand
-            outs.append(b.op(op, x, b.const(0)))
-            outs.append(b.op(op, b.const(0), x))
-            outs.append(b.op(op, x, b.const(1)))
-            outs.append(b.op(op, b.const(1), y))
-            outs.append(b.op(op, b.op(op, x, y), b.op(op, x, y)))         # duplicated subexpression
-            outs.append(b.op(op, b.op("Add", x, y), b.op("Add", y, x)))     # ... up to commutation
-        for v in edge[:6]:
-            outs.append(b.neg(b.const(v)))
-            outs.append(b.tern(b.const(v), x, y))
-            outs.append(b.tern(x, b.const(v), b.const(v)))
-        dead = b.mul(b.add(x, y), b.const(77))                              # unused: shaken
-        dead_fallible = b.op("Shl", x, y)                                   # unused but can fail: kept, still reports
-        assert dead and dead_fallible
-        for o in outs[::2] if variant == 3 else outs:
-            b.signal(o)
+        b = fold_heavy_builder(variant, rnd)
         data = b.to_bin()
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
         compared = 0

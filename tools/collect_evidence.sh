@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence of one code state on one MI355X box (run through gpurun from the repository root):
-#   gpurun --timeout 2400 -- 'bash tools/collect_evidence.sh r02'
-# then, back in the container:  python tools/profile_summary.py r02  and copy the logs named in profiles/README.md.
+#   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r03'
+# then, back in the container:  python tools/profile_summary.py r03  and  bash tools/copy_evidence.sh r03  (the logs named in profiles/README.md).
 # Each rocprofv3 pass is its own command with the program directly behind `--`; counter passes carry no trace domains.
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
@@ -22,17 +22,24 @@ python tools/gpu_sweep.py > $O/sweep_$R.log 2>&1
 python tools/gpu_autopick.py > $O/autopick_$R.log 2>&1
 python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
 (cd tools/ubench && ./coop_mul) > $O/coop_mul_$R.log 2>&1
+(cd tools/ubench && for v in r02 cxx sh32 blk; do echo "== inv_bench_$v"; timeout 120 ./inv_bench_$v; done) > $O/inv_bench_$R.log 2>&1
+python tools/gpu_e2e.py > $O/e2e_$R.log 2>&1
+CWC_FUSE=1001 SOAK_SEEDS=2000 SOAK_BASE=20261004 python tools/gpu_soak.py > $O/soak_fused_$R.log 2>&1
+CWC_FUSE=11 PROBE_B=256 PROBE_T=4353 python tools/gpu_classprof.py > $O/classprof_fused_$R.log 2>&1
 python bench.py --config 3 --cpu-sample 128 > $O/bench_config3_$R.json 2> $O/bench_config3_$R.err
 python bench.py --config 4 --cpu-sample 0 > $O/bench_config4_$R.json 2> $O/bench_config4_$R.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 1 --cpu-sample 0 \
     > $O/bench_dist1_$R.json 2> $O/bench_dist1_$R.err
 python tools/gpu_host_path.py > $O/hostpath_$R.log 2>&1
-python tools/gpu_single_shot.py > $O/single_shot_$R.log 2>&1
+rm -rf /tmp/cwc_cache_$R; CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 python tools/gpu_single_shot.py > $O/single_shot_$R.log 2>&1
+echo "---- second process, program cache warm" >> $O/single_shot_$R.log
+CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 SHOTS=6 python tools/gpu_single_shot.py >> $O/single_shot_$R.log 2>&1
 BIGINT_ROUNDS=4000 PROBE_T=0 python tools/gpu_bigint.py > $O/config5_$R.log 2>&1
 python bench.py --config 5 --cpu-sample 32 > $O/bench_config5_$R.json 2> $O/bench_config5_$R.err
 python tools/gpu_streams.py > $O/streams_$R.log 2>&1
 SOAK_SEEDS=20000 SOAK_BASE=20261003 python tools/gpu_soak.py > $O/soak_$R.log 2>&1
 bash tools/gpu_policies.sh "X=0 --" "CWC_NO_COOP_MUL=1 --" "CWC_COOP_FILL=32 CWC_COOP_SLACK=4000000000 --" "CWC_COOP_FILL=16 CWC_COOP_SLACK=2 --" \
     "CWC_SCHED_MUL_COST=47 CWC_SCHED_LIN_COST=12 --" "CWC_SCHED_MUL_COST=26 CWC_SCHED_LIN_COST=14 --" "CWC_SCHED_MUL_COST=30 CWC_SCHED_LIN_COST=24 --" \
-    "CWC_PACK_V1=1 --" "X=0 -- --batch-per-gpu 256" "CWC_NO_COOP_MUL=1 -- --batch-per-gpu 256" > $O/policies_$R.log 2>&1
+    "CWC_PACK=2 --" "CWC_PACK=2 -- --config 4" "X=0 -- --config 4" "CWC_WITNESS_SLOTS=1 -- --config 4" "X=0 -- --batch-per-gpu 256" "CWC_NO_COOP_MUL=1 -- --batch-per-gpu 256" \
+    "CWC_MODEL_CYCLES=3:73500 --" "CWC_NO_FUSE=1 -- --batch-per-gpu 256" > $O/policies_$R.log 2>&1
 ls $O
