@@ -253,10 +253,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_interp_s * 1e3,
                          "pack_kernel_avg_ms": float(np.mean(pack_ms)),
                          "binding_resource": "valu_issue",
-                         "lanes_active_mean": ps["lanes_active_mean"],
-                         "lanes_active_note": "of a wavefront's 64 lanes, the mean number that hold a node of the graph, weighted by the "
-                                              "modelled time of the bundles (program statistics): what a lone wave pays per bundle does not "
-                                              "depend on it, which is why compute.frac is what it is",
+                         "lanes_active_mean": ps["lanes_active_mean"], "values_per_bundle_mean": ps["values_per_bundle_mean"],
+                         "lanes_active_note": "of a wavefront's 64 lanes, the mean number that hold work of a node of the graph (the four "
+                                              "lanes that share a narrow bundle's product all count), and the mean number of field elements a "
+                                              "bundle produces (64 = one per lane); both weighted by the modelled time of the bundles (program "
+                                              "statistics).  What a lone wave pays per bundle does not depend on either, which is why "
+                                              "compute.frac is what it is",
                          "program": {"class_bundles": ps["class_bundles"], "class_nodes": ps["class_nodes"], "fused_nodes": ps["n_fused_nodes"],
                                      "model_wave_cycles": ps["model_wave_cycles"]},
                          "compute": {"unit": "modmul-equivalents/s", "achieved": eq_per_set * B / avg_interp_s,
@@ -360,13 +362,13 @@ def json_front_end_point(wl, g, n=4096):
 def e2e_json_to_wtns_point(wl, g, n=8192):
     """SURVEY 8(f) f3 end to end: NDJSON of n input objects -> `.wtns` files on a memory file system, through the streaming
     pipeline of gwb_calc_witness_json_to_wtns (parse threads | upload + kernels | device-to-host slices | writer threads).
-    The files of a round are deleted before the next one (n x 2.4 MB would not be polite to /dev/shm); 32 of them are
+    The files of a round are deleted before the next one (8192 x 2.4 MB at once would not be polite to /dev/shm); 32 of them are
     byte-compared with the oracle's `.wtns` first."""
     import shutil
     import tempfile
     from oracle import cbind
     from tools.synth import synth_inputs
-    per_round = 2048
+    per_round = 4096
     src = synth_inputs("field", g.n_inputs, per_round, SEED + 9)
     text = rows_to_ndjson(wl.inputs, src).encode()
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -381,7 +383,7 @@ def e2e_json_to_wtns_point(wl, g, n=8192):
             dt = time.perf_counter() - t0
             bad_status += int((st != 0).sum())
             if r == 0:
-                sample = [0, 1, 2, 3, 511, 512, 513, 1023, 1024, 1500, 2046, 2047] + list(range(700, 720))
+                sample = [0, 1, 2, 3, 511, 512, 513, 1023, 1024, 1500, 2046, 2047, 4095] + list(range(3000, 3019))
                 want, wst = og.evaluate_batch(src[sample])
                 for k, s_ in enumerate(sample):
                     got = open(pat % s_, "rb").read()

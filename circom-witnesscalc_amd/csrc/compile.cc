@@ -914,10 +914,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // ---- load-time re-optimiser (the statistics above describe the graph as loaded) ----
     if (!getenv("CWC_NO_LOAD_OPTIMIZE")) {
         OptimizeStats os;
+        if (const char* e = getenv("CWC_RANDOM_EVAL"))
+            if (atoi(e) != 0) random_eval_passes(g, &os);
         optimize_loaded_graph(g, &os);
         N = g.nodes.size();
-        st.n_folded = os.folded;
-        st.n_numbered = os.numbered + os.constants_merged;
+        st.n_folded = os.folded + os.random_constants;
+        st.n_numbered = os.numbered + os.constants_merged + os.random_numbered;
         st.n_shaken = os.shaken;
         phase("load-time optimiser");
     }

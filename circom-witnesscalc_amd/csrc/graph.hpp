@@ -54,8 +54,12 @@ std::vector<uint8_t> serialize_witnesscalc_graph(const Graph& g);
 // nodes and operations that can fail are kept).  Rewrites g in place; witness values are unchanged.
 struct OptimizeStats {
     uint64_t nodes_before = 0, nodes_after = 0, folded = 0, numbered = 0, constants_merged = 0, shaken = 0;
+    uint64_t random_constants = 0, random_numbered = 0;  // the probabilistic passes (random_eval_passes)
 };
 void optimize_loaded_graph(Graph& g, OptimizeStats* stats);
+// The reference's probabilistic build-time passes (src/graph.rs:499-583: random_eval, value_numbering, constants), opt-in
+// (CWC_RANDOM_EVAL=1): nodes of equal value under random evaluation are merged / folded; run in front of the exact passes.
+void random_eval_passes(Graph& g, OptimizeStats* stats);
 
 // lib.rs:138-152
 size_t get_inputs_size(const Graph& g);

@@ -1,7 +1,7 @@
 // Load-time re-optimiser of a loaded graph: the reference's build-time passes (src/graph.rs:358-619:
 // tree_shake, propagate, value_numbering, constants) restated as EXACT rewrites that a `.bin` from any producer goes
-// through before scheduling.  Nothing here is probabilistic (the reference's value_numbering / constants evaluate the
-// graph on random field elements, :499-600), and every witness value stays bit-identical:
+// through before scheduling.  The default passes are exact (the reference's value_numbering / constants evaluate the graph
+// on random field elements, :499-600: those are restated further down, opt-in), and every witness value stays bit-identical:
 //
 //   propagate        an operation whose operands are all constants becomes a constant, evaluated with the semantics of
 //                    Operation::eval_fr / UnoOperation::eval_fr / TresOperation::eval_fr (src/graph.rs:102-144, 188-197,
@@ -126,6 +126,99 @@ struct FrEq {
 
 }  // namespace
 
+// ---- the reference's PROBABILISTIC passes (src/graph.rs:499-583), opt-in (CWC_RANDOM_EVAL=1) -------------------------------
+// random_eval (:500-533): the graph evaluated on random field elements -- Add / Sub / Mul (and Neg) algebraically, every Input
+// and every other operation as a random function of its operand VALUES.  By Schwartz-Zippel two nodes with the same value
+// are the same polynomial in the inputs and the non-algebraic results (error probability ~ degree / r, below 2^-200 for any
+// graph that fits a file), which sees what structural value numbering cannot: (a + b) * c against a * c + b * c, sums in
+// another association, x - x.
+//   value_numbering (:536-562): every reference to a node goes to the FIRST node with its value.
+//   constants       (:565-583): a node with the same value under two independent evaluations is a constant.
+// A graph from the reference's own build-circuit has been through both; a third-party producer's has not.  Not exact in the
+// strict sense, hence not on by default: the exact passes below run either way and clean up behind these (duplicates, dead
+// nodes; operations that can fail are random functions here and therefore never folded, and tree shaking keeps them).
+// The random functions are keyed hashes (deterministic: every rank of a job compiles the same program).
+namespace {
+uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+Fr prf(uint64_t seed, uint64_t tag, const Fr* a, const Fr* b, const Fr* c) {
+    uint64_t h = mix64(seed ^ mix64(tag));
+    for (const Fr* x : {a, b, c}) {
+        if (!x) continue;
+        for (int i = 0; i < 8; i += 2) h = mix64(h ^ ((uint64_t)x->v[i] | ((uint64_t)x->v[i + 1] << 32)));
+        h = mix64(h + 0x51);
+    }
+    uint8_t bytes[32];
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t w = mix64(h + 0x1000193ull * (uint64_t)(k + 1));
+        memcpy(bytes + 8 * k, &w, 8);
+    }
+    return u256_from_le_bytes_mod_order(bytes, 32);  // a field element, read as a Montgomery residue
+}
+void random_eval(const Graph& g, uint64_t seed, std::vector<Fr>& val) {
+    const size_t N = g.nodes.size();
+    val.resize(N);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        switch (n.kind) {
+            case N_CONST: val[i] = fr_to_mont(g.const_values[n.a]); break;
+            case N_INPUT: val[i] = prf(seed, 0x100000000ull | n.a, nullptr, nullptr, nullptr); break;
+            case N_UNO:
+                if (n.op == UOP_NEG) val[i] = fr_neg(val[n.a]);
+                else val[i] = prf(seed, 0x200000000ull | n.op, &val[n.a], nullptr, nullptr);
+                break;
+            case N_DUO:
+                if (n.op == OP_ADD) val[i] = fr_add(val[n.a], val[n.b]);
+                else if (n.op == OP_SUB) val[i] = fr_sub(val[n.a], val[n.b]);
+                else if (n.op == OP_MUL) val[i] = fr_mul(val[n.a], val[n.b]);
+                else val[i] = prf(seed, 0x300000000ull | n.op, &val[n.a], &val[n.b], nullptr);
+                break;
+            default: val[i] = prf(seed, 0x400000000ull | n.op, &val[n.a], &val[n.b], &val[n.c]); break;
+        }
+    }
+}
+}  // namespace
+
+void random_eval_passes(Graph& g, OptimizeStats* stats) {
+    const size_t N = g.nodes.size();
+    std::vector<Fr> va, vb;
+    random_eval(g, 0x6a09e667f3bcc908ull, va);
+    random_eval(g, 0xbb67ae8584caa73bull, vb);
+    OptimizeStats st;
+    if (stats) st = *stats;
+    // constants (graph.rs:565-583)
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind == N_CONST || n.kind == N_INPUT) continue;
+        if (memcmp(va[i].v, vb[i].v, sizeof va[i].v) == 0) {
+            g.const_values.push_back(fr_from_mont(va[i]));
+            n = Node{N_CONST, 0, (uint32_t)(g.const_values.size() - 1), 0, 0};
+            st.random_constants++;
+        }
+    }
+    // value numbering (graph.rs:536-562): the first node of every value
+    std::unordered_map<Fr, uint32_t, FrHash, FrEq> first;
+    first.reserve(N);
+    std::vector<uint32_t> renumber(N);
+    for (size_t i = 0; i < N; ++i) {
+        auto it = first.emplace(va[i], (uint32_t)i);
+        renumber[i] = it.first->second;
+        st.random_numbered += !it.second && g.nodes[i].kind != N_CONST && g.nodes[i].kind != N_INPUT;
+    }
+    for (Node& n : g.nodes) {
+        const int ar = n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0;
+        if (ar >= 1) n.a = renumber[n.a];
+        if (ar >= 2) n.b = renumber[n.b];
+        if (ar >= 3) n.c = renumber[n.c];
+    }
+    for (uint32_t& w : g.witness_signals) w = renumber[w];
+    if (stats) *stats = st;
+}
+
 // Rewrites g in place (nodes, constants, witness references); the input map is untouched.  References must be backward
 // (validated by the caller).  Returns counts for the statistics line.
 void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
@@ -136,6 +229,10 @@ void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
     std::unordered_map<Fr, uint32_t, FrHash, FrEq> const_node;  // canonical value -> new constant node
     FlatMap128 vn(g.n_op ? g.n_op : N);
     OptimizeStats st;
+    if (stats) {  // (counters of the probabilistic passes that ran in front)
+        st.random_constants = stats->random_constants;
+        st.random_numbered = stats->random_numbered;
+    }
     st.nodes_before = N;
     auto make_const = [&](const Fr& v) -> uint32_t {
         auto it = const_node.find(v);

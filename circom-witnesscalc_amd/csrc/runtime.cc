@@ -1196,8 +1196,14 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
     }
     if (S > B) S = B;
     const size_t K = (B + S - 1) / S;
-    // slices of whole sets, ~24 MB each, three staging buffers per drain
-    size_t slice_sets = row_b ? std::max<size_t>(1, (24u << 20) / row_b) : 1;
+    // slices of whole sets, three staging buffers per drain.  CWC_E2E_SLICE_MB (default 96): a device-to-host copy costs
+    // ~0.2 ms before it moves anything, so 24 MB slices ran the link at 35 GB/s where one large copy reaches 57
+    size_t slice_mb = 96;
+    if (const char* e = getenv("CWC_E2E_SLICE_MB")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 1024) slice_mb = (size_t)v;
+    }
+    size_t slice_sets = row_b ? std::max<size_t>(1, (slice_mb << 20) / row_b) : 1;
     if (slice_sets > S) slice_sets = S;
     const int kStage = 3;
     gwb_graph::E2eBufs& bf = g->e2e;
@@ -1239,7 +1245,7 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
     Graph meta;
     meta.inputs = g->inputs;
     meta.input_index = g->input_index;
-    const unsigned n_parse = env_threads("CWC_PARSE_THREADS", 0), n_write = env_threads("CWC_WRITE_THREADS", 32);
+    const unsigned n_parse = env_threads("CWC_PARSE_THREADS", 0), n_write = env_threads("CWC_WRITE_THREADS", 16)  /* (more writers fight the copy engine for host memory bandwidth: 64 -> 9.4 k, 32 -> 13.9 k, 16 -> 15.5 k witnesses/s, r03_e2e_ab.txt) */;
     WriterPool pool;
     pool.start(n_write, path_pattern, NW);
     std::atomic<int> pending[2][3];
@@ -1529,7 +1535,7 @@ int gwb_program_stats(gwb_graph_t* g, uint32_t program_key, gwb_program_stats_t*
         out->streams = p->n_streams;
         out->n_bundles = p->n_bundles;
         out->n_classes = C_COUNT;
-        double wsum = 0, lsum = 0;
+        double wsum = 0, lsum = 0, vsum = 0;
         for (uint32_t c = 0; c < C_COUNT && c < 16; ++c) {
             out->class_bundles[c] = p->stats.class_bundles[c];
             out->class_nodes[c] = p->stats.class_nodes[c];
@@ -1537,9 +1543,11 @@ int gwb_program_stats(gwb_graph_t* g, uint32_t program_key, gwb_program_stats_t*
             const double lanes = (double)p->stats.class_nodes[c] * p->T * ((c == C_MULQ || c == C_MULF) ? (double)COOP_LANES : 1.0);
             wsum += cyc;
             lsum += p->stats.class_bundles[c] ? cyc * lanes / (double)p->stats.class_bundles[c] : 0.0;
+            vsum += p->stats.class_bundles[c] ? cyc * (double)p->stats.class_nodes[c] * p->T / (double)p->stats.class_bundles[c] : 0.0;
         }
         out->model_wave_cycles = program_wave_cycles(*p);
         out->lanes_active_mean = wsum > 0 ? lsum / wsum : 0.0;
+        out->values_per_bundle_mean = wsum > 0 ? vsum / wsum : 0.0;
         out->n_fused_nodes = p->stats.n_fused_nodes;
         return 0;
     } catch (...) {

@@ -93,7 +93,7 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
  * next one is parsed (host threads) and evaluated while the witness rows of the previous one leave HBM in slices through
  * pinned staging and writer threads frame them as files (lib.rs:114-123).  *n_sets = input sets found; set_status (NULL or
  * max_sets words) takes the per-set status words.  CWC_E2E_SUBBATCH (default 1024), CWC_PARSE_THREADS (default all cores),
- * CWC_WRITE_THREADS (default min(cores, 32)) tune it. */
+ * CWC_WRITE_THREADS (default min(cores, 16)), CWC_E2E_SLICE_MB (default 96) tune it. */
 typedef struct {
   size_t n_sets, sub_batch;
   uint32_t parse_threads, write_threads;
@@ -198,7 +198,8 @@ typedef struct {
   uint64_t class_bundles[16];   /* per bundle class (program_dev.h BundleClass) */
   uint64_t class_nodes[16];
   double model_wave_cycles;     /* the cost model's lone-wave cycles for one tile */
-  double lanes_active_mean;     /* of a wave's 64 lanes: mean number holding a node's work, weighted by the bundles' modelled time */
+  double lanes_active_mean;     /* of a wave's 64 lanes: mean number holding a node's work (the four lanes of a shared product all count), weighted by the bundles' modelled time */
+  double values_per_bundle_mean; /* field elements (node x input set) a bundle produces, same weighting: 64 would be one per lane */
 } gwb_program_stats_t;
 int gwb_program_stats(gwb_graph_t *g, uint32_t program_key, gwb_program_stats_t *out);
 

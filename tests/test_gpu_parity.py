@@ -624,11 +624,13 @@ def test_load_time_optimiser_on_and_off_on_the_gpu(pkg, monkeypatch):
         rows = cbind.ints_to_array([[1, 0, 0], [1, 5, 5], [1, M - 1, 3], [1, 1 << 200, 2], [1, 3, 200]] + [_rand_row(rnd, 3) for _ in range(45)])
         want, wst = cbind.Graph(data).evaluate_batch(rows)
         ok = wst == 0
-        for off in (False, True):
-            if off:
+        for off in (False, True, "random"):  # default passes / none / the reference's probabilistic passes in front of them
+            monkeypatch.delenv("CWC_NO_LOAD_OPTIMIZE", raising=False)
+            monkeypatch.delenv("CWC_RANDOM_EVAL", raising=False)
+            if off is True:
                 monkeypatch.setenv("CWC_NO_LOAD_OPTIMIZE", "1")
-            else:
-                monkeypatch.delenv("CWC_NO_LOAD_OPTIMIZE", raising=False)
+            elif off == "random":
+                monkeypatch.setenv("CWC_RANDOM_EVAL", "1")
             g = pkg.Graph(data)
             for key in (0, 1, 4, 64, 2 | DIVIDER):
                 g.set_tile_width(key)
@@ -638,6 +640,7 @@ def test_load_time_optimiser_on_and_off_on_the_gpu(pkg, monkeypatch):
         if variant == 0:
             assert wst.all()  # (the constant operations that panic in the reference report on every row, folded or not)
     monkeypatch.delenv("CWC_NO_LOAD_OPTIMIZE", raising=False)
+    monkeypatch.delenv("CWC_RANDOM_EVAL", raising=False)
 
 
 @pytest.mark.gpu

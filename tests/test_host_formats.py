@@ -7,6 +7,7 @@ import json
 import os
 import random
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -488,6 +489,77 @@ def test_schedule_quality_guard(pkg):
     assert bl.n_bundles <= 27500 and cb["DIV"] <= 275
     g = pkg.Graph(C.build_sha256(512).to_bin())
     assert pe.Blob(g.export_blob(1)).n_bundles <= 5600
+
+
+def test_reference_graph_check_tool(pkg):
+    """tools/check_reference_graph.py -- the one command a maintainer with cargo runs on a reference-built `.bin` (readers
+    agree, writer reproduces the bytes, witness equals the oracle's, `.wtns` equals the reference's) -- on the one pair
+    of reference-derived files this repository holds: the circuit1 fixture and its hand-derived 204-byte `.wtns`."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "check_reference_graph.py")
+    r = subprocess.run([sys.executable, tool, os.path.join(GOLD, "circuit1.bin"), os.path.join(GOLD, "circuit1_inputs.json"), os.path.join(GOLD, "circuit1.wtns")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("True") == 4, r.stdout + r.stderr
+    other = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cwc_check_tool_inputs_%d.json" % os.getpid())  # other inputs: the witness differs from the fixture's
+    with open(other, "w") as f:
+        f.write('{"a": ["106"], "b": ["303"]}')
+    try:
+        r = subprocess.run([sys.executable, tool, os.path.join(GOLD, "circuit1.bin"), other, os.path.join(GOLD, "circuit1.wtns")], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(other)
+    assert r.returncode != 0 and r.stdout.count("True") == 3, r.stdout
+
+
+def test_probabilistic_passes_of_the_reference(pkg, monkeypatch):
+    """SURVEY 8(f) f2, second half: the reference's random-evaluation passes (src/graph.rs:499-583 random_eval /
+    value_numbering / constants) as an opt-in load-time pass (CWC_RANDOM_EVAL=1).  Algebraically equal nodes of different
+    shape -- (a + b) * c and a * c + b * c, sums in another association, x - x, equal-valued operands of a non-algebraic
+    operation -- become one node / a constant; witnesses stay those of the reference on fuzzed graphs, panicking rows
+    included (operations that can fail are random functions in the evaluation: never folded, never dropped)."""
+    from tools.graphgen.builder import Builder
+    b = Builder()
+    a, bb, c = b.input("a")[0], b.input("b")[0], b.input("c")[0]
+    e1 = b.mul(b.add(a, bb), c)
+    e2 = b.add(b.mul(a, c), b.mul(bb, c))
+    e3 = b.sub(b.add(a, b.add(bb, c)), b.add(b.add(c, a), bb))
+    e4, e5 = b.op("Shr", e1, b.const(3)), b.op("Shr", e2, b.const(3))
+    e6 = b.op("Shl", a, bb)  # can fail: stays, reports
+    for x in (e1, e2, e3, e4, e5, e6):
+        b.signal(x)
+    data = b.to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    counts = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CWC_RANDOM_EVAL", mode)
+        blob = pe.Blob(pkg.Graph(data).export_blob(1))
+        counts[mode] = blob.stats["n_op_compiled"]
+        for row in ([1, 12345, 7, 777], [1, 0, 0, 0], [1, model.M - 1, 5, 2]):
+            got, st = pe.run(blob, row)
+            try:
+                want = model.evaluate(nodes, row, wit)
+            except model.ReferencePanic:
+                assert st != 0
+                continue
+            assert st == 0 and got == want
+    assert counts["1"] <= 5 < 12 <= counts["0"], counts  # (a + b) * c, one Shr, the Shl and little else
+    monkeypatch.setenv("CWC_RANDOM_EVAL", "1")
+    rnd = random.Random(21)
+    for s_ in range(10):
+        bld = C.build_random_dag(100 + s_, n_ops=260, panic_free=(s_ % 2 == 0), parts=1 + s_ % 3) if s_ < 7 else C.build_chain_heavy(s_, n_chains=14)
+        data = bld.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        g = pkg.Graph(data)
+        for key in (1, 4, 2 | DIVIDER):
+            blob = pe.Blob(g.export_blob(key))
+            for _ in range(2):
+                row = [1] + [rnd.randrange(model.M) if rnd.random() < 0.6 else rnd.randrange(1 << 10) for _ in range(blob.n_inputs - 1)]
+                got, st = pe.run(blob, row)
+                try:
+                    want = model.evaluate(nodes, row, wit)
+                except model.ReferencePanic:
+                    assert st != 0
+                    continue
+                assert st == 0 and got == want, (s_, key)
 
 
 def fold_heavy_builder(variant, rnd):
