@@ -160,7 +160,9 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 17
 // what a narrow bundle and a linear bundle cost (1 306 : 706 cycles in the product kernel = 26 : 14; measured best of
 // 26..40 : 14..24 on the authV2-class graph: 1024 sets 13.27 -> 12.19 ms, 256 sets 12.27 -> 10.52 ms; wider tiles, whose
 // multiplication bundles stay full-width, keep the table above: 8192 sets 32.6 ms with either, 33.4 ms with this one).
-static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 16, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 16, 46};
+// (round 3, same-box A/B of 30 : {16, 20, 24, 30} and neighbours: 30 : 24 is 1 % ahead at 1024 sets -- 80.1-80.2 k against 79.3-79.5 k
+// witnesses/s -- and level at 256 / 512 sets, profiles/r03_weights_ab.txt)
+static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 24, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 24, 46};
 static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 47, 46};
 // What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured

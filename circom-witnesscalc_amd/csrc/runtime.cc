@@ -170,6 +170,7 @@ struct gwb_graph {
     std::map<size_t, std::future<Refined>> refining;  // by batch size
     std::map<size_t, uint32_t> provisional;            // batch size -> the quick program's key while the task runs
     bool cache_written = false;                        // single-shot entry point: the refined program went to the on-disk cache
+    std::string cache_path;                            // ... to this file (empty: no cache, or the handle came out of it)
     // buffers of the streaming end-to-end entry point (gwb_calc_witness_json_to_wtns), kept between calls: pinned input rows,
     // device rows in / out / status (double-buffered), pinned staging of the witness copy, streams and events
     struct E2eBufs {
@@ -1816,9 +1817,8 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         for (auto& e : g_cache)
             if (e.hash == h && e.bytes.size() == graph_data_len && memcmp(e.bytes.data(), graph_data, graph_data_len) == 0) g = e.g;
     }
-    std::string cache_file;  // non-empty: this call computed a program worth writing to the on-disk cache
     if (!g) {
-        const std::string cf = program_cache_file(graph_data, graph_data_len);
+        const std::string cf = program_cache_file(graph_data, graph_data_len);  // (SHA-256 of the image: once per graph and process)
         std::vector<uint8_t> blob;
         if (!cf.empty() && read_file(cf, blob) && check_device().empty()) {  // a program an earlier process compiled for this very image
             gwb_graph_t* imported = nullptr;
@@ -1831,7 +1831,7 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
             gwb_graph* raw = nullptr;
             if (load_graph(graph_data, graph_data_len, &raw, err)) return fail(status, "Failed to calculate witness: " + err);
             g.reset(raw);
-            cache_file = cf;
+            g->cache_path = cf;  // where the refined program goes once the background search has finished
         }
         std::lock_guard<std::mutex> lk(g_cache_mu);
         if (g_cache.size() >= 4) g_cache.erase(g_cache.begin());
@@ -1856,10 +1856,15 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         if (err.empty()) err = run_host(g.get(), row.data(), 1, wit.data(), &st);
     }
     if (!err.empty()) return fail(status, "Failed to calculate witness: " + err);
+    if (getenv("CWC_DEBUG_SINGLE")) {  // diagnostic: kernel times of this call
+        gwb_timing_t tm;
+        if (gwb_last_timing(g.get(), &tm) == 0)
+            fprintf(stderr, "gw_calc_witness: program key %#x, %llu bundles, interpreter %.2f ms, pack %.2f ms\n", g->last_key, (unsigned long long)tm.n_bundles, tm.interp_ms, tm.pack_ms);
+    }
     // The program for the on-disk cache: the one the background search settled on (the quick first program is not worth
     // keeping).  Written by whichever call first finds the search finished.
-    if (!cache_file.empty() || (g->has_graph && !g->cache_written)) {
-        const std::string cf = !cache_file.empty() ? cache_file : program_cache_file(graph_data, graph_data_len);
+    if (g->has_graph && !g->cache_written && !g->cache_path.empty()) {
+        const std::string& cf = g->cache_path;
         uint32_t key = 0;
         {
             std::lock_guard<std::mutex> lk(g->mu);
@@ -1876,8 +1881,6 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
             }
             gwb_free_status(&st2);
             free(blob);
-            g->cache_written = true;
-        } else if (cf.empty()) {
             g->cache_written = true;
         }
     }
