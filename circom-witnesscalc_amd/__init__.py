@@ -41,7 +41,7 @@ class ProgramStats(ctypes.Structure):
                 ("values_per_bundle_mean", ctypes.c_double)]
 
 
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "MACRO"]
 
 
 class E2eStats(ctypes.Structure):
@@ -391,7 +391,7 @@ class Graph:
     def profile_classes(self, d_inputs, d_witness, d_status):
         """Diagnostic stamped build: {class: (cycles, 0, 0, bundles)} over sampled waves, plus "_sections":
         {"MUL" / "LIN": (top + staged-operand wait, LDS reads + previous bundle's stores, staging issue, arithmetic, ring write, bundles)}."""
-        out = np.zeros(72, dtype=np.uint64)
+        out = np.zeros(96, dtype=np.uint64)
         st = GwStatus()
         rc = lib().gwb_profile_classes(self._h, d_inputs.data_ptr(), d_inputs.shape[0], d_witness.data_ptr(),
                                        d_status.data_ptr(), out.ctypes.data, ctypes.byref(st))
@@ -399,6 +399,8 @@ class Graph:
         names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
         res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
         res["MULF"] = tuple(int(x) for x in out[64:68])
+        res["MACRO"] = tuple(int(x) for x in out[68:72])
+        res["_macro_sections"] = tuple(int(x) for x in out[72:80])
         res["_sections"] = {"MUL": tuple(int(x) for x in out[48:54]), "LIN": tuple(int(x) for x in out[56:62])}
         n = int(out[63])
         res["_waves"] = {"n": n, "max_cycles": int(out[54]), "min_cycles": (1 << 40) - int(out[55]) if n else 0,

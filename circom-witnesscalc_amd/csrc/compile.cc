@@ -151,7 +151,7 @@ static void fuse_bit_extract(Graph& g) {
 
 // Relative cost of one bundle of each class (measured on gfx950 for a lone wavefront, shader cycles / 50): the unit
 // of the scheduler's critical-path heights and of the tree-height reduction below.
-static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 14, 46};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
+static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 14, 46, 80};  // (LIN: 12 measured best of 6..26 on the authV2-class graph)
 // The same for graphs whose linear nodes outnumber their multiplications (sha256-like: wide, LIN bundles are half of
 // the time): a heavier Add / Sub makes the tree-height reduction rebalance sum chains harder and puts linear chains
 // first in the schedule -- sha256_512 at 4096 sets 10.6 -> 9.2 ms; the authV2-class graph (multiplier chains with
@@ -162,12 +162,12 @@ static const uint32_t kClassCost[C_COUNT] = {100, 47, 12, 1470, 25, 100, 110, 17
 // multiplication bundles stay full-width, keep the table above: 8192 sets 32.6 ms with either, 33.4 ms with this one).
 // (round 3, same-box A/B of 30 : {16, 20, 24, 30} and neighbours: 30 : 24 is 1 % ahead at 1024 sets -- 80.1-80.2 k against 79.3-79.5 k
 // witnesses/s -- and level at 256 / 512 sets, profiles/r03_weights_ab.txt)
-static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 24, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 24, 46};
-static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 47, 46};
+static const uint32_t kClassCostNarrow[C_COUNT] = {100, 30, 24, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 24, 46, 80};
+static const uint32_t kClassCostLinHeavy[C_COUNT] = {100, 47, 47, 1470, 25, 100, 110, 175, 38, 22, 22, 26, 47, 46, 80};
 // What the scheduler's virtual clock advances per bundle (it decides when a division's collect bundle is due; too fast
 // a clock collects before the divider wave has answered and the interpreter waits): shader cycles / 50 as measured
 // at the end of round 1 (MUL 2 100, LIN 670, request / collect 1 300).
-static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24, 14, 44};
+static const uint32_t kClockCost[C_COUNT] = {100, 42, 14, 1470, 25, 100, 110, 175, 38, 26, 26, 24, 14, 44, 80};
 // The inversion entries of the three tables follow the cycle table (model_class_cycles(C_DIV) / 50): one number to change
 // when the inversion gets faster, and what CWC_MODEL_CYCLES overrides.
 static uint32_t div_cost50();
@@ -647,7 +647,15 @@ static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<
 // Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
 // profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
-static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400};
+static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400, 5660};
+// a macro bundle (C_MACRO) is priced as its front end plus its stages; the table entry is four mixed stages, a bundle
+// books what its stages cost less (form_cycles_saved).  Measured (profiles/r03_classprof_macro.txt, stamps taken off):
+// front end 660, a stage 1 070 on average over the authV2-class graph's bundles plus 190 where it re-reads operands of
+// earlier stages (two of three stages do) -- a stage's own decoding (kind, accumulator selects, gather, ring / slot
+// addresses: ~60 instructions at a lone wave's ~5 cycles each) and the LDS round trip of operands from other lane groups
+// cost what the pipelined loop spends per narrow bundle (1 306), so the merged bundles ran 1-6 % slower than the separate
+// ones (profiles/r03_macro_ab.txt) and the class is opt-in (CWC_MACRO=1), kept with its tests as a measured dead end.
+static const double kCyclesMacroFront = 660, kCyclesMacroStage[4] = {0, 1150, 1250, 600} /* by MacroStageKind */, kCyclesMacroLate = 190, kCyclesMacroGather = 80;
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves
 static const double kCyclesFusedStageMul = 760, kCyclesFusedStageLin = 300;
@@ -708,6 +716,7 @@ struct CoopPolicy {
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
     bool all_montgomery = false;  // no representation inference: every value in Montgomery form
     bool witness_slots = false;   // the slots of witness elements in witness order (see the slot allocation)
+    bool macro = false;           // consecutive narrow bundles of the schedule are merged into macro bundles (class C_MACRO) where the cycle table says it pays
     uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused; + 0x10000: product + sum nodes only
 };
 // The rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) depends on the fusion switch and on
@@ -740,6 +749,8 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
     if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
     if (const char* e = getenv("CWC_WITNESS_SLOTS")) base.witness_slots = atoi(e) != 0;
+    // macro bundles (merge_macros): opt-in, CWC_MACRO=1 (measured slower than the separate narrow bundles, see kCyclesMacroFront)
+    if (getenv("CWC_MACRO") && atoi(getenv("CWC_MACRO")) != 0) base.macro = true;
     RewriteCache cache;
     if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) return false;
     if (quick || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;  // (quick: the first call on a graph runs this one schedule while the search runs in the background)
@@ -771,6 +782,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     for (CoopPolicy pol : more) {
         pol.all_montgomery = base.all_montgomery;
         pol.witness_slots = base.witness_slots;
+        pol.macro = base.macro;
         Program alt;
         std::string err2;
         if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
@@ -781,7 +793,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     // Fused narrow chains (fuse_narrow_chains): how far from the critical path a chain is still fused is a policy too --
     // only the critical chain, chains within a few percent of it, every chain -- and the cost model picks
     // (CWC_FUSE=<thousandths + 1> forces one, CWC_NO_FUSE=1 none).
-    if (T <= COOP_FUSE_MAX_T && kept.fill && !getenv("CWC_NO_FUSE")) {
+    if (T <= COOP_FUSE_MAX_T && kept.fill && !kept.macro && !getenv("CWC_NO_FUSE")) {  // (a program has fused bundles or macro bundles)
         std::vector<uint32_t> tries = {1, 11, 101, 1001, 0x10001, 0x1000b, 0x10065, 0x103e9};
         if (const char* e = getenv("CWC_FUSE")) tries.assign(1, (uint32_t)atoi(e));
         for (uint32_t f : tries) {
@@ -1025,7 +1037,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint32_t> use_bundle_of(N, 0xffffffffu);  // bundle that reads the node's operands (differs for a
                                                           // division handed to the divider wave: request vs. collect)
     std::vector<uint32_t> bundle_start;  // index into order
-    std::vector<uint8_t> bundle_coop;    // the bundle is a narrow multiplication bundle (C_MULQ: four lanes per product)
+    std::vector<uint8_t> bundle_coop;    // 1: narrow multiplication bundle (C_MULQ: four lanes per product), 2: fused narrow bundle, 3: macro bundle
+    std::vector<uint32_t> order_pos;     // record position of every entry of `order` inside its bundle
     std::vector<uint32_t> bundle_flags;  // HDR_POST / HDR_WAIT (programs of several streams)
     static const uint32_t REQ_FLAG = 0x80000000u;         // order[] entry: the request half of a division
     // Streams: the graph's independent parts (components that share nothing but Input nodes and constants) can be
@@ -1044,6 +1057,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 bundle_coop.push_back(0);
                 bundle_flags.push_back(0);
                 order.push_back((uint32_t)i);
+                order_pos.push_back(0);
             }
         s_count[0] = (uint32_t)bundle_start.size();
     } else {
@@ -1126,7 +1140,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         // One stream's bundle sequence (bundle indices relative to the stream's first bundle).
         struct StreamSched {
             std::vector<uint32_t> order, bundle_start, div_lanes;
-            std::vector<uint8_t> bundle_coop;
+            std::vector<uint32_t> order_pos;     // record position of every entry of `order` inside its bundle (merge_macros)
+            std::vector<uint8_t> bundle_coop;    // 0 full-width, 1 narrow multiplication bundle, 2 fused narrow bundle, 3 macro bundle
             std::vector<uint32_t> bundle_flags;  // HDR_POST / HDR_WAIT: the bundle is a C_SYNC bundle
             uint64_t class_bundles[C_COUNT] = {0};
             uint32_t n_div_requests = 0;
@@ -1335,6 +1350,144 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             return true;
         };
 
+
+        // ---- macro bundles: runs of consecutive narrow bundles become the stages of one bundle (program_dev.h C_MACRO) ----
+        // A post-pass over a stream's schedule (the list scheduler above decides what runs when): up to MACRO_STAGES
+        // consecutive bundles that are narrow -- a multiplication bundle or a linear bundle of at most coop_nodes(T) nodes --
+        // merge (opt-in, CWC_MACRO).  Stage k of lane group g is record position 4g + k; a node goes to the group whose accumulator
+        // holds one of its operands where it can.
+        auto merge_macros = [&](uint32_t s, StreamSched& ss) {
+            const uint32_t nb = (uint32_t)ss.bundle_start.size();
+            const uint32_t cap = coop_nodes(T);
+            auto b_end = [&](uint32_t b) { return b + 1 < nb ? ss.bundle_start[b + 1] : (uint32_t)ss.order.size(); };
+            ss.order_pos.resize(ss.order.size());
+            for (uint32_t b = 0; b < nb; ++b)
+                for (uint32_t k = ss.bundle_start[b]; k < b_end(b); ++k) ss.order_pos[k] = k - ss.bundle_start[b];
+            if (!policy.macro || cap == 0 || T > COOP_FUSE_MAX_T) return;
+            // (with the measured stage cycles no run of the bench graphs is cheaper merged: the opt-in merges every run it can,
+            // CWC_MACRO=2 only where the cycle table says it pays)
+            const bool macro_always = !(getenv("CWC_MACRO") && atoi(getenv("CWC_MACRO")) == 2);
+            auto stage_kind = [&](uint32_t b) -> uint32_t {
+                const uint32_t k0 = ss.bundle_start[b], k1 = b_end(b);
+                if (ss.bundle_flags[b] || k1 == k0 || k1 - k0 > cap || ss.bundle_coop[b] > 1) return MSK_NONE;
+                bool mul = false, lin = false;
+                for (uint32_t k = k0; k < k1; ++k) {
+                    if (ss.order[k] & REQ_FLAG) return MSK_NONE;
+                    const int c = class_of(g.nodes[ss.order[k]]);
+                    if (c == C_MUL) mul = true;
+                    else if (c == C_LIN) lin = true;
+                    else return MSK_NONE;
+                }
+                return mul ? (lin ? MSK_MIXED : MSK_MUL) : MSK_LIN;
+            };
+            auto separate_cycles = [&](uint32_t b, uint32_t kind) {
+                return kind == MSK_LIN ? kCycles[C_LIN] : ss.bundle_coop[b] ? kCycles[C_MULQ] + (kind == MSK_MIXED ? kCyclesCoopRiders : 0.0) : kCycles[C_MUL];
+            };
+            std::vector<uint32_t> order2, pos2, start2, flags2, remap(nb, 0);
+            std::vector<uint8_t> coop2;
+            order2.reserve(ss.order.size());
+            pos2.reserve(ss.order.size());
+            std::vector<uint32_t> latest(cap), grp;
+            std::vector<uint8_t> used(cap);
+            std::vector<uint32_t> run_pos;  // positions of the run's nodes, stage after stage
+            for (uint32_t b = 0; b < nb;) {
+                uint32_t len = 0;
+                double best_saving = 0;
+                if (stage_kind(b) != MSK_NONE) {
+                    // positions stage by stage; the cheapest prefix of the run wins
+                    std::fill(latest.begin(), latest.end(), 0xffffffffu);
+                    run_pos.clear();
+                    double separate = 0, merged = kCyclesMacroFront;
+                    for (uint32_t k = 0; k < MACRO_STAGES && b + k < nb; ++k) {
+                        const uint32_t kind = stage_kind(b + k);
+                        if (kind == MSK_NONE) break;
+                        const uint32_t k0 = ss.bundle_start[b + k], n = b_end(b + k) - k0;
+                        grp.assign(n, 0xffffffffu);
+                        std::fill(used.begin(), used.end(), 0);
+                        for (uint32_t x = 0; x < n; ++x) {  // first the nodes that continue a group's chain
+                            const Node& nd = g.nodes[ss.order[k0 + x]];
+                            const uint32_t ops[2] = {nd.a, nd.kind == N_UNO ? nd.a : nd.b};
+                            for (uint32_t q = 0; q < cap && grp[x] == 0xffffffffu; ++q)
+                                if (!used[q] && latest[q] != 0xffffffffu && (latest[q] == ops[0] || latest[q] == ops[1])) {
+                                    grp[x] = q;
+                                    used[q] = 1;
+                                }
+                        }
+                        bool late = false, gather = false;
+                        for (uint32_t x = 0, q = 0; x < n; ++x) {
+                            if (grp[x] == 0xffffffffu) {
+                                while (used[q]) ++q;
+                                grp[x] = q;
+                                used[q] = 1;
+                            }
+                            const uint32_t i = ss.order[k0 + x];
+                            const Node& nd = g.nodes[i];
+                            const uint32_t ops[2] = {nd.a, nd.kind == N_UNO ? nd.a : nd.b};
+                            for (int o = 0; o < (nd.kind == N_UNO ? 1 : 2); ++o) {
+                                const uint32_t pr = ops[o];
+                                const bool same = g.nodes[pr].kind != N_CONST && stream_of[pr] == s && bundle_of[pr] >= b && bundle_of[pr] < b + k;  // an earlier stage of this run
+                                if (same && latest[grp[x]] != pr) late = true;
+                            }
+                            if (class_of(nd) == C_MUL && nd.a == nd.b && latest[grp[x]] == nd.a) gather = true;
+                        }
+                        for (uint32_t x = 0; x < n; ++x) {
+                            latest[grp[x]] = ss.order[k0 + x];
+                            run_pos.push_back(grp[x] * MACRO_STAGES + k);
+                        }
+                        separate += separate_cycles(b + k, kind);
+                        merged += kCyclesMacroStage[kind] + (late ? kCyclesMacroLate : 0.0) + (gather ? kCyclesMacroGather : 0.0);
+                        if (k >= 1 && (macro_always || separate - merged > best_saving)) {
+                            best_saving = separate - merged;
+                            len = k + 1;
+                        }
+                    }
+                }
+                const uint32_t nbnew = (uint32_t)start2.size();
+                if (len >= 2) {
+                    start2.push_back((uint32_t)order2.size());
+                    coop2.push_back(3);
+                    flags2.push_back(0);
+                    size_t rp = 0;
+                    for (uint32_t k = 0; k < len; ++k) {
+                        remap[b + k] = nbnew;
+                        for (uint32_t e = ss.bundle_start[b + k]; e < b_end(b + k); ++e) {
+                            order2.push_back(ss.order[e]);
+                            pos2.push_back(run_pos[rp++]);
+                        }
+                        const uint32_t kind = stage_kind(b + k);
+                        ss.class_bundles[kind == MSK_LIN ? (int)C_LIN : ss.bundle_coop[b + k] ? (int)C_MULQ : (int)C_MUL]--;
+                    }
+                    ss.class_bundles[C_MACRO]++;
+                    b += len;
+                } else {
+                    remap[b] = nbnew;
+                    start2.push_back((uint32_t)order2.size());
+                    coop2.push_back(ss.bundle_coop[b]);
+                    flags2.push_back(ss.bundle_flags[b]);
+                    for (uint32_t e = ss.bundle_start[b]; e < b_end(b); ++e) {
+                        order2.push_back(ss.order[e]);
+                        pos2.push_back(ss.order_pos[e]);
+                    }
+                    ++b;
+                }
+            }
+            // bundle indices of the stream's nodes (relative to the stream's first bundle, like the scheduler wrote them)
+            for (uint32_t e : ss.order) {
+                const uint32_t i = e & ~REQ_FLAG;
+                if (e & REQ_FLAG) {
+                    use_bundle_of[i] = remap[use_bundle_of[i]];
+                } else {
+                    bundle_of[i] = remap[bundle_of[i]];
+                    if (!(divider && class_of(g.nodes[i]) == C_DIV)) use_bundle_of[i] = remap[use_bundle_of[i]];
+                }
+            }
+            ss.order.swap(order2);
+            ss.order_pos.swap(pos2);
+            ss.bundle_start.swap(start2);
+            ss.bundle_coop.swap(coop2);
+            ss.bundle_flags.swap(flags2);
+        };
+
         // ---- partition into streams ----
         if (streams > 1 && (divider == 0 || divider == 1)) {
             // components of the operation nodes (edges through Input nodes and constants do not connect)
@@ -1444,6 +1597,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 continue;
             }
             if (!schedule_stream(s, stream_of, ss, true, P > 1)) return false;
+            merge_macros(s, ss);
             const uint32_t nb = (uint32_t)ss.bundle_start.size();
             const uint32_t base = (uint32_t)bundle_start.size();
             s_first[s] = base;
@@ -1465,6 +1619,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 }
             }
             order.insert(order.end(), ss.order.begin(), ss.order.end());
+            order_pos.insert(order_pos.end(), ss.order_pos.begin(), ss.order_pos.end());
             out.div_lanes.insert(out.div_lanes.end(), ss.div_lanes.begin(), ss.div_lanes.end());
             out.n_div_requests += ss.n_div_requests;
             while (s + 1 < P && bundle_start.size() % 4 != 0) {  // idle bundles up to the next stream's first one (never executed)
@@ -1493,13 +1648,17 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     static_assert(RING_BUNDLES >= OPND_AHEAD, "values younger than the staging distance must come from the ring");
     std::vector<uint32_t> pos_in_bundle(N, 0);
     for (uint32_t b = 0; b < NB; ++b)
-        for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k] & ~REQ_FLAG] = k - bundle_start[b];
+        for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k] & ~REQ_FLAG] = order_pos[k];
     enum { SRC_MEM = 0, SRC_RING = 1 };
     auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
         if ((q >= 2 && g.nodes[consumer].kind != N_FUSED) || g.nodes[producer].kind == N_CONST) return SRC_MEM;  // (TernCond reads its third operand in place)
         if (stream_of[producer] != stream_of[consumer]) return SRC_MEM;  // (another wave's ring)
         const uint32_t d = use_bundle_of[consumer] - bundle_of[producer];
-        return (d >= 1 && d <= RING_BUNDLES) ? SRC_RING : SRC_MEM;
+        if (d == 0) return SRC_RING;  // an earlier stage of the consumer's macro bundle (nothing else reads inside its own bundle)
+        // (a macro bundle writes its ring slot stage by stage: what it reads from the slot it is about to overwrite would have to be
+        // told from its own stages' results -- it reads the three younger slots only)
+        const uint32_t reach = bundle_coop[use_bundle_of[consumer]] == 3 ? RING_BUNDLES - 1 : RING_BUNDLES;
+        return (d >= 1 && d <= reach) ? SRC_RING : SRC_MEM;
     };
     std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
     std::vector<uint8_t> needs_slot(N, 0);
@@ -1573,9 +1732,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
         const bool idle = cnt == 0;  // (programs of several streams: padding around the posts and waits; an Add of zeros into the trash slot)
         const bool request = !idle && (order[k0] & REQ_FLAG) != 0, collect = !idle && is_collect(order[k0]);
-        const bool coop = bundle_coop[b] != 0, fusedb = bundle_coop[b] == 2;
+        const bool coop = bundle_coop[b] == 1 || bundle_coop[b] == 2, fusedb = bundle_coop[b] == 2, macrob = bundle_coop[b] == 3;
         const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ / C_MULF node's records take COOP_LANES positions (4j .. 4j+3)
-        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : fusedb ? (int)C_MULF : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
+        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : macrob ? (int)C_MACRO : fusedb ? (int)C_MULF : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
+        // macro bundles: the node in each lane group's accumulator so far, and what the stages hold (header bits)
+        uint32_t m_latest[16], m_mul = 0, m_lin = 0, m_late = 0, m_gather = 0;
+        for (uint32_t& x : m_latest) x = 0xffffffffu;
         uint32_t stream = 0;
         while (stream + 1 < P && b >= s_first[stream + 1]) ++stream;
         if (b == s_first[stream]) free_slots.clear();  // a slot is reused inside the stream that freed it only (the others run at their own pace)
@@ -1607,7 +1769,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k] & ~REQ_FLAG;
             const Node& n = g.nodes[i];
-            const uint32_t js = k - k0;  // node slot
+            const uint32_t js = order_pos[k];  // node slot (record position)
             uint32_t slot = 0xffffffffu;
             if (needs_slot[i] && !request) {
                 if (policy.witness_slots && witness_rank[i] != 0xffffffffu) {
@@ -1663,6 +1825,40 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     if (needs_slot[fops[q]] == 1 && last_mem_use[fops[q]] == b) dying.push_back(fops[q]);
                 continue;
             }
+            if (macrob) {
+                const uint32_t grp = js / MACRO_STAGES, stg = js % MACRO_STAGES, acc = m_latest[grp];
+                const bool mul = class_of(n) == C_MUL;
+                uint32_t mc = MCTRL_ACTIVE;
+                // operand `producer` into position `w` (0: a, 1: b); q names the node's operand for the constant form
+                auto macro_operand = [&](uint32_t producer, int q, int w) {
+                    enc_to(producer, q, off[w], lds[w]);
+                    if (g.nodes[producer].kind == N_CONST || stream_of[producer] != stream_of[i] || bundle_of[producer] != b) return;
+                    if (producer == acc) mc |= w ? MCTRL_B_ACC : MCTRL_A_ACC;
+                    else m_late |= 1u << stg;
+                };
+                if (n.kind == N_UNO) {  // Neg(a) = 0 - a
+                    mc |= SUB_SUB;
+                    macro_operand(n.a, 1, 1);
+                } else if (mul && n.a == acc && n.b != acc) {  // the accumulator is the factor the lanes hold in parts: b
+                    mc |= SUB_MULT;
+                    macro_operand(n.b, 1, 0);
+                    macro_operand(n.a, 0, 1);
+                } else {
+                    mc |= mul ? (uint32_t)SUB_MULT : sub_of(n.op);
+                    macro_operand(n.a, 0, 0);
+                    macro_operand(n.b, 1, 1);
+                }
+                if (mul && (mc & MCTRL_A_ACC)) m_gather |= 1u << stg;
+                (mul ? m_mul : m_lin) |= 1u << stg;
+                m_latest[grp] = i;
+                const uint32_t rm[4] = {off[0], off[1], slot, lds[0] | (lds[1] << 16)};
+                memcpy(&out.recs[((size_t)b * G + js) * 4], rm, sizeof rm);
+                ctrl_of[(size_t)b * G + js] = (uint8_t)mc;
+                const uint32_t mops[2] = {n.a, n.kind == N_UNO ? n.a : n.b};
+                for (int q = 0; q < 2; ++q)
+                    if (needs_slot[mops[q]] == 1 && last_mem_use[mops[q]] == b) dying.push_back(mops[q]);
+                continue;
+            }
             if (!collect)
             switch (n.kind) {
                 case N_INPUT:
@@ -1712,6 +1908,17 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 lin_bits |= (op2 == FOP_MUL ? HDR_F_S2MUL : op2 ? HDR_F_S2LIN : 0u) | (op3 ? HDR_F_S3LIN : 0u);
             }
             form_saved = (lin_bits & HDR_F_S2MUL ? 0.0 : kCyclesFusedStageMul) + ((lin_bits & (HDR_F_S2LIN | HDR_F_S3LIN)) ? 0.0 : kCyclesFusedStageLin);
+        }
+        if (cl == C_MACRO) {
+            double cyc = kCyclesMacroFront;
+            for (uint32_t stg = 0; stg < MACRO_STAGES; ++stg) {
+                const uint32_t kind = (m_mul >> stg & 1u) ? ((m_lin >> stg & 1u) ? MSK_MIXED : MSK_MUL) : (m_lin >> stg & 1u) ? MSK_LIN : MSK_NONE;
+                lin_bits |= kind << (HDR_M_KIND_SHIFT + 2 * (int)stg);
+                if (stg && (m_late >> stg & 1u)) lin_bits |= 1u << (HDR_M_LATE_SHIFT + (int)stg);
+                if (stg && (m_gather >> stg & 1u)) lin_bits |= 1u << (HDR_M_GATHER_SHIFT + (int)stg);
+                cyc += kCyclesMacroStage[kind] + ((m_late >> stg & 1u) ? kCyclesMacroLate : 0.0) + ((m_gather >> stg & 1u) ? kCyclesMacroGather : 0.0);
+            }
+            form_saved = kCycles[C_MACRO] - cyc;
         }
         if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {
@@ -1766,11 +1973,18 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // second pass: destination byte offsets (trash slot = n_slots) + ctrl, and inactive padding records
     const uint32_t trash_off = (uint32_t)(((uint64_t)NC + n_slots) * slot_bytes);
     for (uint32_t b = 0; b < NB; ++b) {
-        const uint32_t rep = bundle_coop[b] ? COOP_LANES : 1u;
-        const uint32_t cnt = (bundle_start[b + 1] - bundle_start[b]) * rep;  // record positions in use
+        const bool macrob = bundle_coop[b] == 3;  // (its nodes sit at positions 4 * group + stage: the active bit tells)
+        const uint32_t rep = bundle_coop[b] == 1 || bundle_coop[b] == 2 ? COOP_LANES : 1u;
+        const uint32_t cnt = macrob ? G : (bundle_start[b + 1] - bundle_start[b]) * rep;  // record positions in use
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         for (uint32_t q = 0; q < cnt; ++q) {
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
+            if (macrob && !(ctrl_of[(size_t)b * G + q] & MCTRL_ACTIVE)) {  // a group idle in this stage: zeros in, trash out
+                r[0] = r[1] = zero_off;
+                r[2] = trash_off;
+                r[3] = (stage + q * T * 16u) | ((stage + 2u * LDS_HALF_BYTES + q * T * 16u) << 16);
+                continue;
+            }
             const uint32_t d = r[2] == 0xffffffffu ? trash_off : (uint32_t)(((uint64_t)NC + r[2]) * slot_bytes);
             r[2] = d | ctrl_of[(size_t)b * G + q];
         }
@@ -1854,7 +2068,17 @@ bool validate_program(const Program& p, std::string& err) {
         if (b == p.stream_first[stream] && p.stream_count[stream] && p.stream_cref_first[stream] != cref_row) return bad("third-operand rows of stream " + std::to_string(stream));
         const bool executed = b < p.stream_first[stream] + p.stream_count[stream];
         const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
-        if (cls >= C_COUNT || (h >> 19) != 0) return bad("bundle " + std::to_string(b) + ": header");
+        if (cls >= C_COUNT || (cls != C_MACRO && (h >> 19) != 0) || (h >> 30) != 0) return bad("bundle " + std::to_string(b) + ": header");
+        if (cls == C_MACRO) {  // stages: kinds without a gap, flags of stages that exist only; never in a program with fused bundles (one interpreter instance each)
+            if (T > COOP_FUSE_MAX_T || cnt > G) return bad("bundle " + std::to_string(b) + ": macro bundle");
+            bool ended = false;
+            for (uint32_t k = 0; k < MACRO_STAGES; ++k) {
+                const uint32_t kind = (h >> (HDR_M_KIND_SHIFT + 2 * (int)k)) & 3u;
+                const bool fl = k && ((h >> (HDR_M_LATE_SHIFT + (int)k)) & 1u || (h >> (HDR_M_GATHER_SHIFT + (int)k)) & 1u);
+                if ((kind != MSK_NONE && ended) || (kind == MSK_NONE && fl) || (k == 0 && kind == MSK_NONE)) return bad("bundle " + std::to_string(b) + ": macro stages");
+                ended = ended || kind == MSK_NONE;
+            }
+        }
         // posts and waits are C_SYNC bundles without nodes: stream 0 posts once, every other stream waits in its first bundle
         // (nothing else is compiled)
         if (((h & (HDR_POST | HDR_WAIT)) != 0) != (cls == C_SYNC) || (cls == C_SYNC && cnt != 0)) return bad("bundle " + std::to_string(b) + ": post / wait bits");
@@ -1892,7 +2116,13 @@ bool validate_program(const Program& p, std::string& err) {
                 if ((q & 1u) ? (code == FOP_MUL || code > FOP_RSUB || (r[2] & ~CTRL_MASK) != trash_off) : code > FOP_RSUB) return bad("bundle " + std::to_string(b) + ": fused stage code");
                 if ((code == FOP_MUL && !(h & HDR_F_S2MUL)) || (code > FOP_MUL && !(h & ((q & 1u) ? HDR_F_S3LIN : HDR_F_S2LIN)))) return bad("bundle " + std::to_string(b) + ": fused stage bits");
             }
-            const uint32_t dst = r[2] & ~CTRL_MASK;
+            if (cls == C_MACRO && (r[2] & MCTRL_ACTIVE)) {  // the record's operation must be one its stage runs
+                const uint32_t kind = (h >> (HDR_M_KIND_SHIFT + 2 * (int)(q % MACRO_STAGES))) & 3u, op = r[2] & MCTRL_OP_MASK;
+                if (kind == MSK_NONE || op > SUB_MULT || (kind == MSK_MUL && op != SUB_MULT) || (kind == MSK_LIN && op == SUB_MULT) ||
+                    ((q % MACRO_STAGES) == 0 && (r[2] & (MCTRL_A_ACC | MCTRL_B_ACC))))
+                    return bad("bundle " + std::to_string(b) + ": macro record");
+            }
+            const uint32_t dst = r[2] & ~(cls == C_MACRO ? MCTRL_MASK : CTRL_MASK);
             if ((dst % slot_bytes) != 0 || dst < (uint64_t)p.n_const * slot_bytes || dst > trash_off) return bad("bundle " + std::to_string(b) + ": destination");
             const uint32_t la = r[3] & 0xffffu, lb = r[3] >> 16;
             const bool bitx = cls == C_BIT && (r[2] & CTRL_SUB_MASK) == SUB_BITX;
@@ -1910,6 +2140,12 @@ bool validate_program(const Program& p, std::string& err) {
         cref_row += cls == C_INPUT || cls == C_TERN;
     }
     if (cref_row != p.n_cref_rows) return bad("third-operand rows");
+    bool any_fused = false, any_macro = false;  // (one interpreter instance each: a program has one kind or the other)
+    for (uint32_t h : p.hdr) {
+        any_fused = any_fused || (h & HDR_CLASS_MASK) == C_MULF;
+        any_macro = any_macro || (h & HDR_CLASS_MASK) == C_MACRO;
+    }
+    if (any_fused && any_macro) return bad("fused and macro bundles in one program");
     if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
     if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)
@@ -1931,7 +2167,7 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 13;
+    h.version = 14;
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -1952,7 +2188,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 13 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 14 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

@@ -83,10 +83,10 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t byte
 // interpreter waves (W = 0), or PACK x (W interpreters + their divider) with the interpreters first.  The waves of a
 // workgroup are dealt round the CU's four SIMDs, so four-wave workgroups put one wave on every SIMD where single-wave
 // (or two-wave) workgroups land unevenly: 1024 tiles without dividers take 23.2 ms as 256 x 4 waves, 31.4 ms as 1024 x 1.
-// FUSED: the program has fused narrow bundles (class C_MULF).  Their path is compiled into instances of their own: inside the
+// MODE 1: the program has fused narrow bundles (class C_MULF), MODE 2: macro bundles (class C_MACRO).  Their paths are compiled into instances of their own: inside the
 // one interpreter loop it cost every other program 5 % (register allocation and layout of the hot paths; same-box A/B on
 // the authV2-class graph, 1024 sets: 12.55 against 11.93 ms, profiles/r03_regress_ab.txt).
-template <int T, bool PROF, int W, int PACK, bool FUSED = false>
+template <int T, bool PROF, int W, int PACK, int MODE = 0>
 __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_kernel(const uint32_t* __restrict__ hdr, const uint4* __restrict__ recs,
                                                     const uint32_t* __restrict__ crefs, InterpDims p, WsTable wst,
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
@@ -244,7 +244,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const uint32_t trash_doff = (p.n_const + p.n_slots) * 2u * HI | t16;
     constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
     unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
-    unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67])
+    unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67]) / C_MACRO (prof[68], prof[71])
+    unsigned long long pm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // sections of the macro bundles (prof[72..79])
     if (PROF) {
 #pragma unroll
         for (int c = 0; c < C_PROF; ++c) pf[c][0] = pf[c][1] = 0;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         if constexpr (COOP) {
             uint32_t cls_q = h & HDR_CLASS_MASK;
             asm volatile("" : "+s"(cls_q));
-            static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_COUNT == 14, "one compare (class >= C_MULQ) leads to both narrow classes");
+            static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_MACRO == 14 && C_COUNT == 15, "one compare (class >= C_MULQ) leads to the narrow classes");
             if (cls_q >= C_MULQ) {
             if (cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
                 // (laid out behind the loop's main line: a taken branch costs a lone wave ~50 cycles, and two of three bundles are not narrow)
@@ -331,7 +332,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 }
                 continue;
             }
-            if constexpr (FUSED && (uint32_t)T <= COOP_FUSE_MAX_T) {
+            if constexpr (MODE == 1 && (uint32_t)T <= COOP_FUSE_MAX_T) {
             if (cls_q == C_MULF) {  // fused narrow bundle: (a * b) op2 x2 op3 x3 in the registers of the node's four lanes (program_dev.h)
                 // lane l holds record l / T: the group's main record (even positions) and extra record (odd positions) by DPP
                 constexpr int QP_MAIN = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x00 /* [0,0,0,0] */, QP_EXTRA = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xAA /* [2,2,2,2] */;
@@ -389,6 +390,123 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     const unsigned long long t_now = __builtin_amdgcn_s_memtime();
                     pf_fused[0] += t_now - st0;
                     pf_fused[1] += 1;
+                }
+                continue;
+            }
+            }
+            if constexpr (MODE == 2 && (uint32_t)T <= COOP_FUSE_MAX_T) {
+            if (cls_q == C_MACRO) {  // macro bundle: up to four narrow bundles of the schedule as the stages of one (program_dev.h)
+                // record position 4g + k is stage k of this lane's group g (lane 4v + q, v = t + T * g); the REC image is indexed by
+                // lane, position p sits at lanes pT .. pT + T - 1
+                const uint32_t gp = (cv / (uint32_t)T) * MACRO_STAGES;
+                const char* const recb = ldsb + LDS_REC_OFF + (b % REC_AHEAD) * REC_BYTES + 16u * T * gp + 8u;
+                uint2 rk[MACRO_STAGES];
+#pragma unroll
+                for (uint32_t k = 0; k < MACRO_STAGES; ++k) rk[k] = *reinterpret_cast<const uint2*>(recb + 16u * T * k);
+                const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
+                const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
+                uint32_t h_n2;
+                asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+                hdr_off_n2 += 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(rk[0].x), "v"(rk[1].x), "v"(rk[2].x), "v"(rk[3].x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                CWC_STAMP(m1);
+                // the operands of every stage (what an earlier stage of this bundle produces comes from the accumulator, or is
+                // read again in front of its stage): the staging loads of bundle b + 2 overwrite this bundle's cells below
+                Fr af[MACRO_STAGES];
+                uint2 aq[MACRO_STAGES], bq[MACRO_STAGES];
+#pragma unroll
+                for (uint32_t k = 0; k < MACRO_STAGES; ++k) {
+                    const uint32_t la = rk[k].y + (t16c | (t16c << 16));
+                    af[k] = ld_lds(la & 0xffffu);
+                    aq[k] = *reinterpret_cast<const uint2*>(ldsb + (la & 0xffffu) + coop_chunk);
+                    bq[k] = *reinterpret_cast<const uint2*>(ldsb + (la >> 16) + coop_chunk);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(af[0].v[0]), "v"(af[0].v[4]), "v"(af[1].v[0]), "v"(af[1].v[4]), "v"(af[2].v[0]), "v"(af[2].v[4]), "v"(af[3].v[0]), "v"(af[3].v[4]),
+                             "v"(aq[0].x), "v"(aq[1].x), "v"(aq[2].x), "v"(aq[3].x), "v"(bq[0].x), "v"(bq[1].x), "v"(bq[2].x), "v"(bq[3].x) : "memory");
+                CWC_STAMP(m2);
+                stage_operands(b + 2, rec_n2);
+                stage_rec(b + 4);
+                CWC_STAMP(m3);
+                if (PROF) {
+                    pm[0] += m1 - st0;
+                    pm[1] += m2 - m1;
+                    pm[2] += m3 - m2;
+                }
+                const uint32_t ring_b = LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES;
+                uint32_t acc0 = 0, acc1 = 0;  // the group's accumulator: the lane's two limbs of its most recent result
+#pragma unroll
+                for (uint32_t k = 0; k < MACRO_STAGES; ++k) {
+                    const uint32_t kind = (h >> (HDR_M_KIND_SHIFT + 2 * (int)k)) & 3u;
+                    if (kind == MSK_NONE) break;
+                    CWC_STAMP(ms0);
+                    if (k > 0 && ((h >> (HDR_M_LATE_SHIFT + (int)k)) & 1u)) {  // operands an earlier stage wrote into this bundle's ring slot
+                        const uint32_t la = rk[k].y + (t16c | (t16c << 16));
+                        const uint32_t a_ad = la & 0xffffu, b_ad = la >> 16;
+                        const Fr a2 = ld_lds(a_ad);
+                        const uint2 aq2 = *reinterpret_cast<const uint2*>(ldsb + a_ad + coop_chunk), bq2 = *reinterpret_cast<const uint2*>(ldsb + b_ad + coop_chunk);
+                        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a2.v[0]), "v"(a2.v[4]), "v"(aq2.x), "v"(bq2.x) : "memory");
+                        const bool a_new = a_ad - ring_b < RING_SLOT_BYTES, b_new = b_ad - ring_b < RING_SLOT_BYTES;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) af[k].v[i] = a_new ? a2.v[i] : af[k].v[i];
+                        aq[k] = a_new ? aq2 : aq[k];
+                        bq[k] = b_new ? bq2 : bq[k];
+                        if (PROF) {
+                            CWC_STAMP(ms1);
+                            pm[5] += ms1 - ms0;
+                            pm[6] += 1;
+                        }
+                    }
+                    const uint32_t c = rk[k].x;
+                    const bool a_acc = (c & MCTRL_A_ACC) != 0, b_acc = (c & MCTRL_B_ACC) != 0;
+                    const uint32_t b0 = b_acc ? acc0 : bq[k].x, b1 = b_acc ? acc1 : bq[k].y;
+                    const uint32_t a0 = a_acc ? acc0 : aq[k].x, a1 = a_acc ? acc1 : aq[k].y;
+                    uint32_t o[2];
+                    if (kind == MSK_LIN) {  // graph.rs:110-111
+                        fr_addsub_coop4(a0, a1, b0, b1, nq0, nq1, c & 1u, o);
+                    } else {                // graph.rs:105 (and linear nodes in groups of their own)
+                        if (k > 0 && ((h >> (HDR_M_GATHER_SHIFT + (int)k)) & 1u)) {  // the accumulator as the full-width factor: the group's lanes exchange their limbs
+                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0x00, 0xf, 0xf, false), g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0x00, 0xf, 0xf, false);
+                            const uint32_t g2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0x55, 0xf, 0xf, false), g3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0x55, 0xf, 0xf, false);
+                            const uint32_t g4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0xAA, 0xf, 0xf, false), g5 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0xAA, 0xf, 0xf, false);
+                            const uint32_t g6 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0xFF, 0xf, 0xf, false), g7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0xFF, 0xf, 0xf, false);
+                            const uint32_t gv[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) af[k].v[i] = a_acc ? gv[i] : af[k].v[i];
+                        }
+                        if (kind == MSK_MUL) fr_mul_coop4(af[k], b0, b1, nq0, nq1, o);
+                        else fr_mul_coop4r(af[k], a0, a1, b0, b1, nq0, nq1, c & MCTRL_OP_MASK, o);
+                    }
+                    const bool act = (c & MCTRL_ACTIVE) != 0;
+                    acc0 = act ? o[0] : acc0;
+                    acc1 = act ? o[1] : acc1;
+                    // the stage's results: ring cell 4g + k of this bundle (an idle group's cell is nobody's operand) and the slot
+                    *reinterpret_cast<uint2*>(ldsb + ring_b + 16u * T * (gp + k) + t16c + coop_chunk) = make_uint2(o[0], o[1]);
+                    {
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[0], o[1]}, rsrc, (int)((c & ~MCTRL_MASK) + coop_dst_off), 0, 0);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (PROF) {
+                        CWC_STAMP(ms2);
+                        pm[3] += ms2 - ms0;
+                        pm[4] += 1;
+                    }
+                }
+                CWC_STAMP(m4);
+                doff_prev = trash_doff;
+                rec_hi = rec_hi_n1;
+                rec_hi_n1 = rec_hi_n2;
+                h_cur = h_n1;
+                h_n1 = h_n2;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (PROF) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+                    pf_fused[0] += t_now - st0;
+                    pf_fused[1] += 1;
+                    pm[7] += t_now - m4;
                 }
                 continue;
             }
@@ -686,8 +804,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             atomicAdd(&prof[c * 4 + 0], pf[c][0]);
             atomicAdd(&prof[c * 4 + 3], pf[c][1]);
         }
-        atomicAdd(&prof[64], pf_fused[0]);
-        atomicAdd(&prof[67], pf_fused[1]);
+        atomicAdd(&prof[MODE == 2 ? 68 : 64], pf_fused[0]);
+        atomicAdd(&prof[MODE == 2 ? 71 : 67], pf_fused[1]);
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) atomicAdd(&prof[72 + q], pm[q]);
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -838,15 +960,16 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
         dims.stream_div_requests[0] = n_div_requests;
     }
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-    const bool fused = p.has_fused != 0;
-    if (fused && T > COOP_FUSE_MAX_T) return hipErrorInvalidValue;
+    const uint32_t mode = p.has_fused;  // 0, 1: fused narrow bundles, 2: macro bundles (validate_program: never both)
+    if (mode > 2 || (mode && T > COOP_FUSE_MAX_T)) return hipErrorInvalidValue;
 #define CWC_LAUNCH3(TT, PP, WW, KK)                                                                                                     \
     do {                                                                                                                                \
         if constexpr ((uint32_t)(TT) <= COOP_FUSE_MAX_T) {                                                                              \
-            if (fused) interp_kernel<TT, PP, WW, KK, true><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
-            else interp_kernel<TT, PP, WW, KK, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);     \
+            if (mode == 2) interp_kernel<TT, PP, WW, KK, 2><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
+            else if (mode == 1) interp_kernel<TT, PP, WW, KK, 1><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
+            else interp_kernel<TT, PP, WW, KK, 0><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);     \
         } else {                                                                                                                        \
-            interp_kernel<TT, PP, WW, KK, false><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);          \
+            interp_kernel<TT, PP, WW, KK, 0><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);          \
         }                                                                                                                               \
     } while (0)
 #define CWC_LAUNCH2(TT, PP)                                  \

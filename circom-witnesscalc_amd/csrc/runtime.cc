@@ -114,7 +114,8 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_inputs = p.n_inputs;
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
-    dp.dev.has_fused = p.stats.class_bundles[C_MULF] ? 1u : 0u;
+    dp.dev.has_fused = 0;  // (from the bundle headers themselves: an imported program's statistics are not what the kernel runs)
+    for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : (h & HDR_CLASS_MASK) == C_MACRO ? 2u : 0u;
     dp.dev.n_streams = p.n_streams;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dp.dev.stream_first[s] = p.stream_first[s];
@@ -1580,12 +1581,12 @@ int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void
     std::string err = check_device();
     if (!err.empty()) return fail(status, err);
     unsigned long long* d = nullptr;
-    if (hipMalloc(&d, 72 * 8) != hipSuccess || hipMemset(d, 0, 72 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
+    if (hipMalloc(&d, 96 * 8) != hipSuccess || hipMemset(d, 0, 96 * 8) != hipSuccess) return fail(status, "hipMalloc failed");
     g->d_prof = d;
     err = run_device(g, d_inputs, batch, d_witness, d_set_status, nullptr);
     g->d_prof = nullptr;
     if (err.empty() && hipDeviceSynchronize() != hipSuccess) err = "hipDeviceSynchronize failed";
-    if (err.empty() && hipMemcpy(out36, d, 72 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
+    if (err.empty() && hipMemcpy(out36, d, 96 * 8, hipMemcpyDeviceToHost) != hipSuccess) err = "hipMemcpy failed";
     (void)hipFree(d);
     if (!err.empty()) return fail(status, err);
     set_status(status, OK, "");

@@ -178,7 +178,10 @@ int gwb_timing_history(gwb_graph_t *g, size_t max_launches, float *interp_ms, fl
  * bundles out64[48 + 8*k + {0: loop top + wait for staged operands, 1: LDS operand reads with the previous bundle's
  * stores issued behind them, 2: issuing the staging loads, 3: dispatch + arithmetic, 4: ring write, 5: bundles}];
  * over all interpreter waves: out64[54] = longest run time of the loop, out64[55] = 2^40 - shortest, out64[62] = sum,
- * out64[63] = waves; out64[64] / out64[67] = cycles / bundles of the fused narrow bundles (class 13).  out64 must hold 72 words. */
+ * out64[63] = waves; out64[64] / out64[67] = cycles / bundles of the fused narrow bundles (class 13), out64[68] / out64[71] of the macro
+ * bundles (class 14); out64[72..79] = sections of the macro bundles: cycles up to the records, up to the operands, issuing the staging
+ * loads, in the stages, number of stages, cycles re-reading operands of earlier stages, number of such stages, cycles behind the
+ * last stage.  out64 must hold 96 words. */
 int gwb_profile_classes(gwb_graph_t *g, const void *d_inputs, size_t batch, void *d_witness,
                         uint32_t *d_set_status, uint64_t *out64, gw_status_t *status);
 

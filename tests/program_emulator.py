@@ -21,15 +21,19 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d46Q"
+HDR_FMT = "<12I12I6I12d48Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "MACRO"]
 N_CLASSES = len(CLASS_NAMES)
 FOP_NONE, FOP_MUL, FOP_ADD, FOP_SUB, FOP_RSUB = range(5)  # stage codes of a fused node (class MULF)
 HDR_F_S2MUL, HDR_F_S2LIN, HDR_F_S3LIN = 1 << 11, 1 << 12, 1 << 13
 COOP_FUSE_MAX_T = 2
 COOP_LANES, COOP_MAX_T = 4, 4
+# macro bundles (class MACRO): record position 4g + k = stage k of lane group g; header: two bits per stage from bit 19
+# (0 none, 1 products, 2 products and linear nodes, 3 linear nodes), LATE of stage k at bit 26 + k, GATHER at bit 10 + k
+MACRO_STAGES, HDR_M_KIND_SHIFT, HDR_M_LATE_SHIFT, HDR_M_GATHER_SHIFT = 4, 19, 26, 10
+MCTRL_OP_MASK, MCTRL_A_ACC, MCTRL_ACTIVE, MCTRL_B_ACC, MCTRL_MASK = 3, 4, 8, 16, 31
 
 
 class Blob:
@@ -128,7 +132,7 @@ def run(blob: Blob, inputs_row):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         name = CLASS_NAMES[cls]
-        assert h >> 19 == 0 and (1 <= cnt <= G or (cnt == 0 and name in ("LIN", "SYNC")))
+        assert (h >> 19 == 0 or name == "MACRO") and h >> 30 == 0 and (1 <= cnt <= G or (cnt == 0 and name in ("LIN", "SYNC")))
         assert (name == "SYNC") == bool(h & (HDR_POST | HDR_WAIT)) and not (name == "SYNC" and cnt)
         a_canon, b_canon, out_canon = bool(h & HDR_A_CANON), bool(h & HDR_B_CANON), bool(h & HDR_OUT_CANON)
         assert not (a_canon or b_canon) or name in ("BIT", "IDIVMOD", "CMPS")
@@ -150,7 +154,74 @@ def run(blob: Blob, inputs_row):
             request = {}
         if name == "DIVGET":
             assert blob.divider and mailbox is not None and len(mailbox) == cnt, "collect must mirror the request"
-        for pos in range(G):
+        macro_cells = None
+        if name == "MACRO":
+            # The stages in order; within a stage every lane group reads its operands -- memory operands from its own stage
+            # cells, results of the three bundles before from the ring (read before the first stage writes), results of
+            # earlier stages of this bundle from the group's accumulator (ctrl bits) or from this bundle's own ring cells,
+            # which needs the stage's LATE bit -- then the stage's results become visible.
+            assert T <= COOP_FUSE_MAX_T and blob.stats["class_bundles"][CLASS_NAMES.index("MULF")] == 0 and (h >> 14) & 0x1F == 0
+            kinds = [(h >> (HDR_M_KIND_SHIFT + 2 * k)) & 3 for k in range(MACRO_STAGES)]
+            late = [k > 0 and bool((h >> (HDR_M_LATE_SHIFT + k)) & 1) for k in range(MACRO_STAGES)]
+            gather = [k > 0 and bool((h >> (HDR_M_GATHER_SHIFT + k)) & 1) for k in range(MACRO_STAGES)]
+            n_st = kinds.index(0) if 0 in kinds else MACRO_STAGES
+            assert n_st >= 2 and not any(kinds[n_st:]) and not any(late[n_st:]) and not any(gather[n_st:]), "stages without a gap, at least two"
+            acc, macro_cells, n_active = {}, {}, 0
+            for k in range(MACRO_STAGES):
+                seen = {"mul": False, "lin": False, "late": False, "gather": False}
+                out_k = []
+                for grp in range(G // MACRO_STAGES):
+                    pos = MACRO_STAGES * grp + k
+                    a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
+                    ctrl, dst = dctl & MCTRL_MASK, dctl & ~MCTRL_MASK
+                    if not ctrl & MCTRL_ACTIVE:
+                        assert ctrl == 0 and dst == trash and a_off == zero_off and b_off == zero_off, "idle group of a stage"
+                        continue
+                    assert k < n_st, "a node in a stage the header does not have"
+                    n_active += 1
+
+                    def mfetch(off, la, q, is_acc):
+                        if is_acc:
+                            assert k > 0 and grp in acc and off == zero_off, "accumulator operand without a result in the group"
+                            rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
+                            assert rs == b % RING_BUNDLES and macro_cells[rem // (16 * T)] == acc[grp], "the accumulator operand names the producer's cell"
+                            return acc[grp]
+                        if la == stage + 2 * q * LDS_HALF_BYTES + pos * T * 16:
+                            return mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD)
+                        assert off == zero_off, "ring operand must stage the zero constant"
+                        rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
+                        assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
+                        cell = rem // (16 * T)
+                        if rs == b % RING_BUNDLES:  # this bundle's own ring slot: a result of an earlier stage, read again
+                            assert late[k] and cell in macro_cells, "operand from an earlier stage without the LATE bit"
+                            seen["late"] = True
+                            return macro_cells[cell]
+                        wb, val = ring[(rs, cell)]
+                        assert 1 <= b - wb <= RING_BUNDLES - 1, "ring cell too old for a macro bundle"
+                        return val
+                    x = mfetch(a_off, lds & 0xFFFF, 0, bool(ctrl & MCTRL_A_ACC))
+                    y = mfetch(b_off, lds >> 16, 1, bool(ctrl & MCTRL_B_ACC))
+                    op = ctrl & MCTRL_OP_MASK
+                    assert op <= 2
+                    if op == 2:
+                        seen["mul"] = True
+                        if ctrl & MCTRL_A_ACC:
+                            assert gather[k], "the accumulator as the full-width factor needs the GATHER bit"
+                            seen["gather"] = True
+                        v = x * y * R_INV % model.M
+                    else:
+                        seen["lin"] = True
+                        v = (x + y) % model.M if op == 0 else (x - y) % model.M
+                    out_k.append((grp, pos, dst, v))
+                if k < n_st:
+                    assert kinds[k] == (2 if seen["mul"] and seen["lin"] else 1 if seen["mul"] else 3), "stage kind must describe the records"
+                    assert late[k] == seen["late"] and gather[k] == seen["gather"], "LATE / GATHER bits must describe the records"
+                for grp, pos, dst, v in out_k:
+                    acc[grp] = v
+                    macro_cells[pos] = v
+                    results.append((dst, v))
+            assert n_active == cnt
+        for pos in range(0 if name == "MACRO" else G):
             j = pos // rep
             a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
             if name == "MULF" and pos % rep:
@@ -261,7 +332,7 @@ def run(blob: Blob, inputs_row):
             mailbox = None
         else:
             assert name != "DIV" or not blob.divider
-        if name == "MULF":
+        if name in ("MULF", "MACRO"):
             pass
         elif name == "BIT":
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
@@ -273,7 +344,7 @@ def run(blob: Blob, inputs_row):
             assert ((h >> 13) & 1) == 0
         if name == "MULF":
             assert (h & (HDR_F_S2MUL | HDR_F_S2LIN | HDR_F_S3LIN)) == fused_bits, "stage bits of a fused bundle must describe its records"
-        else:
+        elif name != "MACRO":
             assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
@@ -283,10 +354,16 @@ def run(blob: Blob, inputs_row):
                 hist = history.setdefault(d // slot_bytes - NC, [])
                 assert not hist or hist[0][0] == stream, "a slot is written by one stream only"
                 hist.append((stream, b, v))
-        for j, (_, v) in enumerate(results):
-            ring[(b % RING_BUNDLES, j)] = (b, v)
-        for j in range(cnt if name != "DIVREQ" else 0, G):
-            ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
+        if macro_cells is not None:
+            for j in range(G):  # (cells of idle groups hold garbage)
+                ring.pop((b % RING_BUNDLES, j), None)
+            for j, v in macro_cells.items():
+                ring[(b % RING_BUNDLES, j)] = (b, v)
+        else:
+            for j, (_, v) in enumerate(results):
+                ring[(b % RING_BUNDLES, j)] = (b, v)
+            for j in range(cnt if name != "DIVREQ" else 0, G):
+                ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
 
         if b == blob.stream_first[stream] + blob.stream_count[stream] - 1:
             assert mailbox is None and n_requests == blob.stream_div_requests[stream]

@@ -163,6 +163,20 @@ def test_compiler_rewrites_on_chain_heavy_graphs(pkg):
         _check(pkg, b.to_bin(), rows, tiles=(1, 2, 16, 64, 2 | DIVIDER, 8 | DIVIDER, 1 | GROUP, 8 | GROUP))
 
 
+def test_macro_bundles_opt_in_on_the_gpu(pkg, monkeypatch):
+    """CWC_MACRO=1: runs of narrow bundles as the stages of macro bundles (class C_MACRO, its own interpreter instances) --
+    measured slower than the separate bundles and therefore opt-in, but exact: Poseidon, chain-heavy and random graphs at
+    tile widths 1 and 2, with divider waves and as stream programs, against the oracle."""
+    monkeypatch.setenv("CWC_MACRO", "1")
+    rnd = random.Random(78)
+    n_macro = 0
+    for b, n_in in [(C.build_poseidon(2), 3), (C.build_chain_heavy(5), 6), (C.build_chain_heavy(9, n_chains=16), 6)] + \
+                   [(C.build_random_dag(s, n_ops=300, panic_free=True, parts=1 + s % 3), 7) for s in range(6)]:
+        g = _check(pkg, b.to_bin(), [_rand_row(rnd, n_in) for _ in range(37)], tiles=(1, 2, 1 | DIVIDER, 2 | DIVIDER, 2 | 0x1000))
+        n_macro += g.program_stats()["class_bundles"].get("MACRO", 0)
+    assert n_macro > 50
+
+
 def test_short_soak_random_graphs_batches_programs(pkg):
     """120 random graphs (every op, panic edges, chain-heavy) x random batch sizes x random program keys."""
     from tools import gpu_soak
