@@ -1001,6 +1001,14 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     return hipGetLastError();
 }
 
+// An empty kernel of this code object: its first launch makes the runtime load the object (every interpreter instance) --
+// the single-shot entry point does that on a thread of its own while the host parses and compiles (runtime.cc warm_device).
+__global__ void warm_kernel() {}
+hipError_t launch_warm(hipStream_t stream) {
+    warm_kernel<<<1, 64, 0, stream>>>();
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream) {
     if (n_tiles == 0 || p.n_const == 0) return hipSuccess;
     dim3 grid((p.n_const * 2u * T + 255u) / 256u, n_tiles < 16384u ? n_tiles : 16384u), block(256);

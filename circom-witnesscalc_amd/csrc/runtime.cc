@@ -35,6 +35,7 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
 hipError_t launch_pack(uint32_t T, const ProgramDev& p, const WsTable& wst, void* out, uint32_t batch, hipStream_t stream, bool montgomery);
 hipError_t launch_modmul_ubench(uint32_t n_cus, uint32_t waves_per_simd, uint32_t iters, uint32_t* sink, hipStream_t stream, bool block_multiplier);
 hipError_t launch_fill_consts(uint32_t T, const ProgramDev& p, const WsTable& wst, uint32_t n_tiles, hipStream_t stream);
+hipError_t launch_warm(hipStream_t stream);
 }  // namespace cwc
 
 using namespace cwc;
@@ -170,6 +171,9 @@ struct gwb_graph {
     };
     std::map<size_t, std::future<Refined>> refining;  // by batch size
     std::map<size_t, uint32_t> provisional;            // batch size -> the quick program's key while the task runs
+    // the task starts compiling once the call that launched it has its kernels enqueued: eight compiler threads beside the first
+    // call's allocations, upload and launches cost that call ~100 ms (measured; allocator and page-fault contention)
+    std::shared_ptr<std::atomic<bool>> refine_gate;
     bool cache_written = false;                        // single-shot entry point: the refined program went to the on-disk cache
     std::string cache_path;                            // ... to this file (empty: no cache, or the handle came out of it)
     // buffers of the streaming end-to-end entry point (gwb_calc_witness_json_to_wtns), kept between calls: pinned input rows,
@@ -364,6 +368,29 @@ std::vector<uint32_t> candidate_keys(const ProgramStats& stats, size_t batch, ui
     return keys;
 }
 
+uint64_t fnv1a(const uint8_t* p, size_t n);
+// What gwb_graph_export hands out / the on-disk cache holds: the program blob, the input map, a checksummed trailer.
+std::vector<uint8_t> exported_bytes(const Program& p, const std::vector<InputSignal>& inputs) {
+    std::vector<uint8_t> b = program_to_blob(p);
+    auto put32 = [&](uint32_t v) { b.insert(b.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
+    const size_t exact_len = b.size();
+    while (b.size() % 8) b.push_back(0);
+    const size_t prog_len = b.size();
+    put32((uint32_t)inputs.size());
+    for (const InputSignal& s : inputs) {
+        put32(s.offset);
+        put32(s.len);
+        put32((uint32_t)s.name.size());
+        b.insert(b.end(), s.name.begin(), s.name.end());
+    }
+    // trailer: exact program length, padded program length (= where the input map starts), FNV-1a of everything before
+    uint64_t tr[3] = {(uint64_t)exact_len, (uint64_t)prog_len, 0};
+    tr[2] = fnv1a(b.data(), b.size());
+    b.insert(b.end(), (uint8_t*)tr, (uint8_t*)tr + sizeof tr);
+    return b;
+}
+void write_file_atomically(const std::string& path, const void* data, size_t n);
+
 // the full choice for a batch size, on a thread of its own (reads the graph only): every candidate compiled with the
 // search over schedule variants, priced by the cost model
 gwb_graph::Refined refine_choice(const Graph& graph, const ProgramStats& stats, size_t batch, uint32_t rule, uint32_t min_t) {
@@ -450,7 +477,27 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
             const Graph* graph = &g->graph;
             const ProgramStats stats = g->stats;
             g->provisional[batch] = quick_key;
-            g->refining[batch] = std::async(std::launch::async, [graph, stats, batch, rule, min_t]() { return refine_choice(*graph, stats, batch, rule, min_t); });
+            // (the single-shot entry point's on-disk cache: the task writes the program it settles on, no call waits for the file)
+            const std::string cache_file = batch == 1 && !g->cache_written ? g->cache_path : std::string();
+            const std::vector<InputSignal> inputs = cache_file.empty() ? std::vector<InputSignal>() : g->inputs;
+            if (!cache_file.empty()) g->cache_written = true;
+            if (!g->refine_gate) g->refine_gate = std::make_shared<std::atomic<bool>>(false);
+            g->refine_gate->store(false);
+            std::shared_ptr<std::atomic<bool>> gate = g->refine_gate;
+            g->refining[batch] = std::async(std::launch::async, [graph, stats, batch, rule, min_t, cache_file, inputs, gate]() {
+                for (int waited = 0; !gate->load() && waited < 2000; ++waited) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                gwb_graph::Refined r = refine_choice(*graph, stats, batch, rule, min_t);
+                auto best = r.programs.find(r.best);
+                if (!cache_file.empty() && r.best && best != r.programs.end()) {
+                    try {
+                        const std::vector<uint8_t> b = exported_bytes(*best->second, inputs);
+                        write_file_atomically(cache_file, b.data(), b.size());
+                        if (getenv("CWC_DEBUG_CACHE")) fprintf(stderr, "program cache: wrote %s (program key %#x, %zu bytes)\n", cache_file.c_str(), r.best, b.size());
+                    } catch (...) {
+                    }
+                }
+                return r;
+            });
             return quick_key;
         }
     }
@@ -521,10 +568,15 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
                        hipStream_t stream, bool montgomery = false, hipEvent_t done_event = nullptr) {
     if (batch == 0) return "";
     if (batch > 0x7fffffffull) return "batch too large";
+    static const bool dbg_steps = getenv("CWC_DEBUG_SINGLE") != nullptr;  // diagnostic: program choice / upload of a call
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = dbg_steps ? now_ms() : 0.0;
     const uint32_t key = pick_tile_width(g, batch);
+    const double t_1 = dbg_steps ? now_ms() : 0.0;
     DeviceProgram* dp = nullptr;
     std::string err = get_program(g, key, &dp);
     if (!err.empty()) return err;
+    const double t_2 = dbg_steps ? now_ms() : 0.0;
     g->last_key = (key & ~KEY_MODE_MASK) == 64 ? 64u : key;
     const Program& p = dp->host;
     const uint32_t T = p.T;
@@ -588,6 +640,7 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
         g->filled_tiles_per_chunk = chunk_tiles;
         g->filled_chunks = per_launch;
     }
+    const double t_3 = dbg_steps ? now_ms() : 0.0;
     g->last_call_launches = 0;
     g->timing = gwb_timing_t{};
     g->timing.tile_width = T;
@@ -627,6 +680,9 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     }
     g->timing_pending = true;
     if (done_event) HIP_TRY(hipEventRecord(done_event, stream));
+    if (g->refine_gate) g->refine_gate->store(true);  // the first call's work is on the device: the background search may take the host's cores
+    if (dbg_steps && now_ms() - t_0 > 20.0)
+        fprintf(stderr, "run_device: program choice %.1f ms, program on the device %.1f ms, workspace + constants %.1f ms, launches %.1f ms\n", t_1 - t_0, t_2 - t_1, t_3 - t_2, now_ms() - t_3);
     return "";
 }
 
@@ -677,15 +733,20 @@ std::string device_to_host_rows(gwb_graph* g, void* dst, const void* d_src, size
         const long v = atol(e);
         if (v >= 1 && v <= 1024) slice = (size_t)v << 20;
     }
+    // (pinned memory is slow to get -- two 32 MB buffers were 90 ms of the single-shot entry point's first call: a transfer
+    // that fits one slice takes one buffer of its own size)
+    if (bytes < slice) slice = std::max<size_t>(g->stage_bytes, (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1));
+    const int n_stage = bytes > slice ? 2 : 1;
     if (g->stage_bytes < slice) {
         for (int i = 0; i < 2; ++i) {
             if (g->stage[i]) HIP_TRY(hipHostFree(g->stage[i]));
             g->stage[i] = nullptr;
         }
         g->stage_bytes = 0;
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&g->stage[i], slice, hipHostMallocDefault));
+        for (int i = 0; i < n_stage; ++i) HIP_TRY(hipHostMalloc(&g->stage[i], slice, hipHostMallocDefault));
         g->stage_bytes = slice;
     }
+    if (n_stage == 2 && !g->stage[1]) HIP_TRY(hipHostMalloc(&g->stage[1], g->stage_bytes, hipHostMallocDefault));
     for (int i = 0; i < 2; ++i)
         if (!g->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
     const size_t n_slices = (bytes + slice - 1) / slice;
@@ -755,17 +816,25 @@ std::string run_host(gwb_graph* g, const void* inputs, size_t batch, void* witne
         have = need;
         return "";
     };
+    static const bool dbg_steps = getenv("CWC_DEBUG_SINGLE") != nullptr;  // diagnostic: the steps of a host-rows call
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = dbg_steps ? now_ms() : 0.0;
     std::string err = grow(g->h_in, g->h_in_bytes, in_b ? in_b : 32);
     if (err.empty()) err = grow(g->h_out, g->h_out_bytes, out_b ? out_b : 32);
     if (err.empty()) err = grow(g->h_st, g->h_st_bytes, batch * 4);
     if (!err.empty()) return err;
     HIP_TRY(hipMemcpy(g->h_in, inputs, in_b, hipMemcpyHostToDevice));
+    const double t1 = dbg_steps ? now_ms() : 0.0;
     err = run_device(g, g->h_in, batch, g->h_out, (uint32_t*)g->h_st, nullptr);
     if (!err.empty()) return err;
+    const double t2 = dbg_steps ? now_ms() : 0.0;
     HIP_TRY(hipDeviceSynchronize());
+    const double t3 = dbg_steps ? now_ms() : 0.0;
     err = device_to_host_rows(g, witness, g->h_out, out_b);
     if (!err.empty()) return err;
     HIP_TRY(hipMemcpy(set_status, g->h_st, batch * 4, hipMemcpyDeviceToHost));
+    if (dbg_steps && now_ms() - t0 > 20.0)
+        fprintf(stderr, "run_host: device buffers + rows in %.1f ms, run_device (choice, upload, workspace, launches) %.1f ms, wait for the device %.1f ms, rows out %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
     return "";
 }
 
@@ -776,6 +845,29 @@ std::string set_status_text(uint32_t bits) {
     if (bits & 0x40000000u) s += std::string(s.empty() ? "" : "; ") + "internal error: wait for another stream's post timed out";
     if (bits & ST_BITOP_EQ_R) s += std::string(s.empty() ? "" : "; ") + "bit operation result equals the modulus (reference panics at graph.rs:686/701/716)";
     return s;
+}
+
+// First use of the device in a process: the runtime's initialisation (~60 ms), the device context its first allocation
+// makes (~90 ms) and the load of this library's code object are started on a thread of their own by the single-shot entry
+// point, beside the host's parsing and compiling of a new graph (~120 ms for the authV2-class graph) -- the calling thread
+// does its host work first and touches the device last (it then waits on the runtime's own locks for what is left).
+// Errors are left to the calling thread's own checks.
+void warm_device() {
+    static std::once_flag once;
+    std::call_once(once, []() {
+        if (getenv("CWC_NO_WARM_THREAD")) return;
+        std::thread([]() {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+                (void)hipGetLastError();
+                return;
+            }
+            void* p = nullptr;  // (the first allocation makes the device context: ~90 ms)
+            if (hipMalloc(&p, 4096) == hipSuccess) (void)hipFree(p);
+            else (void)hipGetLastError();
+            if (launch_warm(nullptr) != hipSuccess) (void)hipGetLastError();
+        }).detach();
+    });
 }
 
 // ---- compiled-graph cache for the single-shot entry point (the reference re-parses per call, lib.rs:129) ----
@@ -1621,23 +1713,7 @@ int gwb_graph_export(gwb_graph_t* g, uint32_t T, void** blob, size_t* blob_len, 
         if (!compile_program(g->graph, T & ~KEY_MODE_MASK, key_divider_waves(T), tmp, err, key_streams(T))) return fail(status, err);
         p = &tmp;
     }
-    std::vector<uint8_t> b = program_to_blob(*p);
-    // trailer: input map
-    auto put32 = [&](uint32_t v) { b.insert(b.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
-    const size_t exact_len = b.size();
-    while (b.size() % 8) b.push_back(0);
-    const size_t prog_len = b.size();
-    put32((uint32_t)g->inputs.size());
-    for (const InputSignal& s : g->inputs) {
-        put32(s.offset);
-        put32(s.len);
-        put32((uint32_t)s.name.size());
-        b.insert(b.end(), s.name.begin(), s.name.end());
-    }
-    // trailer: exact program length, padded program length (= where the input map starts), FNV-1a of everything before
-    uint64_t tr[3] = {(uint64_t)exact_len, (uint64_t)prog_len, 0};
-    tr[2] = fnv1a(b.data(), b.size());
-    b.insert(b.end(), (uint8_t*)tr, (uint8_t*)tr + sizeof tr);
+    const std::vector<uint8_t> b = exported_bytes(*p, g->inputs);
     *blob = malloc(b.size());
     if (!*blob) return fail(status, "out of memory");
     memcpy(*blob, b.data(), b.size());
@@ -1807,7 +1883,12 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
     // calc_witness (lib.rs:125-136): inputs first, then the graph
     InputList list;
     std::string err;
+    const bool dbg_single = getenv("CWC_DEBUG_SINGLE") != nullptr;  // diagnostic: where a call's time goes
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now_ms();
+    warm_device();
     if (!deserialize_inputs(inputs, strlen(inputs), list, err)) return fail(status, "Failed to calculate witness: " + err);
+    const double t_inputs = now_ms();
 
     std::shared_ptr<gwb_graph> g;
     // (a sampled fingerprint picks the candidate, the byte compare below decides: hashing the whole 3 MB image on every
@@ -1821,7 +1902,7 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
     if (!g) {
         const std::string cf = program_cache_file(graph_data, graph_data_len);  // (SHA-256 of the image: once per graph and process)
         std::vector<uint8_t> blob;
-        if (!cf.empty() && read_file(cf, blob) && check_device().empty()) {  // a program an earlier process compiled for this very image
+        if (!cf.empty() && read_file(cf, blob)) {  // a program an earlier process compiled for this very image (the import checks for a device behind its host work)
             gwb_graph_t* imported = nullptr;
             gw_status_t st2{OK, nullptr};
             if (gwb_graph_import(blob.data(), blob.size(), &imported, &st2) == 0) g.reset(imported);
@@ -1851,16 +1932,21 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
             printf("input %s, offset %u, len %u\n", kv.first.c_str(), s.offset, s.len);
         }
     uint32_t st = 0;
+    const double t_graph = now_ms();
+    double t_device = t_graph;
     {
         std::lock_guard<std::mutex> lk(g->mu);
+        (void)pick_tile_width(g.get(), 1);  // host work first: a new graph's program is compiled while warm_device's thread brings the device up
         err = check_device();
+        t_device = now_ms();
         if (err.empty()) err = run_host(g.get(), row.data(), 1, wit.data(), &st);
     }
     if (!err.empty()) return fail(status, "Failed to calculate witness: " + err);
-    if (getenv("CWC_DEBUG_SINGLE")) {  // diagnostic: kernel times of this call
+    if (dbg_single) {
         gwb_timing_t tm;
         if (gwb_last_timing(g.get(), &tm) == 0)
-            fprintf(stderr, "gw_calc_witness: program key %#x, %llu bundles, interpreter %.2f ms, pack %.2f ms\n", g->last_key, (unsigned long long)tm.n_bundles, tm.interp_ms, tm.pack_ms);
+            fprintf(stderr, "gw_calc_witness: program key %#x, %llu bundles, interpreter %.2f ms, pack %.2f ms | inputs %.1f ms, graph handle + input row %.1f ms, program choice + device check %.1f ms, upload + run %.1f ms\n",
+                    g->last_key, (unsigned long long)tm.n_bundles, tm.interp_ms, tm.pack_ms, t_inputs - t_in, t_graph - t_inputs, t_device - t_graph, now_ms() - t_device);
     }
     // The program for the on-disk cache: the one the background search settled on (the quick first program is not worth
     // keeping).  Written by whichever call first finds the search finished.
