@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "gwb_host_alloc", "gwb_host_free", "gwb_timing_history", "gwb_calc_witness_batch_handoff", "gwb_ubench_modmul", "gwb_graph_pick_tile_width", "gwb_graph_broadcast",
     "gwb_builder_new", "gwb_builder_free", "gwb_builder_input", "gwb_builder_constant", "gwb_builder_uno", "gwb_builder_duo", "gwb_builder_tres",
     "gwb_builder_witness", "gwb_builder_input_signal", "gwb_builder_node_count", "gwb_builder_finish",
-    "gwb_ubench_modmul_block", "gwb_program_stats", "gwb_calc_witness_json_to_wtns",
+    "gwb_ubench_modmul_block", "gwb_program_stats", "gwb_calc_witness_json_to_wtns", "gwb_model_class_cycles",
 ]
 
 
@@ -140,6 +140,8 @@ def lib():
         L.gwb_ubench_modmul.restype = ctypes.c_double
         L.gwb_ubench_modmul.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         L.gwb_ubench_modmul_block.restype = ctypes.c_double
+        L.gwb_model_class_cycles.restype = ctypes.c_double
+        L.gwb_model_class_cycles.argtypes = [ctypes.c_uint32]
         L.gwb_ubench_modmul_block.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         L.gwb_program_stats.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ProgramStats)]
         L.gwb_calc_witness_json_to_wtns.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz, ctypes.POINTER(sz), vp, sz, ctypes.POINTER(E2eStats), stp]
@@ -195,6 +197,12 @@ def ubench_modmul(waves_per_simd=4, iters=2000, block=False):
     if block:
         return float(lib().gwb_ubench_modmul_block(waves_per_simd, iters))
     return float(lib().gwb_ubench_modmul(waves_per_simd, iters))
+
+
+def model_cycles():
+    """The cost model's lone-wave cycles per bundle class as the library loaded them ({class name: cycles};
+    gwb_model_class_cycles): built-in, CWC_MODEL_CYCLES, or the calibration file of tools/gpu_calibrate.py."""
+    return {n: float(lib().gwb_model_class_cycles(c)) for c, n in enumerate(CLASS_NAMES)}
 
 
 def pick_tile_width(batch):

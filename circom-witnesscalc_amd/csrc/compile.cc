@@ -659,27 +659,72 @@ static const double kCyclesMacroFront = 660, kCyclesMacroStage[4] = {0, 1150, 12
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves
 static const double kCyclesFusedStageMul = 760, kCyclesFusedStageLin = 300;
-// (CWC_MODEL_CYCLES="class:cycles,..." overrides entries: what-if runs of the cost model and same-box recalibration)
+// The table above was measured on one box.  Overrides, read once when the library is loaded: CWC_MODEL_CYCLES=
+// "class:cycles,..." (what-if runs of the cost model), else the calibration file tools/gpu_calibrate.py --write leaves
+// behind after measuring the classes on the machine at hand with the stamped interpreter build -- CWC_MODEL_CYCLES_FILE, or
+// model_cycles.txt in the program cache's directory (CWC_PROGRAM_CACHE / XDG_CACHE_HOME / ~/.cache/circom-witnesscalc-amd;
+// no directory, no file).  Same "class:cycles,..." text; entries outside [0.25, 4] x the built-in value are ignored.
 struct CycleTable {
     double v[C_COUNT];
+    bool from_file = false;
+    void parse(const char* e, bool bounded) {
+        while (*e) {
+            char* end = nullptr;
+            const long c = strtol(e, &end, 10);
+            if (end == e || *end != ':') break;
+            const double cyc = strtod(end + 1, &end);
+            if (c >= 0 && c < (long)C_COUNT && cyc > 0 && (!bounded || (cyc >= 0.25 * kCyclesDefault[c] && cyc <= 4.0 * kCyclesDefault[c]))) v[c] = cyc;
+            while (*end == ' ' || *end == '\n' || *end == '\r') ++end;
+            e = *end == ',' ? end + 1 : end;
+            if (*end != ',') break;
+        }
+    }
     CycleTable() {
         for (int c = 0; c < (int)C_COUNT; ++c) v[c] = kCyclesDefault[c];
         if (const char* e = getenv("CWC_MODEL_CYCLES")) {
-            while (*e) {
-                char* end = nullptr;
-                const long c = strtol(e, &end, 10);
-                if (end == e || *end != ':') break;
-                const double cyc = strtod(end + 1, &end);
-                if (c >= 0 && c < (long)C_COUNT && cyc > 0) v[c] = cyc;
-                e = *end == ',' ? end + 1 : end;
-                if (*end != ',') break;
+            parse(e, false);
+            return;
+        }
+        std::string path;
+        if (const char* f = getenv("CWC_MODEL_CYCLES_FILE")) {
+            path = f;
+        } else {
+            std::string dir;
+            if (const char* e = getenv("CWC_PROGRAM_CACHE")) {
+                if (*e && strcmp(e, "0") && strcmp(e, "off")) dir = e;
+                else return;
+            } else if (const char* x = getenv("XDG_CACHE_HOME")) {
+                if (*x) dir = std::string(x) + "/circom-witnesscalc-amd";
             }
+            if (dir.empty()) {
+                const char* home = getenv("HOME");
+                if (!home || !*home) return;
+                dir = std::string(home) + "/.cache/circom-witnesscalc-amd";
+            }
+            path = dir + "/model_cycles.txt";
+        }
+        if (FILE* f = fopen(path.c_str(), "rb")) {
+            char buf[1024];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            parse(buf, true);
+            from_file = true;
         }
     }
     double operator[](int c) const { return v[c]; }
 };
 static const CycleTable kCycles;
 double model_class_cycles(int c) { return c >= 0 && c < (int)C_COUNT ? kCycles[c] : 0.0; }
+// a word that changes with the table: programs are chosen (and cached on disk) under one table
+uint64_t model_table_id() {
+    uint64_t h = 1469598103934665603ull;
+    for (int c = 0; c < (int)C_COUNT; ++c) {
+        const uint64_t x = (uint64_t)(kCycles[c] * 16.0);
+        h = (h ^ x) * 1099511628211ull;
+    }
+    return h;
+}
 static uint32_t div_cost50() { return (uint32_t)(kCycles[C_DIV] / 50.0); }
 // (round 2, bigint-class graph with every operand and result canonical: BIT 2 650, IDIVMOD 2 880, CMPS 1 900 net of stamps)
 static const double kCyclesBitStraight = 1500;  // what a Shr-only / Band-only bundle saves against the per-lane select over all bit operations

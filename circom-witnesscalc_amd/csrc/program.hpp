@@ -78,6 +78,7 @@ static inline uint32_t key_mode_of_divider(uint32_t divider) { return divider ==
 double program_wave_cycles(const Program& p);
 double program_wave_cycles_mul_div(const Program& p);
 double model_class_cycles(int bundle_class);  // the table behind both (lone-wave shader cycles per bundle of a class)
+uint64_t model_table_id();                     // changes with that table (built-in, CWC_MODEL_CYCLES, or the calibration file)
 
 // Structural check of a program from outside compile_program (imported blob): every offset, index and LDS address the
 // kernels take from it lies inside the tile / LDS / input geometry.

@@ -960,7 +960,11 @@ std::string program_cache_file(const void* graph_data, size_t len) {
         if (!home || !*home) return "";
         dir = std::string(home) + "/.cache/circom-witnesscalc-amd";
     }
-    static const std::string build = sha256_hex((const uint8_t*)(__DATE__ " " __TIME__ " format 13"), sizeof(__DATE__ " " __TIME__ " format 13") - 1).substr(0, 12);
+    // (this build, the program format, the cost model's cycle table: a program is chosen under one table)
+    static const std::string build = []() {
+        const std::string id = std::string(__DATE__ " " __TIME__ " format 14 table ") + std::to_string((unsigned long long)model_table_id());
+        return sha256_hex((const uint8_t*)id.data(), id.size()).substr(0, 12);
+    }();
     return dir + "/" + sha256_hex((const uint8_t*)graph_data, len) + "-" + build + ".cwcprog";
 }
 bool read_file(const std::string& path, std::vector<uint8_t>& out) {
@@ -1532,6 +1536,7 @@ int gwb_calc_witness_batch_handoff(gwb_graph_t* g, const void* d_inputs, size_t 
 static double ubench_modmul(uint32_t waves_per_simd, uint32_t iters, bool block_multiplier);
 double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters) { return ubench_modmul(waves_per_simd, iters, false); }
 double gwb_ubench_modmul_block(uint32_t waves_per_simd, uint32_t iters) { return ubench_modmul(waves_per_simd, iters, true); }
+double gwb_model_class_cycles(uint32_t bundle_class) { return model_class_cycles((int)bundle_class); }
 static double ubench_modmul(uint32_t waves_per_simd, uint32_t iters, bool block_multiplier) {
     // chip-wide one-lane Montgomery products per second with `waves_per_simd` waves on every SIMD (bench.py's compute
     // ceiling, measured in the same run); 0 on failure

@@ -193,6 +193,9 @@ double gwb_ubench_modmul(uint32_t waves_per_simd, uint32_t iters);
 /* ... and with the multiplier of the interpreter's full-width bundles (one asm block, 322 issue slots, pinned accumulators:
  * waves_per_simd 1 or 2): the denominator of bench.py's `roofline.compute`. */
 double gwb_ubench_modmul_block(uint32_t waves_per_simd, uint32_t iters);
+/* The cost model's lone-wave cycles per bundle of a class (program_dev.h BundleClass), as loaded: built-in, or overridden by
+ * CWC_MODEL_CYCLES / the calibration file (tools/gpu_calibrate.py --write; csrc/compile.cc CycleTable).  0 for an unknown class. */
+double gwb_model_class_cycles(uint32_t bundle_class);
 
 /* Statistics of a compiled program (program_key 0: the program the last batch call on this handle used). */
 typedef struct {

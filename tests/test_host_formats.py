@@ -518,6 +518,30 @@ def test_schedule_quality_guard(pkg):
     assert pe.Blob(g.export_blob(1)).n_bundles <= 5600
 
 
+def test_cost_table_calibration_file(pkg, tmp_path):
+    """The cost model's cycle table is read once at load time: built-in values, CWC_MODEL_CYCLES, or the calibration file
+    tools/gpu_calibrate.py --write leaves behind (CWC_MODEL_CYCLES_FILE / model_cycles.txt beside the program cache).
+    Entries far from the built-in value and unknown classes are ignored; the environment string wins over the file."""
+    import subprocess
+    f = tmp_path / "model_cycles.txt"
+    f.write_text("1:2100,2:750,99:5,3:1,11:1400\n")
+    code = "import sys; sys.path.insert(0, %r); import cwc_import; m = cwc_import.load().model_cycles(); print(m['MUL'], m['LIN'], m['DIV'], m['MULQ'])" % ROOT
+    env = dict(os.environ)
+    env.pop("CWC_MODEL_CYCLES", None)
+    env.pop("CWC_MODEL_CYCLES_FILE", None)
+    base = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120).stdout.split()
+    assert base == ["2015.0", "706.0", "55000.0", "1306.0"], base
+    got = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, CWC_MODEL_CYCLES_FILE=str(f)), timeout=120).stdout.split()
+    assert got == ["2100.0", "750.0", "55000.0", "1400.0"], got
+    got = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, CWC_MODEL_CYCLES_FILE=str(f), CWC_MODEL_CYCLES="1:1900"), timeout=120).stdout.split()
+    assert got == ["1900.0", "706.0", "55000.0", "1306.0"], got
+    # the default place: model_cycles.txt in the program cache's directory
+    (tmp_path / "cache").mkdir()
+    (tmp_path / "cache" / "model_cycles.txt").write_text("2:800")
+    got = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, CWC_PROGRAM_CACHE=str(tmp_path / "cache")), timeout=120).stdout.split()
+    assert got == ["2015.0", "800.0", "55000.0", "1306.0"], got
+
+
 def test_reference_graph_check_tool(pkg):
     """tools/check_reference_graph.py -- the one command a maintainer with cargo runs on a reference-built `.bin` (readers
     agree, writer reproduces the bytes, witness equals the oracle's, `.wtns` equals the reference's) -- on the one pair

@@ -31,9 +31,16 @@ python bench.py --config 4 --cpu-sample 0 > $O/bench_config4_$R.json 2> $O/bench
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 1 --cpu-sample 0 \
     > $O/bench_dist1_$R.json 2> $O/bench_dist1_$R.err
 python tools/gpu_host_path.py > $O/hostpath_$R.log 2>&1
+python tools/gpu_calibrate.py > $O/calibration_$R.log 2>&1
+CWC_MACRO=1 SOAK_SEEDS=1500 SOAK_BASE=20261005 python tools/gpu_soak.py > $O/soak_macro_$R.log 2>&1
+bash tools/gpu_policies.sh "X=0 --" "CWC_MACRO=1 --" "X=0 -- --batch-per-gpu 256" "CWC_MACRO=1 -- --batch-per-gpu 256" "X=0 -- --batch-per-gpu 512" "CWC_MACRO=1 -- --batch-per-gpu 512" > $O/macro_ab_$R.log 2>&1
+CWC_MACRO=1 PROBE_T=258 python tools/gpu_classprof.py > $O/classprof_macro_$R.log 2>&1
+CWC_MACRO=1 PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_macro_$R.log 2>&1
 rm -rf /tmp/cwc_cache_$R; CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 python tools/gpu_single_shot.py > $O/single_shot_$R.log 2>&1
 echo "---- second process, program cache warm" >> $O/single_shot_$R.log
 CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 SHOTS=6 python tools/gpu_single_shot.py >> $O/single_shot_$R.log 2>&1
+echo "---- third process, no cache, where the first call's time goes" >> $O/single_shot_$R.log
+CWC_PROGRAM_CACHE=0 CWC_DEBUG_SINGLE=1 SHOTS=2 python tools/gpu_single_shot.py >> $O/single_shot_$R.log 2>&1
 BIGINT_ROUNDS=4000 PROBE_T=0 python tools/gpu_bigint.py > $O/config5_$R.log 2>&1
 python bench.py --config 5 --cpu-sample 32 > $O/bench_config5_$R.json 2> $O/bench_config5_$R.err
 python tools/gpu_streams.py > $O/streams_$R.log 2>&1
