@@ -271,7 +271,17 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     uint32_t h_cur = hdr[B0], h_n1 = hdr[clampb(B0 + 1)];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_wave0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-    uint32_t hdr_off_n2 = 4u * B0 + 8u;  // byte offset of the header two bundles ahead
+    // The header an iteration needs -- bundle b + 2's -- is fetched by the iteration before it, right behind that iteration's
+    // wait for its LDS reads, and retired by this iteration's wait a bundle's arithmetic later: a miss of the scalar cache
+    // (one per 64-byte line of headers, ~1 000 cycles when awaited at once) costs nothing.
+    // CWC_HDR_LANDING: the load lands in XNACK_MASK_LO, an SGPR the compiler never allocates (the kernels are built without
+    // XNACK and the hardware does not use the mask then).  A pending scalar load in a register the compiler knows about does
+    // not survive: it copies a loop-carried asm output between registers before the data has arrived (66 of 298 sites when
+    // tried).  The iteration moves the header out behind its wait and issues the next fetch in one statement.  The compiler's
+    // own counted LDS waits stay safe with one scalar load it does not know of in flight: the true count is never below the
+    // one it assumes.  (The header array is padded: no clamp.)
+    asm volatile("s_load_dword xnack_mask_lo, %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "s"(hdr), "s"(4u * B0 + 8u) : "memory");
+    uint32_t hdr_off_n2 = 4u * B0 + 12u;  // byte offset of the header the first iteration fetches (for the second)
     Fr r_prev = fr_zero();  // results of the previous bundle, stored one iteration late (first iteration: zeros -> trash slot)
     uint32_t doff_prev = trash_doff;
     for (uint32_t b = B0; b < NBND; ++b) {
@@ -292,12 +302,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint2 aq = *reinterpret_cast<const uint2*>(ldsb + (la & 0xffffu) + coop_chunk);  // (for linear riders)
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
-                uint32_t h_n2;
-                asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-                hdr_off_n2 += 4u;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(aq.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(aq.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
+                asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+                hdr_off_n2 += 4u;
                 CWC_STAMP(st2);
                 stage_operands(b + 2, rec_n2);
                 stage_rec(b + 4);
@@ -348,12 +358,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint2 x3q = *reinterpret_cast<const uint2*>(ldsb + (lx >> 16) + coop_chunk);          // third stage: an addition
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
-                uint32_t h_n2;
-                asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-                hdr_off_n2 += 4u;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(x2_full.v[0]), "v"(x2_full.v[4]), "v"(x2q.x), "v"(x3q.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(x2_full.v[0]), "v"(x2_full.v[4]), "v"(x2q.x), "v"(x3q.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
+                asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+                hdr_off_n2 += 4u;
                 stage_operands(b + 2, rec_n2);
                 stage_rec(b + 4);
                 uint32_t out[2];
@@ -405,12 +415,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 for (uint32_t k = 0; k < MACRO_STAGES; ++k) rk[k] = *reinterpret_cast<const uint2*>(recb + 16u * T * k);
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
-                uint32_t h_n2;
-                asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-                hdr_off_n2 += 4u;
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(rk[0].x), "v"(rk[1].x), "v"(rk[2].x), "v"(rk[3].x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(rk[0].x), "v"(rk[1].x), "v"(rk[2].x), "v"(rk[3].x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+                uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
+                asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+                hdr_off_n2 += 4u;
                 CWC_STAMP(m1);
                 // the operands of every stage (what an earlier stage of this bundle produces comes from the accumulator, or is
                 // read again in front of its stage): the staging loads of bundle b + 2 overwrite this bundle's cells below
@@ -523,15 +533,15 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // header of bundle b+2: a scalar load issued behind the LDS reads and retired with them by the wait below (left
         // to the compiler it lands after the staging loads, and its whole latency in front of the arithmetic: the
         // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
-        uint32_t h_n2;
-        asm volatile("s_load_dword %0, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");  // (the header array is padded: no clamp)
-        hdr_off_n2 += 4u;
         // results of bundle b-1 -> tile (unconditional: values without a slot and inactive node slots go to the tile's
         // trash slot; a fixed number of vector-memory operations per bundle is what makes the counted wait possible)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
         // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2] / REC[b mod 4]
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h_n2) : "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+        uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
+        asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+        hdr_off_n2 += 4u;
         CWC_STAMP(st2);
         stage_operands(b + 2, rec_n2);
         stage_rec(b + 4);
