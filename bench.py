@@ -295,6 +295,8 @@ def extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, o
         if cfg == 2:
             out["pcie_inclusive"] = host_path_point(pkg, g, rows, d_out)
             out["json_front_end"] = json_front_end_point(wl, g)
+            if wl.source != "CWC_GRAPH_BIN":
+                out["single_shot"] = single_shot_point(pkg, wl)
             t0 = time.perf_counter()
             out["e2e_json_to_wtns"] = e2e_json_to_wtns_point(wl, g)
             log("e2e_json_to_wtns: %.1f s" % (time.perf_counter() - t0))
@@ -332,6 +334,42 @@ def host_path_point(pkg, g, rows, d_out):
             best = dt if best is None or dt < best else best
         res[name] = {"value": rows.shape[0] / best, "ms_per_step": best * 1e3, "matches_device_path": bool(np.array_equal(wit, want))}
     return res
+
+
+def single_shot_point(pkg, wl, shots=12):
+    """Informational only (never `value`): the reference's own entry point gw_calc_witness (one input set per call, graph
+    image and inputs JSON in, `.wtns` bytes out; reference lib.rs:125-136) on the reference's authV2 input file.  The first
+    call on a graph parses and compiles it (a quick program; the search for the best one runs in the background and the
+    calls switch over when it is done); later calls find the handle by the image's bytes.  The on-disk program cache is off
+    for this record (CWC_PROGRAM_CACHE=0 in its child process) so that the first call is a real one."""
+    import subprocess
+    code = (
+        "import sys, time, json, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import cwc_import\n"
+        "pkg = cwc_import.load()\n"
+        "from oracle import cbind\n"
+        "data = pkg.graphgen.circuits.build_authv2_class().to_bin()\n"
+        "js = open(os.path.join(%r, 'tests', 'golden', 'circuit9_authV2_inputs.json')).read()\n"
+        "ms = []\n"
+        "for i in range(%d):\n"
+        "    t0 = time.perf_counter(); w = pkg.calc_witness_wtns(js, data); ms.append((time.perf_counter() - t0) * 1e3)\n"
+        "    if i < 6: time.sleep(0.4)\n"
+        "import numpy as np\n"
+        "og = cbind.Graph(data)\n"
+        "row = np.asarray(pkg.Graph(data).inputs_from_json(js), dtype=np.uint8).reshape(1, og.n_inputs, 32)\n"
+        "want, st = og.evaluate_batch(row)\n"
+        "ok = bool(st[0] == 0 and w == cbind.wtns_from_witness(want[0]))\n"
+        "print(json.dumps({'ms': ms, 'ok': ok, 'bytes': len(w)}))\n") % (ROOT, ROOT, shots)
+    env = dict(os.environ, CWC_PROGRAM_CACHE="0")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # (a sub-record: its failure is reported, not fatal)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    warm = sorted(rec["ms"][-5:])
+    return {"unit": "ms per gw_calc_witness call", "first_call_ms": rec["ms"][0], "warm_call_ms_median_of_last_5": warm[2], "calls_ms": [round(x, 2) for x in rec["ms"]],
+            "wtns_bytes": rec["bytes"], "matches_oracle_wtns": rec["ok"], "note": "own process; first call includes the device runtime's start-up"}
 
 
 def rows_to_ndjson(g_inputs, rows):

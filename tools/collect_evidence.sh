@@ -15,6 +15,9 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$R -o runc -- $BENCH > $O/pmc_fetch_$
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$R -o runc -- $BENCH > $O/pmc_write_$R.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
     -d $O/pmc_sq_$R -o runc -- $BENCH > $O/pmc_sq_$R.log 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_icache_$R -o runc -- $BENCH > $O/pmc_icache_$R.log 2>&1
+rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ SQ_INSTS_SMEM -d $O/pmc_dcache_$R -o runc -- $BENCH > $O/pmc_dcache_$R.log 2>&1
+python tools/pmc_cache_summary.py $R > $O/cache_counters_$R.log 2>&1
 PROBE_T=258,2,4 python tools/gpu_classprof.py > $O/classprof_$R.log 2>&1
 PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 PROBE_GRAPH=bigint PROBE_B=32 PROBE_T=1 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1

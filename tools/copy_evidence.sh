@@ -24,6 +24,7 @@ cp $O/soak_$R.log $P/${R}_soak.txt
 cp $O/soak_fused_$R.log $P/${R}_soak_fused.txt
 cp $O/policies_$R.log $P/${R}_policies.txt
 cp $O/calibration_$R.log $P/${R}_calibration.txt
+cp $O/cache_counters_$R.log $P/${R}_cache_counters.txt
 cp $O/soak_macro_$R.log $P/${R}_soak_macro.txt
 cp $O/macro_ab_$R.log $P/${R}_macro_ab.txt
 cp $O/classprof_macro_$R.log $P/${R}_classprof_macro.txt
