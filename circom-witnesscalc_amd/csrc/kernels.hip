@@ -302,6 +302,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint2 aq = *reinterpret_cast<const uint2*>(ldsb + (la & 0xffffu) + coop_chunk);  // (for linear riders)
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
+                stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(aq.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
@@ -310,7 +311,6 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 hdr_off_n2 += 4u;
                 CWC_STAMP(st2);
                 stage_operands(b + 2, rec_n2);
-                stage_rec(b + 4);
                 CWC_STAMP(st3);
                 uint32_t out[2];
                 if (h & (HDR_LIN_ADD | HDR_LIN_SUB)) {  // linear nodes ride in groups of their own (ctrl sub-op per record)
@@ -358,6 +358,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint2 x3q = *reinterpret_cast<const uint2*>(ldsb + (lx >> 16) + coop_chunk);          // third stage: an addition
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
+                stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(x2_full.v[0]), "v"(x2_full.v[4]), "v"(x2q.x), "v"(x3q.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
@@ -365,7 +366,6 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
                 hdr_off_n2 += 4u;
                 stage_operands(b + 2, rec_n2);
-                stage_rec(b + 4);
                 uint32_t out[2];
                 fr_mul_coop4(a_op, bq.x, bq.y, nq0, nq1, out);
                 const uint32_t op2 = mx & CTRL_SUB_MASK, op3 = xx & CTRL_SUB_MASK;
@@ -535,16 +535,16 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
         // results of bundle b-1 -> tile (unconditional: values without a slot and inactive node slots go to the tile's
         // trash slot; a fixed number of vector-memory operations per bundle is what makes the counted wait possible)
+        stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
-        // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2] / REC[b mod 4]
+        // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2]
         asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
         uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
         asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
         hdr_off_n2 += 4u;
         CWC_STAMP(st2);
         stage_operands(b + 2, rec_n2);
-        stage_rec(b + 4);
         CWC_STAMP(st3);
 
         const uint32_t cls = h & HDR_CLASS_MASK;
