@@ -109,6 +109,30 @@ def test_terncond_and_inputs_ge_r(pkg):
     assert [cbind.array_to_ints(o)[2] for o in got] == [0, 5, ((1 << 256) - 1) % M]
 
 
+def test_terncond_third_operand_fresh_from_the_previous_bundles(pkg):
+    """TernCond's third operand is loaded in place, from memory, in the iteration that runs the node (kernels.hip C_TERN) --
+    also when the bundle right in front of it produced the value, whose store is issued at the top of that same iteration.
+    Chains in which every selection's third operand is one, two or three operations old, at every tile width and with
+    divider waves, against the oracle (round 3 found that a direct-to-LDS staging load issued in the iteration of the store
+    it depends on reads stale data; this is the one place where a load follows its store that closely)."""
+    rnd = random.Random(79)
+    b = Builder()
+    (c,) = b.input("c")
+    xs = b.input("x", 6)
+    one, k = b.const(1), b.const(12345)
+    for lag in (1, 2, 3):
+        for x in xs:
+            hist = [x]
+            for step in range(40):
+                y = b.add(b.mul(hist[-1], hist[-1]), one)       # fresh value
+                hist.append(y)
+                cond = b.op("Lt", b.op("Band", y, b.const(255)), b.const(128 if step % 2 else 64))
+                z = b.tern(cond if step % 3 else c, k, hist[-min(lag, len(hist))])  # third operand: `lag` operations old
+                hist.append(b.signal(b.add(z, x)))
+    rows = [[1] + [rnd.choice([0, 1, rnd.randrange(M)])] + [rnd.randrange(M) for _ in range(6)] for _ in range(70)]
+    _check(pkg, b.to_bin(), rows, tiles=(1, 2, 4, 8, 16, 32, 64, 2 | DIVIDER, 8 | DIVIDER, 1 | 0x1000, 4 | 0x800))
+
+
 def test_golden_fixtures_through_gw_calc_witness(pkg):
     """The reference's drop-in symbol, byte-compared with committed `.wtns` digests (from the big-int model)."""
     data = open(os.path.join(GOLD, "circuit1.bin"), "rb").read()
