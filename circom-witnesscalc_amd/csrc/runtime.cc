@@ -301,8 +301,10 @@ std::string check_device() {
 // take: measured x1.3 for the multiplier / inversion bundles (issue-bound, two waves overlap well) and x1.9 for the
 // rest (LDS / vector-memory bound), i.e. x1.28-1.36 for the authV2-class graph and x1.75-2.0 for sha256; beyond 2048
 // waves they run in rounds.  A divider wave per interpreter counts as a wave of its CU but idles about half of the time
-// (x1.33 measured at 1024 pairs); one divider per four interpreters means five-wave workgroups, one per CU (LDS): x1.23
-// at 1024 tiles, rounds of 1024 tiles beyond.  (profiles/r01_sweep_batch_tile.txt)
+// (x1.33 measured at 1024 pairs); one divider per four interpreters means five-wave workgroups, one per CU (LDS): x1.30
+// at 1024 tiles (measured / modelled 1.19-1.26 in rounds 2 and 3 against 1.11-1.25 for the pair programs: at x1.23 the model
+// took T = 2 + group divider for 2048 sets, 6 % behind T = 4 + pairs in both rounds' sweeps), rounds of 1024 tiles beyond.
+// (profiles/r01_sweep_batch_tile.txt, r03_sweep_batch_tile.txt)
 double estimate_cycles(const Program& p, size_t batch) {
     // (tiles of 8 sets and more: their bundles measure ~10 % above the per-class table, which was taken at T = 2 --
     // round 2, authV2-class: 8192 sets T = 4 41.2 ms, T = 8 44.2 ms, T = 8 + group divider 45.0 ms; 16384 sets T = 8 69.2 ms)
@@ -328,7 +330,7 @@ double estimate_cycles(const Program& p, size_t batch) {
     const double heavy = program_wave_cycles_mul_div(p) * wide;
     const double waves = (double)((batch + p.T - 1) / p.T);
     const double two_per_simd = (1.3 * heavy + 1.9 * (per_wave - heavy)) / per_wave;
-    if (p.divider == 4) return per_wave * 1.23 * (waves <= 1024 ? 1.0 : waves / 1024);
+    if (p.divider == 4) return per_wave * 1.30 * (waves <= 1024 ? 1.0 : waves / 1024);
     // three interpreters + their divider = a four-wave workgroup, one per CU: every wave has its SIMD up to 768 tiles;
     // the shared divider costs 8 % against a divider per interpreter (measured at 512 tiles: 16.8 vs 15.6 ms)
     if (p.divider == 3) return per_wave * 1.08 * (waves <= 768 ? 1.0 : two_per_simd * (waves <= 1536 ? 1.0 : waves / 1536));
