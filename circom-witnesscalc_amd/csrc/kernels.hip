@@ -538,14 +538,18 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
-        // every LDS read above must have completed before the loads below overwrite STAGE[b mod 2]
-        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
         uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
-        asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-        hdr_off_n2 += 4u;
-        CWC_STAMP(st2);
-        stage_operands(b + 2, rec_n2);
-        CWC_STAMP(st3);
+        unsigned long long st2 = 0, st3 = 0;
+        // the wait for the LDS reads and what must follow it: every read must have completed before the staging loads overwrite
+        // STAGE[b mod 2].  A lambda because the linear class runs it behind its own branch (below), the rest in line.
+        auto wait_and_stage = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
+            asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
+            hdr_off_n2 += 4u;
+            if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st2)::"memory");
+            stage_operands(b + 2, rec_n2);
+            if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st3)::"memory");
+        };
 
         const uint32_t cls = h & HDR_CLASS_MASK;
         // the two classes that are 97 % of the bundles are tested first, on a copy the compiler cannot fold into the
@@ -598,6 +602,24 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // booleans in the form the bundle's users read: Montgomery (2^256 mod r) or the canonical integer 1 (evaluated in the
         // classes that produce booleans only: in front of the dispatch it costs every bundle ten issue slots)
         auto one_out = [&]() -> Fr { return (h & HDR_OUT_CANON) ? Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}} : fr_one(); };
+        // The linear class branches off in front of the wait: its taken branch (~50 cycles for a lone wave) then runs in the
+        // shadow of the LDS reads; the multiplier stays the fall-through behind the wait.
+        if (cls_hot2 == C_LIN) {
+            wait_and_stage();
+            // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
+            // uniform (header bits); a mixed one computes both and selects per lane.
+            if (!(h & HDR_LIN_SUB)) {
+                r = fr_add_wave(a_op, b_op, pv);
+            } else if (!(h & HDR_LIN_ADD)) {
+                r = fr_sub_wave(a_op, b_op, pv);
+            } else {
+                const unsigned long long subm = __ballot(sub == SUB_SUB);
+                r = fr_addsub_wave(a_op, b_op, pv, sub == SUB_SUB ? ~0u : 0u, subm, ~subm);
+            }
+            finish(r);
+            continue;
+        }
+        wait_and_stage();
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
             r = fr_mul_wave(a_op, b_op, pv);
             // linear nodes riding in this bundle's free node slots (graph.rs:110-111)
@@ -608,20 +630,6 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 r = u256_select(sub == SUB_ADD, fr_add_wave(a_op, b_op, pv), r);
             } else if (h & HDR_LIN_SUB) {
                 r = u256_select(sub == SUB_SUB, fr_sub_wave(a_op, b_op, pv), r);
-            }
-            finish(r);
-            continue;
-        }
-        if (__builtin_expect(cls_hot2 == C_LIN, 1)) {
-            // graph.rs:110-111 Add/Sub; Neg (:188-194) arrives as 0 - a (0 - 0 = 0, else r - a).  Most bundles are
-            // uniform (header bits); a mixed one computes both and selects per lane.
-            if (!(h & HDR_LIN_SUB)) {
-                r = fr_add_wave(a_op, b_op, pv);
-            } else if (!(h & HDR_LIN_ADD)) {
-                r = fr_sub_wave(a_op, b_op, pv);
-            } else {
-                const unsigned long long subm = __ballot(sub == SUB_SUB);
-                r = fr_addsub_wave(a_op, b_op, pv, sub == SUB_SUB ? ~0u : 0u, subm, ~subm);
             }
             finish(r);
             continue;
