@@ -292,7 +292,18 @@ std::string check_device() {
     if (e != hipSuccess || n <= 0)
         return std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
                "); this library has no CPU fallback";
-    return "";
+    // The interpreter parks a pending scalar load in XNACK_MASK, which the hardware owns when XNACK (retry on page fault) is
+    // enabled: such a device is refused instead of risking a corrupted replay.  (Asked once per process.)
+    static const std::string xnack_refusal = []() -> std::string {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return "";
+        }
+        return strstr(prop.gcnArchName, "xnack+") ? std::string("device ") + prop.gcnArchName + ": XNACK-enabled devices are not supported (run with HSA_XNACK=0)" : "";
+    }();
+    return xnack_refusal;
 }
 
 // Cost model behind the automatic program choice.  A wave's time is the sum of its bundles (lone-wave shader cycles
