@@ -866,10 +866,19 @@ std::string set_status_text(uint32_t bits) {
 // does its host work first and touches the device last (it then waits on the runtime's own locks for what is left).
 // Errors are left to the calling thread's own checks.
 void warm_device() {
+    // (joined when the process exits -- an error return may leave the caller free to exit while the runtime is still
+    // coming up on this thread; the holder is made on first use, so it is destroyed before the runtime's own statics)
+    struct Joined {
+        std::thread t;
+        ~Joined() {
+            if (t.joinable()) t.join();
+        }
+    };
+    static Joined warm;
     static std::once_flag once;
     std::call_once(once, []() {
         if (getenv("CWC_NO_WARM_THREAD")) return;
-        std::thread([]() {
+        warm.t = std::thread([]() {
             int n = 0;
             if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
                 (void)hipGetLastError();
@@ -879,7 +888,7 @@ void warm_device() {
             if (hipMalloc(&p, 4096) == hipSuccess) (void)hipFree(p);
             else (void)hipGetLastError();
             if (launch_warm(nullptr) != hipSuccess) (void)hipGetLastError();
-        }).detach();
+        });
     });
 }
 
