@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <functional>
 #include <chrono>
+#include <deque>
+#include <mutex>
 #include <unordered_map>
 
 #include "flat_map.hpp"
@@ -196,15 +198,24 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
     std::vector<uint64_t> rt;                 // earliest finish time of each new node (unbounded width)
     rt.reserve(N + N / 4);
     h.nodes.reserve(N + N / 4);
-    size_t n_add = 0, n_mul = 0;
-    for (const Node& n : g.nodes) {
-        n_add += n.kind == N_DUO && n.op == OP_ADD;
-        n_mul += n.kind == N_DUO && n.op == OP_MUL;
-    }
-    FlatMap128 vn[2] = {FlatMap128(n_add + n_add / 4), FlatMap128(n_mul + n_mul / 4)};  // value numbering of Add (0) / Mul (1) nodes by operand pair
+    // Value numbering of the Add / Mul nodes by operand pair (x <= y).  Not one big hash table: the tables of a
+    // multi-million-node graph are far larger than the caches and every probe was a miss (2.4 per node; 10.5 M nodes:
+    // 3.7 of the compile's 7.5 s).  Instead every node y heads a list, per operation, of the nodes whose larger operand
+    // it is -- y was read a moment ago (its ready time), the list's members were made after it: the lookups stay in
+    // the caches.  A list that grows beyond kListMax (one value combined with very many earlier ones) moves into a
+    // hash table of its own kind, so the walk stays bounded.
+    struct Link { uint32_t head[2], next; };
+    const uint32_t NIL = 0xffffffffu, kListMax = 24;
+    std::vector<Link> link;
+    link.reserve(N + N / 4);
+    std::vector<uint8_t> hashed;  // bit 0 / 1: node y's Add / Mul list lives in `overflow`
+    hashed.reserve(N + N / 4);
+    FlatMap64 overflow[2] = {FlatMap64(1024), FlatMap64(1024)};
     auto emit = [&](const Node& n, uint64_t t) -> uint32_t {
         h.nodes.push_back(n);
         rt.push_back(t);
+        link.push_back(Link{{NIL, NIL}, NIL});
+        hashed.push_back(0);
         return (uint32_t)(h.nodes.size() - 1);
     };
     for (size_t i = 0; i < N; ++i)  // constants first (rewrite_pow2_divisions appends some behind their users)
@@ -212,13 +223,29 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
     auto is_ac = [&](uint32_t idx, uint8_t op) { return h.nodes[idx].kind == N_DUO && h.nodes[idx].op == op; };
     auto combine = [&](uint8_t op, uint32_t x, uint32_t y) -> uint32_t {  // shared (op, x, y) node
         if (x > y) std::swap(x, y);
+        const int k = op == OP_MUL;
         const uint64_t key = ((uint64_t)x << 32) | y;
-        auto& table = vn[op == OP_MUL];
+        const uint64_t cost = class_cost[k ? C_MUL : C_LIN];
         uint32_t idx;
-        if (table.find(key, 0, &idx)) return idx;
-        const uint64_t cost = class_cost[op == OP_MUL ? C_MUL : C_LIN];
+        if (hashed[y] & (1u << k)) {
+            if (overflow[k].find(key, &idx)) return idx;
+            idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
+            overflow[k].find_or_insert(key, idx, nullptr);
+            return idx;
+        }
+        uint32_t len = 0;
+        for (idx = link[y].head[k]; idx != NIL; idx = link[idx].next, ++len)
+            if (h.nodes[idx].a == x) return idx;
         idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
-        table.find_or_insert(key, 0, idx, nullptr);
+        if (len >= kListMax) {  // the list moves into the hash table, this node with it
+            for (uint32_t q = link[y].head[k]; q != NIL; q = link[q].next) overflow[k].find_or_insert(((uint64_t)h.nodes[q].a << 32) | y, q, nullptr);
+            overflow[k].find_or_insert(key, idx, nullptr);
+            hashed[y] |= (uint8_t)(1u << k);
+            link[y].head[k] = NIL;
+        } else {
+            link[idx].next = link[y].head[k];
+            link[y].head[k] = idx;
+        }
         return idx;
     };
     // A node inside a chain -- its one user is a node of the same operation and it is no witness element -- needs no tree
@@ -770,12 +797,24 @@ struct RewriteCache {
     struct Entry {
         bool bit_fusion;
         const uint32_t* table;  // kClassCost / kClassCostNarrow (before the linear-heavy switch and the A/B overrides)
+        uint32_t G;             // (the tree-height reduction's leaf bound follows it)
         Graph g;
         ProgramStats st;
         const uint32_t* class_cost;
     };
-    std::vector<Entry> entries;
+    std::deque<Entry> entries;  // (a deque: entries stay where they are while other threads append)
+    std::mutex* lock = nullptr; // set when the compiles of several threads share the cache
 };
+struct SharedRewrites {  // one cache and one lock per tile width 1, 2, .. 64: compiles of different widths do not wait for each other
+    std::mutex m[7];
+    RewriteCache cache[7];
+};
+SharedRewrites* make_shared_rewrites() {
+    SharedRewrites* s = new SharedRewrites();
+    for (int i = 0; i < 7; ++i) s->cache[i].lock = &s->m[i];
+    return s;
+}
+void free_shared_rewrites(SharedRewrites* s) { delete s; }
 static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, bool bit_fusion, const CoopPolicy& policy, Program& out, std::string& err,
                             RewriteCache* cache = nullptr, bool probe_only = false, uint32_t streams = 1);
 
@@ -786,7 +825,7 @@ bool probe_graph(const Graph& g, Program& out, std::string& err) { return compil
 // up in bundles: the program is compiled with and without the bit-extract fusion, then under a few narrow-bundle
 // policies, and the cheapest schedule by the measured cycles per bundle class (program_wave_cycles) is kept -- the
 // policies are not fitted to one graph, the cost model picks per graph and tile width.
-bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams, bool quick) {
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams, bool quick, SharedRewrites* shared) {
     const uint32_t G = T ? 64 / T : 1;
     CoopPolicy base{G, ~0u};  // narrow whenever everything ready fits
     if (const char* e = getenv("CWC_COOP_FILL")) base.fill = (uint32_t)atol(e);
@@ -796,7 +835,8 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     if (const char* e = getenv("CWC_WITNESS_SLOTS")) base.witness_slots = atoi(e) != 0;
     // macro bundles (merge_macros): opt-in, CWC_MACRO=1 (measured slower than the separate narrow bundles, see kCyclesMacroFront)
     if (getenv("CWC_MACRO") && atoi(getenv("CWC_MACRO")) != 0) base.macro = true;
-    RewriteCache cache;
+    RewriteCache own_cache;
+    RewriteCache& cache = shared && T >= 1 && T <= 64 && !(T & (T - 1)) ? shared->cache[__builtin_ctz(T)] : own_cache;
     if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) return false;
     if (quick || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;  // (quick: the first call on a graph runs this one schedule while the search runs in the background)
     // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
@@ -864,9 +904,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     }
     const uint32_t* weight_table = policy.fill && T <= 2 ? kClassCostNarrow : kClassCost;
     const RewriteCache::Entry* hit = nullptr;
+    // (a shared cache: whoever comes first rewrites with the lock held, the others wait for the entry)
+    std::unique_lock<std::mutex> cache_lock;
+    if (cache && cache->lock) cache_lock = std::unique_lock<std::mutex>(*cache->lock);
     if (cache)
         for (const auto& e : cache->entries)
-            if (e.bit_fusion == bit_fusion && e.table == weight_table) hit = &e;
+            if (e.bit_fusion == bit_fusion && e.table == weight_table && e.G == 64 / T) hit = &e;
     // validate operand order on the graph as loaded, then work on a rewritten copy
     for (size_t i = 0; !hit && i < g_in.nodes.size(); ++i) {
         const Node& n = g_in.nodes[i];
@@ -881,6 +924,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
     }
     Graph g = hit ? hit->g : g_in;
+    if (hit && cache_lock.owns_lock()) cache_lock.unlock();
     // CWC_DEBUG_COMPILE_TIMES=1: seconds per phase on stderr
     const bool phase_times = getenv("CWC_DEBUG_COMPILE_TIMES") != nullptr;
     auto t_phase = std::chrono::steady_clock::now();
@@ -1014,8 +1058,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         N = g.nodes.size();
     }
     for (const Node& n : g.nodes) st.n_op_compiled += arity_of(n) ? 1 : 0;
-    if (cache && class_cost != cost_override) cache->entries.push_back(RewriteCache::Entry{bit_fusion, weight_table, g, st, class_cost});
+    if (cache && class_cost != cost_override) cache->entries.push_back(RewriteCache::Entry{bit_fusion, weight_table, G, g, st, class_cost});
     }  // (!hit)
+    if (cache_lock.owns_lock()) cache_lock.unlock();
 
     phase("rewrites");
     // ---- one form per value: Montgomery or canonical (inserts the conversions; see infer_representations) ----
@@ -1628,6 +1673,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         s_chain[stream_of[i]] = std::max(s_chain[stream_of[i]], cp[i]);
                     }
             } else {
+                // one part only: the program would be the one-stream program of the same key.  Among the candidates of a
+                // choice (shared rewrites) that sibling is being compiled anyway: refuse, the caller drops this key
+                // (10.5 M nodes: half of the choice's compile work).
+                if (cache && cache->lock) {
+                    err = "the graph has one independent part: a stream program would equal the one-stream program";
+                    return false;
+                }
                 std::fill(prologue.begin(), prologue.end(), 0);
             }
         }
@@ -2208,11 +2260,16 @@ struct BlobHeader {
     ProgramStats stats;
 };
 
-std::vector<uint8_t> program_to_blob(const Program& p) {
+size_t program_blob_size(const Program& p) {
+    return sizeof(BlobHeader) + 4 * (p.hdr.size() + p.recs.size() + p.crefs.size() + p.consts.size() + p.witness_refs.size() + p.div_lanes.size());
+}
+
+// the blob at dst (program_blob_size(p) bytes): what gwb_graph_export writes straight into the caller's buffer
+void program_blob_write(const Program& p, uint8_t* dst) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 14;
+    h.version = 15;  // (15: the exported image's trailer carries blob_checksum instead of FNV-1a; the program layout is 14's)
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -2223,9 +2280,18 @@ std::vector<uint8_t> program_to_blob(const Program& p) {
         h.stream_cycles[s] = p.stream_cycles[s]; h.stream_cycles_mul_div[s] = p.stream_cycles_mul_div[s]; h.stream_chain_cycles[s] = p.stream_chain_cycles[s];
     }
     h.stats = p.stats;
-    std::vector<uint8_t> out((uint8_t*)&h, (uint8_t*)&h + sizeof h);
-    auto put = [&](const std::vector<uint32_t>& v) { out.insert(out.end(), (const uint8_t*)v.data(), (const uint8_t*)(v.data() + v.size())); };
+    memcpy(dst, &h, sizeof h);
+    dst += sizeof h;
+    auto put = [&](const std::vector<uint32_t>& v) {
+        if (!v.empty()) memcpy(dst, v.data(), 4 * v.size());
+        dst += 4 * v.size();
+    };
     put(p.hdr); put(p.recs); put(p.crefs); put(p.consts); put(p.witness_refs); put(p.div_lanes);
+}
+
+std::vector<uint8_t> program_to_blob(const Program& p) {
+    std::vector<uint8_t> out(program_blob_size(p));
+    program_blob_write(p, out.data());
     return out;
 }
 
@@ -2233,7 +2299,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 14 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 15 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

@@ -59,7 +59,14 @@ struct Program {
 // parts; divider 0 or 1 only).
 // quick: one schedule (the base policy) instead of the search over schedule variants: a tenth of the compile time, a few percent
 // more cycles.
-bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams = 1, bool quick = false);
+// `shared`: the rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) does not depend on the
+// divider mode or the stream count -- candidates of one choice (pick_tile_width) hand the same holder to their compiles,
+// the first one through rewrites, the others copy (make_shared_rewrites / free_shared_rewrites; thread-safe).
+struct SharedRewrites;
+SharedRewrites* make_shared_rewrites();
+void free_shared_rewrites(SharedRewrites*);
+bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out, std::string& err, uint32_t streams = 1, bool quick = false,
+                     SharedRewrites* shared = nullptr);
 // Validation and statistics of a loaded graph without compiling a program: out.stats, out.n_inputs, out.n_witness.
 bool probe_graph(const Graph& g, Program& out, std::string& err);
 // "program key" used by the runtime and the C-ABI wherever a tile width is passed: T | KEY_DIVIDER | KEY_GROUP
@@ -86,6 +93,8 @@ bool validate_program(const Program& p, std::string& err);
 
 // pointer-free serialisation (what is broadcast between GPUs)
 std::vector<uint8_t> program_to_blob(const Program& p);
+size_t program_blob_size(const Program& p);
+void program_blob_write(const Program& p, uint8_t* dst);  // (program_blob_size(p) bytes at dst)
 bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string& err);
 
 }  // namespace cwc

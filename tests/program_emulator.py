@@ -36,6 +36,21 @@ MACRO_STAGES, HDR_M_KIND_SHIFT, HDR_M_LATE_SHIFT, HDR_M_GATHER_SHIFT = 4, 19, 26
 MCTRL_OP_MASK, MCTRL_A_ACC, MCTRL_ACTIVE, MCTRL_B_ACC, MCTRL_MASK = 3, 4, 8, 16, 31
 
 
+def blob_checksum(body):
+    """The trailer checksum of an exported image (runtime.cc blob_checksum): position-dependent sum over 64-bit words."""
+    import numpy as np
+    K1, K2, K3, M = 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, (1 << 64) - 1
+    n = len(body)
+    w = np.frombuffer(bytes(body) + b"\0" * (-n % 8), dtype="<u8")
+    with np.errstate(over="ignore"):
+        x = (w ^ (np.arange(len(w), dtype=np.uint64) * np.uint64(K1))) * np.uint64(K2)
+        x ^= x >> np.uint64(29)
+        h = (int(x.sum(dtype=np.uint64)) + n * K3) & M
+    h ^= h >> 32
+    h = (h * K1) & M
+    return h ^ (h >> 29)
+
+
 class Blob:
     def __init__(self, data):
         h = struct.unpack_from(HDR_FMT, data, 0)

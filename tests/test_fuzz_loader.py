@@ -97,11 +97,7 @@ def test_corrupted_program_blobs_are_rejected(pkg):
             with pytest.raises(pkg.WitnessCalcError, match="bad blob|bad program blob"):
                 pkg.Graph.from_blob(bytes(d))
         # a hostile sender: consistent checksum, damaged contents -> the structural validation has to catch it
-        def refnv(body):
-            h = 1469598103934665603
-            for byte in body:
-                h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-            return h
+        from tests.program_emulator import blob_checksum as refnv
         body, (exact, padded, _) = bytearray(blob[:-24]), struct.unpack("<3Q", blob[-24:])
         hits = 0
         for _ in range(120):
@@ -140,11 +136,7 @@ def test_stream_programs_are_validated_for_every_stream(pkg):
     import struct
     from tests import program_emulator as E
 
-    def refnv(body):
-        h = 1469598103934665603
-        for byte in body:
-            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-        return h
+    refnv = E.blob_checksum
     g = pkg.Graph(C.build_random_dag(11, n_ops=150, parts=4).to_bin())
     blob = g.export_blob(1 | 0x1000)
     bl = E.Blob(blob)

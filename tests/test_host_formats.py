@@ -311,6 +311,41 @@ def test_macro_bundles_are_exact(pkg, monkeypatch):
     assert pe.Blob(pkg.Graph(C.build_poseidon(2).to_bin()).export_blob(4)).stats["class_bundles"][14] == 0
 
 
+def test_value_numbering_lists_and_overflow(pkg):
+    """The tree-height reduction numbers its Add / Mul nodes through per-node lists (compile.cc reduce_tree_height: the
+    nodes whose larger operand a value is), and a value combined with more than 24 earlier ones moves into a hash table.
+    A late value multiplied with / added to 60 inputs, every pair twice and in both operand orders, summed in long chains
+    that the reduction opens: duplicates merge, and the emulator gives the reference's witnesses for every tile width."""
+    from tools.graphgen.builder import Builder
+    rnd = random.Random(5)
+    b = Builder()
+    xs = b.input("in", 60)
+    y = b.add(b.mul(xs[0], xs[1]), xs[2])          # made after every input: the larger operand of what follows
+    prods = [b.mul(x, y) for x in xs] + [b.mul(y, x) for x in xs]
+    sums = [b.add(y, x) for x in xs] + [b.add(x, y) for x in xs]
+    acc = prods[0]
+    for t in prods[1:] + sums:
+        acc = b.add(acc, t)
+    b.signal(acc)
+    acc2 = sums[3]
+    for t in sums[4:40]:
+        acc2 = b.mul(acc2, t)
+    b.signal(acc2)
+    for t in (prods[7], prods[67], sums[9], sums[69], y):
+        b.signal(t)
+    data = b.to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    g = pkg.Graph(data)
+    for key in (1, 2, 8, 64):
+        blob = pe.Blob(g.export_blob(key))
+        if key != 64:   # x * y and y * x are one node, and so are x + y and y + x (T = 64 keeps the reference's node order)
+            assert blob.stats["n_op_compiled"] < len([n for n in nodes if n[0] not in ("Const", "Input")]) - 50
+        for _ in range(2):
+            row = [1] + [rnd.randrange(model.M) for _ in range(blob.n_inputs - 1)]
+            got, st = pe.run(blob, row)
+            assert st == 0 and got == model.evaluate(nodes, row, wit)
+
+
 def test_slot_reuse_keeps_workspace_small(pkg):
     b = C.build_poseidon(2)
     g = pkg.Graph(b.to_bin())
