@@ -82,6 +82,7 @@ EXPORTED_SYMBOLS = [
     "gwb_builder_new", "gwb_builder_free", "gwb_builder_input", "gwb_builder_constant", "gwb_builder_uno", "gwb_builder_duo", "gwb_builder_tres",
     "gwb_builder_witness", "gwb_builder_input_signal", "gwb_builder_node_count", "gwb_builder_finish",
     "gwb_ubench_modmul_block", "gwb_program_stats", "gwb_calc_witness_json_to_wtns", "gwb_model_class_cycles",
+    "gwb_kernel_source_hash",
 ]
 
 
@@ -141,6 +142,8 @@ def lib():
         L.gwb_ubench_modmul.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         L.gwb_ubench_modmul_block.restype = ctypes.c_double
         L.gwb_model_class_cycles.restype = ctypes.c_double
+        L.gwb_kernel_source_hash.restype = ctypes.c_char_p
+        L.gwb_kernel_source_hash.argtypes = []
         L.gwb_model_class_cycles.argtypes = [ctypes.c_uint32]
         L.gwb_ubench_modmul_block.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
         L.gwb_program_stats.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ProgramStats)]
@@ -197,6 +200,11 @@ def ubench_modmul(waves_per_simd=4, iters=2000, block=False):
     if block:
         return float(lib().gwb_ubench_modmul_block(waves_per_simd, iters))
     return float(lib().gwb_ubench_modmul(waves_per_simd, iters))
+
+
+def kernel_source_hash():
+    """SHA-256 of the kernel sources the loaded library's device code was built from (gwb_kernel_source_hash)."""
+    return lib().gwb_kernel_source_hash().decode()
 
 
 def model_cycles():

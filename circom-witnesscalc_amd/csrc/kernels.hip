@@ -1019,6 +1019,14 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     return hipGetLastError();
 }
 
+// The content hash of this file and of what it includes, as the Makefile computed it when this compile started
+// (build/kernels.srchash): tests/test_host_formats.py compares it with the sources in the tree -- an object that was built
+// from something else (a source restored while its compile was running) does not pass for the current kernels again.
+#ifndef CWC_KSRC_HASH
+#define CWC_KSRC_HASH "unstamped"
+#endif
+extern "C" const char* gwb_kernel_source_hash() { return CWC_KSRC_HASH; }
+
 // An empty kernel of this code object: its first launch makes the runtime load the object (every interpreter instance) --
 // the single-shot entry point does that on a thread of its own while the host parses and compiles (runtime.cc warm_device).
 __global__ void warm_kernel() {}

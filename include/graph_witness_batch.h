@@ -196,6 +196,9 @@ double gwb_ubench_modmul_block(uint32_t waves_per_simd, uint32_t iters);
 /* The cost model's lone-wave cycles per bundle of a class (program_dev.h BundleClass), as loaded: built-in, or overridden by
  * CWC_MODEL_CYCLES / the calibration file (tools/gpu_calibrate.py --write; csrc/compile.cc CycleTable).  0 for an unknown class. */
 double gwb_model_class_cycles(uint32_t bundle_class);
+/* SHA-256 (hex) of the kernel sources the loaded library's device code was built from, as stamped by csrc/Makefile
+ * ("unstamped" for a build outside it): lets a deployment or a test tell a stale kernel object from the tree's. */
+const char* gwb_kernel_source_hash(void);
 
 /* Statistics of a compiled program (program_key 0: the program the last batch call on this handle used). */
 typedef struct {

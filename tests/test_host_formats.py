@@ -346,6 +346,18 @@ def test_value_numbering_lists_and_overflow(pkg):
             assert st == 0 and got == model.evaluate(nodes, row, wit)
 
 
+def test_library_kernels_match_the_sources(pkg):
+    """The device code of the in-tree library was built from the kernel sources in the tree: the Makefile stamps the
+    content hash of kernels.hip and its includes into the object (gwb_kernel_source_hash), and prints the same hash of
+    the files as they are now.  (Round 3: a kernels.o newer than kernels.hip but built from an abandoned variant -- the
+    source had been restored while its compile was running -- travelled to the GPU box and cost 2-9 %.)"""
+    import subprocess
+    csrc = os.path.join(os.path.dirname(pkg.LIB_PATH), "csrc")
+    now = subprocess.run(["make", "-s", "-C", csrc, "print-ksrc-hash"], capture_output=True, text=True, check=True).stdout.strip()
+    assert len(now) == 64
+    assert pkg.kernel_source_hash() == now, "libcircom_witnesscalc_amd.so holds kernels of other sources: run make"
+
+
 def test_slot_reuse_keeps_workspace_small(pkg):
     b = C.build_poseidon(2)
     g = pkg.Graph(b.to_bin())
