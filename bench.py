@@ -17,12 +17,19 @@ line on rank 0.  Outside `value`, the same line carries (N = 1 unless said other
   config4_per_gpu    BASELINE config 4's per-GPU share: 8192 authV2-class sets, sampled sets against the oracle
   config4            (every N) the config-4 job itself: a global batch of 8192 x N sets, contiguous shards, per-set checksums
                      of all ranks hashed and compared with the same job recomputed on rank 0 alone
+  config5            BASELINE config 5 at its named size: the 10.5 M-node bigint / long_div-class graph, 32 sets on this GPU
+                     (generation ~10 s, compile ~6 s, 3 timed steps, 4 sets against the oracle = its CPU baseline sample)
   json_front_end     sets/s of the batched NDJSON -> rows front-end
   e2e_json_to_wtns   NDJSON -> `.wtns` files on tmpfs through the streaming pipeline (parse | kernels | D2H slices | writers)
   pcie_inclusive     the host-buffer entry point (never `value`)
 
-`--config 3` / `--config 4` make one of those the timed `value` instead; CWC_GRAPH_BIN=<file.bin> runs a real graph
-(synthetic inputs by its input count) in place of the generated authV2-class one.
+`--config 3` / `--config 4` / `--config 5` make one of those the timed `value` instead; CWC_GRAPH_BIN=<file.bin> runs a
+real graph (synthetic inputs by its input count) in place of the generated authV2-class one.
+
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself: a CHILD `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` spawned before anything touches a GPU, its JSON line relayed (never an exec).  `--dry-run`
+runs the same multi-rank flow on CPU (gloo, the program emulator of tests/ instead of the kernels, a toy graph): what the
+world-size-2 test of the launch path uses.
 """
 import argparse
 import hashlib
@@ -77,7 +84,7 @@ class Workload:
             self.source = "CWC_GRAPH_BIN"
         else:
             # (bigint: BASELINE config 5's shape -- 32 limbs x 4000 rounds of multiply / long-divide / compare = 10.5 M nodes,
-            # depth 1.29 M; about two minutes of generation and graph compilation in front of the timed steps)
+            # depth 1.29 M; ~10 s of generation and ~6 s of graph compilation in front of the timed steps)
             builder = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else C.build_bigint_class(k=32, rounds=4000)
             nodes, wit, self.inputs = builder.finalize()
             self.stats = graph_stats(nodes, wit)
@@ -125,6 +132,137 @@ def kernel_times(g, steps):
     return tm, interp_ms * tm["n_launches"], pack_ms * tm["n_launches"]
 
 
+class Watchdog:
+    """Ends the process (exit code 3, message on stderr) when the guarded block has not finished after `seconds`: a rank that
+    never arrives at a collective (RCCL communicator, gwb_graph_broadcast) must fail the job, not hang it -- the launcher then
+    ends the other ranks.  Never re-execs anything."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.what, self.seconds = what, seconds
+
+    def fire(self):
+        try:
+            os.write(2, ("bench.py: watchdog: %s did not finish within %.0f s (rank %s); exiting\n" % (self.what, self.seconds, os.environ.get("RANK", "0"))).encode())
+        finally:
+            os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def self_launch(n, argv, real_stdout):
+    """`python bench.py --gpus N` (N > 1, no RANK): the ranks are started by a child `python -m torch.distributed.run` -- the
+    same command line the driver would use -- and its stdout (rank 0's one JSON line) is relayed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out, _ = p.communicate()
+    line = None
+    for ln in out.decode("utf-8", "replace").splitlines():  # (the launcher may print warnings of its own on stdout)
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            log(ln)
+    if line is not None:
+        os.write(real_stdout, (line + "\n").encode())
+    elif p.returncode == 0:
+        log("bench.py: the ranks exited 0 without a JSON line")
+        return 4
+    return p.returncode
+
+
+def dry_run(args, real_stdout):
+    """CPU rehearsal of the distributed bench (world-size-N flow without a GPU): gloo process group, a toy graph (the gadget
+    graph: every op class), rank 0 compiles the cost model's program for a shard and broadcasts the blob, every rank
+    evaluates ITS shard of one global batch on the program emulator (tests/program_emulator.py -- the test suite's model
+    of the interpreter; the product has no CPU path), per-set checksums are gathered and hashed, rank 0 recomputes the job
+    alone.  The line has the shape of the real one; its numbers are not measurements of anything."""
+    import cwc_import
+    pkg = cwc_import.load()
+    from circom_witnesscalc_amd import dist as cdist
+    from tools.synth import synth_inputs
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import program_emulator as pe
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if distributed:
+        dist.init_process_group("gloo")
+    per = args.batch_per_gpu or 6
+    total = per * world
+    blob, key = b"", 0
+    if rank == 0:
+        g = pkg.Graph(pkg.graphgen.circuits.build_gadgets().to_bin())
+        key = g.pick_tile_width(per)   # host-only: the cost model needs no device
+        blob = g.export_blob(key)
+    if distributed:
+        with Watchdog(float(os.environ.get("BENCH_BCAST_TIMEOUT", "120")), "program broadcast (gloo)"):
+            blob = cdist.broadcast_blob(blob, src=0, device="cpu")
+    prog = pe.Blob(blob)
+
+    def evaluate(lo, hi):
+        rows = synth_inputs("field", prog.n_inputs, hi - lo, SEED + 4, lo)
+        wit = np.zeros((hi - lo, prog.n_witness, 32), dtype=np.uint8)
+        bad = 0
+        for k in range(hi - lo):
+            vals, status = pe.run(prog, [int.from_bytes(rows[k, q].tobytes(), "little") for q in range(prog.n_inputs)])
+            bad += status != 0
+            if status == 0:
+                wit[k] = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32)
+        return cdist.set_checksums(torch.from_numpy(wit)), bad
+    lo, hi = cdist.shard_range(total, rank, world)
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        cs, bad = evaluate(lo, hi)
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        te = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+        parts = [torch.empty(cdist.shard_range(total, r, world)[1] - cdist.shard_range(total, r, world)[0], dtype=torch.int64) for r in range(world)]
+        dist.all_gather(parts, cs)
+        cs_all = torch.cat(parts)
+        group_ranks = dist.get_world_size()
+    else:
+        cs_all, group_ranks = cs, 1
+    if rank == 0:
+        digest = hashlib.sha256(cs_all.numpy().tobytes()).hexdigest()
+        single = hashlib.sha256(evaluate(0, total)[0].numpy().tobytes()).hexdigest()
+        steps = max(1, args.steps)
+        out = {"metric": "witnesses/sec", "value": total * steps / elapsed, "unit": "witnesses/s", "n_gpus": world, "steps": steps, "warmup": 0,
+               "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "python int",
+               "data": "synthetic", "dry_run": True,
+               "config": {"workload": "DRY RUN on CPU: gadget graph, %d sets per rank on the program emulator (launch-path rehearsal, not a measurement)" % per,
+                          "tile_width": prog.T, "parallelism": "contiguous shards of one global batch x%d, program blob broadcast over gloo" % world},
+               "rccl_ranks": None, "group_ranks": group_ranks, "program_key": key, "digest_of_set_checksums": digest, "single_gpu_digest": single,
+               "matches_single_gpu_digest": digest == single, "sets_with_error_status": int(bad)}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     # Everything except the final JSON line goes to stderr (RCCL prints a version banner on stdout at init).
     sys.stdout.flush()
@@ -142,7 +280,14 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0 = only the timed metric (no sub-records)")
     ap.add_argument("--extra-batch", type=int, default=None, help=argparse.SUPPRESS)   # (round-1 flags, still accepted)
     ap.add_argument("--host-path", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank flow: gloo, program emulator, toy graph (no GPU, no timing claim)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # One command for the N-GPU run: start the ranks as a CHILD launcher (nothing in this process has touched a GPU:
+        # `import torch` does not initialise one) and relay its line.  Never an exec.
+        sys.exit(self_launch(args.gpus, sys.argv[1:], real_stdout))
+    if args.dry_run:
+        return dry_run(args, real_stdout)
     if args.graph == "sha256" and args.config == 2:
         args.config = 3
     if args.extra_batch == 0 and args.host_path == 0:
@@ -158,7 +303,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d: launch with torch.distributed.run --nproc-per-node == --gpus (or plain `python bench.py --gpus N`, which does that itself)" % (world, args.gpus)
     # under torch.distributed.run (RANK set) the distributed path is taken even with a single rank, so that the
     # RCCL init / program broadcast / import code is exercised on 1-GPU boxes too
     distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
@@ -180,8 +325,10 @@ def main():
     wl = Workload(kind) if rank == 0 else None
     rccl_ranks = None
     if distributed:
-        # the program goes out through the C-ABI collective (gwb_graph_broadcast on a RCCL communicator of this job's ranks)
-        g, rccl_ranks = cdist.broadcast_graph_rccl(pkg, wl.data if rank == 0 else None, args.tile_width, src=0, device=dev, batch_per_rank=B)
+        # the program goes out through the C-ABI collective (gwb_graph_broadcast on a RCCL communicator of this job's ranks);
+        # a rank that never arrives must not hang the job: the watchdog ends this process (non-zero) and the launcher the rest
+        with Watchdog(float(os.environ.get("BENCH_BCAST_TIMEOUT", "120")) + (600 if cfg == 5 else 0), "RCCL communicator / gwb_graph_broadcast"):
+            g, rccl_ranks = cdist.broadcast_graph_rccl(pkg, wl.data if rank == 0 else None, args.tile_width, src=0, device=dev, batch_per_rank=B)
     else:
         g = pkg.Graph(wl.data)
         g.set_tile_width(args.tile_width)
@@ -249,6 +396,11 @@ def main():
                                     "(operands are forwarded on chip: measured traffic is a fraction of the algorithmic bytes)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # the same algorithmic bytes over the whole step (interpreter + pack kernel), and what the counters say
+                         # the memory system really moved over the interpreter's time: the figure that tells how far from the HBM
+                         # roofline this kernel runs (it is bound by instruction issue, see `binding`)
+                         "frac_step": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "hbm_measured_frac": (traffic / avg_interp_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_interp_s * 1e3,
                          "pack_kernel_avg_ms": float(np.mean(pack_ms)),
@@ -310,6 +462,13 @@ def extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, o
             t0 = time.perf_counter()
             out["config4_per_gpu"] = config4_per_gpu_point(pkg, wl, dev)
             log("config4_per_gpu: %.1f s" % (time.perf_counter() - t0))
+        if cfg != 5 and os.environ.get("BENCH_SKIP_CONFIG5") is None:
+            t0 = time.perf_counter()
+            try:
+                out["config5"] = config5_point(pkg, dev)
+            except Exception as e:  # (a sub-record: its failure is reported, not fatal)
+                out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("config5: %.1f s" % (time.perf_counter() - t0))
     if wl is None or wl.kind == "authv2" or world > 1:
         t0 = time.perf_counter()
         rec = config4_job(pkg, cdist, wl, dev, rank, world, distributed)
@@ -442,8 +601,8 @@ def e2e_json_to_wtns_point(wl, g, n=8192):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def timed_batch(g, d_in, d_out, d_st, steps=3):
-    g.set_tile_width(0)
+def timed_batch(g, d_in, d_out, d_st, steps=3, key=0):
+    g.set_tile_width(key)
     g.calc_witness_batch_device(d_in, d_out, d_st)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -509,6 +668,41 @@ def config4_per_gpu_point(pkg, wl, dev, batch=8192):
             "tile_width": tm["tile_width"], "interpreter_waves_per_divider_wave": tm["divider"], "launches": tm["n_launches"],
             "roofline_frac": achieved / HBM_PEAK_GBS, "sets_with_error_status": int((d_st != 0).sum().item()),
             "matches_oracle": bool(np.array_equal(got, want) and not st.any()), "sets_checked_against_oracle": len(sample)}
+
+
+def config5_point(pkg, dev, batch=32, steps=3, cpu_sample=4):
+    """BASELINE config 5 at its named size: the 10.5 M-node bigint / long_div-class graph (32 limbs x 4000 rounds), 32 input
+    sets on one GPU (256 over 8), library-chosen program.  `cpu_sample` sets against the oracle as whole witnesses -- the same
+    sets are the CPU baseline's sample (one pinned core, then every core)."""
+    from oracle import cbind
+    t0 = time.perf_counter()
+    wl = Workload("bigint")
+    t_gen = time.perf_counter() - t0
+    g = pkg.Graph(wl.data)
+    rows = make_inputs(wl, g, batch, 5)
+    t0 = time.perf_counter()
+    key = g.pick_tile_width(batch)
+    g.set_tile_width(key)
+    blob_len = len(g.export_blob(key))   # (compiles the chosen program on the host; the blob is what a multi-GPU job broadcasts)
+    t_compile = time.perf_counter() - t0
+    d_in = torch.from_numpy(rows).to(dev)
+    d_out = torch.empty((batch, g.n_witness, 32), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(batch, dtype=torch.int32, device=dev)
+    dt, tm, interp_ms, pack_ms = timed_batch(g, d_in, d_out, d_st, steps=steps, key=key)
+    cpu = None
+    if cpu_sample > 0 and CPU_SAMPLE > 0:
+        cpu = cpu_baseline(wl.data, rows, d_out, min(cpu_sample, batch), parse_reps=1, all_cores_sets=batch)
+        cpu["gpu_over_one_core"] = (batch / dt) / cpu["value"]
+        if "all_cores" in cpu:
+            cpu["gpu_over_all_cores"] = (batch / dt) / cpu["all_cores"]["value"]
+    ps = g.program_stats()
+    return {"workload": "%s, %d nodes, %d input sets on one GPU (BASELINE config 5: 256 sets over 8 GPUs)" % (wl.name, g.n_nodes, batch),
+            "value": batch / dt, "unit": "witnesses/s", "ms_per_step": dt * 1e3, "steps": steps, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms,
+            "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth, "tile_width": tm["tile_width"],
+            "bundles": tm["n_bundles"], "slots": tm["n_slots"], "generate_seconds": t_gen, "compile_and_export_seconds": t_compile,
+            "program_bytes": blob_len, "class_bundles": ps["class_bundles"], "lanes_active_mean": ps["lanes_active_mean"],
+            "field_ops_per_sec": batch / dt * g.n_op, "sets_with_error_status": int((d_st != 0).sum().item()),
+            "cpu_baseline": cpu, "matches_oracle": (cpu or {}).get("matches_gpu"), "sets_checked_against_oracle": min(cpu_sample, batch) if cpu else 0}
 
 
 def config4_job(pkg, cdist, wl, dev, rank, world, distributed, per_gpu=8192):
@@ -592,7 +786,7 @@ def committed_traffic(graph_kind, batch, tile_width):
     return best, src or "none: no committed PMC profile matches this graph / batch / tile width"
 
 
-def cpu_baseline(graph_data, rows, d_out, n):
+def cpu_baseline(graph_data, rows, d_out, n, parse_reps=3, all_cores_sets=None):
     """The oracle's C restatement of the reference evaluate() (sequential, scalar 4x64 Montgomery, one core),
     timed on a bounded sample of the same input sets; also cross-checks those sets against the GPU witnesses."""
     from oracle import cbind
@@ -619,16 +813,17 @@ def cpu_baseline(graph_data, rows, d_out, n):
            "seconds": t, "matches_gpu": bool(np.array_equal(got[ok], want[ok])) if got is not None else None}
     # reported beside it: the reference really re-parses the .bin per call (lib.rs:129) ...
     t0 = time.perf_counter()
-    for _ in range(3):
+    for _ in range(parse_reps):
         cbind.Graph(graph_data)
-    t_parse = (time.perf_counter() - t0) / 3
+    t_parse = (time.perf_counter() - t0) / parse_reps
     out["including_parse_per_call"] = {"value": 1.0 / (t / n + t_parse), "unit": "witnesses/s", "parse_seconds": t_parse}
     # ... and a courtesy upper bound: the same loop on every host core (the reference is single-threaded)
     cores = len(aff) if aff else (os.cpu_count() or 1)
     if cores > 1:
-        tt, want_mt, st_mt = cbind.time_batch_threads(og, rows[:n], cores)
-        out["all_cores"] = {"value": n / tt, "unit": "witnesses/s", "cores": cores, "seconds": tt,
-                            "matches_one_core": bool(np.array_equal(want_mt, want) and np.array_equal(st_mt, st))}
+        m = min(all_cores_sets or n, rows.shape[0])  # (graphs that take a core a third of a second per set: more sets than the one-core sample)
+        tt, want_mt, st_mt = cbind.time_batch_threads(og, rows[:m], cores)
+        out["all_cores"] = {"value": m / tt, "unit": "witnesses/s", "cores": cores, "threads_with_work": min(m, cores), "sets": m, "seconds": tt,
+                            "matches_one_core": bool(np.array_equal(want_mt[:n], want) and np.array_equal(st_mt[:n], st))}
     return out
 
 

@@ -41,13 +41,13 @@ class ProgramStats(ctypes.Structure):
                 ("values_per_bundle_mean", ctypes.c_double)]
 
 
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "MACRO"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "SCAN"]
 
 
 class E2eStats(ctypes.Structure):
     _fields_ = [("n_sets", ctypes.c_size_t), ("sub_batch", ctypes.c_size_t), ("parse_threads", ctypes.c_uint32), ("write_threads", ctypes.c_uint32),
                 ("parse_seconds", ctypes.c_double), ("wait_for_drain_seconds", ctypes.c_double), ("total_seconds", ctypes.c_double),
-                ("witness_bytes", ctypes.c_uint64)]
+                ("witness_bytes", ctypes.c_uint64), ("failed_sets", ctypes.c_uint64)]
 
 
 class Handoff(ctypes.Structure):
@@ -86,12 +86,16 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-def build(verbose=False):
-    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+def build(verbose=False, diag=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950).  diag=True also builds the diagnostic library
+    (stamped interpreter instances for gwb_profile_classes; the class-profile / calibration tools load it via CWC_LIB_PATH)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"] + (["all", "diag"] if diag else [])
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)
+
+
+DIAG_LIB_PATH = os.path.join(_HERE, "libcircom_witnesscalc_amd_diag.so")
 
 
 def lib():
@@ -339,16 +343,18 @@ class Graph:
         _check(rc, st)
         return rows
 
-    def json_to_wtns(self, text, path_pattern, first_index=0):
+    def json_to_wtns(self, text, path_pattern, first_index=0, with_status=True):
         """End to end, streaming (gwb_calc_witness_json_to_wtns): JSON array / NDJSON text -> one `.wtns` file per input set
-        (path_pattern with one %lu).  Returns (per-set status uint32 [B], stats dict)."""
+        (path_pattern with one %lu); a set with a non-zero status word gets no file.  Returns (per-set status uint32 [B],
+        stats dict); with_status=False passes no status buffer: a failed set then raises."""
         if isinstance(text, str):
             text = text.encode("utf-8")
         n = ctypes.c_size_t()
         cap = max(1, text.count(b"\n") + 1, text.count(b"{"))
         status = np.zeros(cap, dtype=np.uint32)
         es, st = E2eStats(), GwStatus()
-        rc = lib().gwb_calc_witness_json_to_wtns(self._h, text, len(text), path_pattern.encode(), first_index, ctypes.byref(n), status.ctypes.data, cap,
+        rc = lib().gwb_calc_witness_json_to_wtns(self._h, text, len(text), path_pattern.encode(), first_index, ctypes.byref(n),
+                                                  status.ctypes.data if with_status else None, cap if with_status else 0,
                                                   ctypes.byref(es), ctypes.byref(st))
         _check(rc, st)
         return status[:n.value], {k: getattr(es, k) for k, _ in E2eStats._fields_}
@@ -415,8 +421,7 @@ class Graph:
         names = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ"]
         res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
         res["MULF"] = tuple(int(x) for x in out[64:68])
-        res["MACRO"] = tuple(int(x) for x in out[68:72])
-        res["_macro_sections"] = tuple(int(x) for x in out[72:80])
+        res["SCAN"] = tuple(int(x) for x in out[68:72])
         res["_sections"] = {"MUL": tuple(int(x) for x in out[48:54]), "LIN": tuple(int(x) for x in out[56:62])}
         n = int(out[63])
         res["_waves"] = {"n": n, "max_cycles": int(out[54]), "min_cycles": (1 << 40) - int(out[55]) if n else 0,

@@ -27,6 +27,7 @@ static inline uint8_t fused_code(bool sq, uint32_t op2, uint32_t op3) { return (
 static int class_of(const Node& n) {
     switch (n.kind) {
         case N_FUSED: return C_MULF;
+        case N_SCAN: return C_SCAN;
         case N_INPUT: return C_INPUT;
         case N_UNO: return C_LIN;
         case N_TRES: return C_TERN;
@@ -47,6 +48,7 @@ static int class_of(const Node& n) {
 // (a fused node's operands in a, b, c: the factor(s) of its product, then the operands of its second and third stage)
 static int arity_of(const Node& n) {
     if (n.kind == N_FUSED) return fused_sq(n.op) ? 1 + (fused_op2(n.op) ? 1 : 0) + (fused_op3(n.op) ? 1 : 0) : 3;
+    if (n.kind == N_SCAN) return (n.op & SCAN_OP_DIV) ? 3 : 2;  // x, the accumulator coming in, the divisor
     return n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0;
 }
 
@@ -178,7 +180,11 @@ static inline uint64_t cost_of(const uint32_t* table, int c) { return c == (int)
 static inline uint64_t fused_cost50(uint8_t op) {
     return 12u + 15u + (fused_op2(op) == FOP_MUL ? 15u : fused_op2(op) ? 6u : 0u) + (fused_op3(op) ? 6u : 0u);
 }
-static inline uint64_t node_cost(const uint32_t* table, const Node& n) { return n.kind == N_FUSED ? fused_cost50(n.op) : cost_of(table, class_of(n)); }
+// a step of a scan bundle: its share of the bundle's front end and one round of the loop (cycles / 50; kCyclesScan* below)
+static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 30u : 5u; }
+static inline uint64_t node_cost(const uint32_t* table, const Node& n) {
+    return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : cost_of(table, class_of(n));
+}
 
 // Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
 // chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
@@ -491,7 +497,9 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
         const int c = class_of(n);
         uint8_t r = REP_M, f = 0;
         if (ar && !off) {
-            const bool want_c = pref[i] > 0.0f;
+            // (no vote at all -- a value only the witness reads: an integer operation then keeps its canonical result, which saves
+            // its bundle the conversion and lets limb recurrences that end in witness elements run as scan bundles)
+            const bool want_c = pref[i] > 0.0f || (pref[i] == 0.0f && is_integer_class(c));
             auto form_of = [&](uint32_t o, uint8_t if_const) -> uint8_t { return is_const(o) ? if_const : orep[o]; };
             if (is_integer_class(c) || c == C_CMPZ) {
                 if (is_integer_class(c)) {
@@ -560,6 +568,197 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
     }
     for (uint32_t& w : g.witness_signals) w = at[w];
     g.nodes.swap(out);
+}
+
+// ---- scan chains (round 4) ------------------------------------------------------------------------------------------
+// Limb-wise big-integer circuits (RSA / long_div-class: BASELINE config 5) are serial recurrences over canonical integers,
+// one step per limb: the carry chain of a multi-limb sum
+//     t = x_c + carry_c;  limb_c = t mod 2^n (Band after the strength reduction);  carry_{c+1} = t \ 2^n (Shr)
+// and the remainder chain of a long division by one limb
+//     t = rem_c * 2^k + x_c;  q_c = t \ d;  rem_{c+1} = t mod d.
+// Unfused, a step is two or three bundles on the graph's critical chain (Add, then Band + Shr side by side; Mul, Add, then
+// Idiv + Mod), each with ~600 cycles of front end for a few dozen instructions of limb arithmetic: 1.74 M bundles for the
+// 10.5 M-node graph.  A step whose inner nodes nothing else reads becomes a PAIR of N_SCAN nodes -- the step's OUT value
+// (limb / quotient digit) and its ACC value (carry / remainder), both naming the step's operands (a = x, b = the accumulator
+// coming in, c = the divisor) -- and the scheduler places the consecutive steps of a chain in consecutive pairs of node
+// slots of ONE bundle (class C_SCAN, program_dev.h), which runs them with a loop inside the bundle.  Exact: the kernel's
+// step is the same field addition / product and the same integer operations (graph.rs:105, 110-121, 637-687) on the same
+// canonical integers; nothing that can fail is involved (Band with 2^n - 1 stays below 2^253, Shr / Idiv / Mod cannot fail).
+// Only values that representation inference keeps canonical are touched.  scan_imm[node]: CARRY the shift n, DIV the node
+// index of the constant 2^k (its Montgomery form is what the general path multiplies with).
+// scan_partner[node]: the other node of the step.
+static void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner,
+                         uint64_t& n_steps) {
+    const size_t N = g.nodes.size();
+    static const uint32_t NONE = 0xffffffffu;
+    std::vector<uint32_t> uses(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) uses[ops[q]]++;
+    }
+    for (uint32_t w : g.witness_signals) uses[w] += 2;  // (a witness element is never an inner node)
+    // constants: 2^k -> k, 2^n - 1 -> n, small integers
+    auto const_value = [&](uint32_t idx) -> const Fr* { return g.nodes[idx].kind == N_CONST ? &g.const_values[g.nodes[idx].a] : nullptr; };
+    auto pow2_of = [&](uint32_t idx) -> int {
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        int k = -1, bits = 0;
+        for (int w = 0; w < 8; ++w)
+            if (v->v[w]) {
+                bits += __builtin_popcount(v->v[w]);
+                k = 32 * w + __builtin_ctz(v->v[w]);
+            }
+        return bits == 1 && k >= 1 && k <= 253 ? k : -1;
+    };
+    auto mask_of = [&](uint32_t idx) -> int {  // 2^n - 1 -> n
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        int n = 0;
+        bool ended = false;
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t x = v->v[w];
+            if (ended) {
+                if (x) return -1;
+            } else if (x == 0xffffffffu) {
+                n += 32;
+            } else {
+                if (x & (x + 1u)) return -1;
+                n += __builtin_popcount(x);
+                ended = true;
+            }
+        }
+        return n >= 1 && n <= 253 ? n : -1;
+    };
+    auto small_of = [&](uint32_t idx) -> int {  // a shift count
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        for (int w = 1; w < 8; ++w)
+            if (v->v[w]) return -1;
+        return v->v[0] >= 1 && v->v[0] <= 253 ? (int)v->v[0] : -1;
+    };
+    auto canon = [&](uint32_t o) { return g.nodes[o].kind == N_CONST || rep[o] == REP_C; };
+    // the two users of every candidate t: (Band, Shr) or (Idiv, Mod)
+    std::vector<uint32_t> user_out(N, NONE), user_acc(N, NONE);
+    for (size_t j = 0; j < N; ++j) {
+        Node& n = g.nodes[j];
+        if (n.kind != N_DUO) continue;
+        // (value numbering orders the operands of commutative operations by index: the mask may come first)
+        if (n.op == OP_BAND && g.nodes[n.a].kind == N_CONST && g.nodes[n.b].kind != N_CONST) {
+            std::swap(n.a, n.b);
+            vflags[j] = (uint8_t)((vflags[j] & ~(VF_A_CANON | VF_B_CANON)) | ((vflags[j] & VF_A_CANON) ? VF_B_CANON : 0) | ((vflags[j] & VF_B_CANON) ? VF_A_CANON : 0));
+        }
+        if (g.nodes[n.a].kind != N_DUO || g.nodes[n.a].op != OP_ADD) continue;
+        const uint8_t want = VF_A_CANON | VF_B_CANON | VF_OUT_CANON;
+        if ((vflags[j] & want) != want) continue;
+        if (n.op == OP_BAND || n.op == OP_IDIV) user_out[n.a] = user_out[n.a] == NONE ? (uint32_t)j : NONE - 1;
+        else if (n.op == OP_SHR || n.op == OP_MOD) user_acc[n.a] = user_acc[n.a] == NONE ? (uint32_t)j : NONE - 1;
+    }
+    struct Step { uint32_t t, out, acc, x, acc_in, d, imm; bool div; };
+    std::vector<Step> steps;
+    std::vector<uint32_t> step_of_acc(N, NONE);  // ACC node (Shr / Mod) -> step
+    for (size_t t = 0; t < N; ++t) {
+        const uint32_t o = user_out[t], a = user_acc[t];
+        if (o >= NONE - 1 || a >= NONE - 1 || uses[t] != 2 || rep[t] != REP_C) continue;
+        const Node& T_ = g.nodes[t];
+        const Node &O = g.nodes[o], &A = g.nodes[a];
+        if (!canon(T_.a) || !canon(T_.b)) continue;
+        if (O.op == OP_BAND && A.op == OP_SHR) {
+            const int n = small_of(A.b);
+            if (n < 0 || mask_of(O.b) != n) continue;
+            steps.push_back(Step{(uint32_t)t, o, a, T_.a, T_.b, 0, (uint32_t)n, false});
+        } else if (O.op == OP_IDIV && A.op == OP_MOD && O.b == A.b && canon(O.b)) {
+            // t = m + x with m = rem * 2^k read by nothing else
+            int side = -1;
+            for (int q = 0; q < 2 && side < 0; ++q) {
+                const uint32_t m = q ? T_.b : T_.a;
+                const Node& M = g.nodes[m];
+                if (M.kind != N_DUO || M.op != OP_MUL || uses[m] != 1 || rep[m] != REP_C) continue;
+                if ((pow2_of(M.b) >= 0 && canon(M.a) && g.nodes[M.a].kind != N_CONST) || (pow2_of(M.a) >= 0 && canon(M.b) && g.nodes[M.b].kind != N_CONST)) side = q;
+            }
+            if (side < 0) continue;
+            const uint32_t m = side ? T_.b : T_.a, x = side ? T_.a : T_.b;
+            const Node& M = g.nodes[m];
+            const bool base_b = pow2_of(M.b) >= 0 && g.nodes[M.a].kind != N_CONST;
+            steps.push_back(Step{(uint32_t)t, o, a, x, base_b ? M.a : M.b, O.b, base_b ? M.b : M.a, true});
+        }
+    }
+    if (getenv("CWC_DEBUG_SCAN")) {
+        size_t n_band = 0, n_shr = 0, pairs = 0, uses_ok = 0, rep_ok = 0, canon_ok = 0;
+        for (size_t t = 0; t < N; ++t) {
+            n_band += user_out[t] < NONE - 1;
+            n_shr += user_acc[t] < NONE - 1;
+            if (user_out[t] >= NONE - 1 || user_acc[t] >= NONE - 1) continue;
+            ++pairs;
+            uses_ok += uses[t] == 2;
+            rep_ok += rep[t] == REP_C;
+            canon_ok += canon(g.nodes[t].a) && canon(g.nodes[t].b);
+        }
+        fprintf(stderr, "scan detection: %zu Add nodes with an OUT user, %zu with an ACC user, %zu with both; of those uses == 2: %zu, canonical: %zu, canonical operands: %zu; steps %zu\n",
+                n_band, n_shr, pairs, uses_ok, rep_ok, canon_ok, steps.size());
+    }
+    if (steps.empty()) return;
+    for (size_t k = 0; k < steps.size(); ++k) step_of_acc[steps[k].acc] = (uint32_t)k;
+    // CARRY steps: the accumulator is the operand that is another step's carry (so that chains link up); either one at a chain's head
+    for (Step& st : steps) {
+        if (st.div) continue;
+        const uint32_t sx = step_of_acc[st.x], sa = step_of_acc[st.acc_in];
+        const bool x_links = sx != NONE && !steps[sx].div && steps[sx].imm == st.imm, a_links = sa != NONE && !steps[sa].div && steps[sa].imm == st.imm;
+        if (x_links && !a_links) std::swap(st.x, st.acc_in);
+    }
+    // rewrite: OUT and ACC become N_SCAN nodes on the step's operands, the inner nodes (t, m) lose their users
+    std::vector<uint8_t> dead(N, 0);
+    for (const Step& st : steps) {
+        const uint8_t kind = st.div ? SCAN_OP_DIV : 0;
+        g.nodes[st.out] = Node{N_SCAN, kind, st.x, st.acc_in, st.d};
+        g.nodes[st.acc] = Node{N_SCAN, (uint8_t)(kind | SCAN_OP_ACC), st.x, st.acc_in, st.d};
+        vflags[st.out] = vflags[st.acc] = 0;
+        dead[st.t] = 1;
+        if (st.div) dead[g.nodes[st.t].a == st.x ? g.nodes[st.t].b : g.nodes[st.t].a] = 1;
+    }
+    // Node order: a step's nodes sit where Band / Shr (Idiv / Mod) sat, behind t and therefore behind every operand.
+    scan_imm.assign(N, 0);
+    scan_partner.assign(N, NONE);
+    for (const Step& st : steps) {
+        scan_imm[st.out] = scan_imm[st.acc] = st.imm;
+        scan_partner[st.out] = st.acc;
+        scan_partner[st.acc] = st.out;
+    }
+    n_steps += steps.size();
+    // compact (the dead inner nodes would be scheduled)
+    std::vector<uint32_t> pos(N, NONE);
+    std::vector<Node> kept;
+    std::vector<uint8_t> krep, kfl;
+    std::vector<uint32_t> kimm, kpart;
+    kept.reserve(N);
+    krep.reserve(N);
+    kfl.reserve(N);
+    kimm.reserve(N);
+    kpart.reserve(N);
+    for (size_t i = 0; i < N; ++i) {
+        if (dead[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        uint32_t imm = scan_imm[i];
+        if (n.kind == N_SCAN && (n.op & SCAN_OP_DIV)) imm = pos[imm];  // (the constant 2^k: a node index)
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+        krep.push_back(rep[i]);
+        kfl.push_back(vflags[i]);
+        kimm.push_back(imm);
+        kpart.push_back(scan_partner[i]);  // (old index: renumbered below, the partner may sit behind this node)
+    }
+    for (uint32_t& x : kpart)
+        if (x != NONE) x = pos[x];
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
+    rep.swap(krep);
+    vflags.swap(kfl);
+    scan_imm.swap(kimm);
+    scan_partner.swap(kpart);
 }
 
 // ---- fused narrow chains (round 3) --------------------------------------------------------------------------------
@@ -674,15 +873,10 @@ static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<
 // Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
 // profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
-static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400, 5660};
-// a macro bundle (C_MACRO) is priced as its front end plus its stages; the table entry is four mixed stages, a bundle
-// books what its stages cost less (form_cycles_saved).  Measured (profiles/r03_classprof_macro.txt, stamps taken off):
-// front end 660, a stage 1 070 on average over the authV2-class graph's bundles plus 190 where it re-reads operands of
-// earlier stages (two of three stages do) -- a stage's own decoding (kind, accumulator selects, gather, ring / slot
-// addresses: ~60 instructions at a lone wave's ~5 cycles each) and the LDS round trip of operands from other lane groups
-// cost what the pipelined loop spends per narrow bundle (1 306), so the merged bundles ran 1-6 % slower than the separate
-// ones (profiles/r03_macro_ab.txt) and the class is opt-in (CWC_MACRO=1), kept with its tests as a measured dead end.
-static const double kCyclesMacroFront = 660, kCyclesMacroStage[4] = {0, 1150, 1250, 600} /* by MacroStageKind */, kCyclesMacroLate = 190, kCyclesMacroGather = 80;
+static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400, 48900};
+// a scan bundle (C_SCAN) is priced as its front end plus the rounds of its loop (the table entry is 32 rounds of the
+// division step; a bundle books what it costs less): the limb-sized paths, measured on MI355X (profiles/r04_class_profile.txt)
+static const double kCyclesScanFront = 900, kCyclesScanStepCarry = 260, kCyclesScanStepDiv = 1500;
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves
 static const double kCyclesFusedStageMul = 760, kCyclesFusedStageLin = 300;
@@ -788,7 +982,6 @@ struct CoopPolicy {
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
     bool all_montgomery = false;  // no representation inference: every value in Montgomery form
     bool witness_slots = false;   // the slots of witness elements in witness order (see the slot allocation)
-    bool macro = false;           // consecutive narrow bundles of the schedule are merged into macro bundles (class C_MACRO) where the cycle table says it pays
     uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused; + 0x10000: product + sum nodes only
 };
 // The rewritten graph (load-time optimiser, bit-extract fusion, tree-height reduction) depends on the fusion switch and on
@@ -833,8 +1026,6 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     const bool forced = getenv("CWC_COOP_FILL") || getenv("CWC_COOP_SLACK");
     if (getenv("CWC_NO_COOP_MUL") || coop_nodes(T) == 0) base.fill = 0;
     if (const char* e = getenv("CWC_WITNESS_SLOTS")) base.witness_slots = atoi(e) != 0;
-    // macro bundles (merge_macros): opt-in, CWC_MACRO=1 (measured slower than the separate narrow bundles, see kCyclesMacroFront)
-    if (getenv("CWC_MACRO") && atoi(getenv("CWC_MACRO")) != 0) base.macro = true;
     RewriteCache own_cache;
     RewriteCache& cache = shared && T >= 1 && T <= 64 && !(T & (T - 1)) ? shared->cache[__builtin_ctz(T)] : own_cache;
     if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) return false;
@@ -867,7 +1058,6 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     for (CoopPolicy pol : more) {
         pol.all_montgomery = base.all_montgomery;
         pol.witness_slots = base.witness_slots;
-        pol.macro = base.macro;
         Program alt;
         std::string err2;
         if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
@@ -878,7 +1068,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     // Fused narrow chains (fuse_narrow_chains): how far from the critical path a chain is still fused is a policy too --
     // only the critical chain, chains within a few percent of it, every chain -- and the cost model picks
     // (CWC_FUSE=<thousandths + 1> forces one, CWC_NO_FUSE=1 none).
-    if (T <= COOP_FUSE_MAX_T && kept.fill && !kept.macro && !getenv("CWC_NO_FUSE")) {  // (a program has fused bundles or macro bundles)
+    if (T <= COOP_FUSE_MAX_T && kept.fill && !getenv("CWC_NO_FUSE")) {
         std::vector<uint32_t> tries = {1, 11, 101, 1001, 0x10001, 0x1000b, 0x10065, 0x103e9};
         if (const char* e = getenv("CWC_FUSE")) tries.assign(1, (uint32_t)atoi(e));
         for (uint32_t f : tries) {
@@ -1068,7 +1258,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery);
     N = g.nodes.size();
     phase("representation inference");
-    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1) {
+    // ---- scan chains: the steps of serial limb recurrences as pairs of N_SCAN nodes (class C_SCAN) ----
+    std::vector<uint32_t> scan_imm, scan_partner;
+    if (T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_SCAN")) {
+        detect_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
+        N = g.nodes.size();
+        phase("scan chains");
+    }
+    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1 && st.n_scan_steps == 0) {  // (a program has fused bundles or scan bundles: one interpreter instance each)
         fuse_narrow_chains(g, node_rep, node_vflags, class_cost, (policy.fuse & 0xffffu) - 1, (policy.fuse & 0x10000u) != 0, st.n_fused_nodes);
         N = g.nodes.size();
         phase("fused narrow chains");
@@ -1096,6 +1293,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             return lin_operand && node_rep[i] == REP_C;
         }
         if (c == C_TERN) return q >= 1 && node_rep[i] == REP_C;
+        if (c == C_SCAN) return true;  // x, the accumulator, the divisor: canonical integers
         return false;  // Mul / Div: Montgomery form
     };
     for (size_t i = 0; i < N; ++i) {
@@ -1127,7 +1325,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint32_t> use_bundle_of(N, 0xffffffffu);  // bundle that reads the node's operands (differs for a
                                                           // division handed to the divider wave: request vs. collect)
     std::vector<uint32_t> bundle_start;  // index into order
-    std::vector<uint8_t> bundle_coop;    // 1: narrow multiplication bundle (C_MULQ: four lanes per product), 2: fused narrow bundle, 3: macro bundle
+    std::vector<uint8_t> bundle_coop;    // 1: narrow multiplication bundle (C_MULQ: four lanes per product), 2: fused narrow bundle
     std::vector<uint32_t> order_pos;     // record position of every entry of `order` inside its bundle
     std::vector<uint32_t> bundle_flags;  // HDR_POST / HDR_WAIT (programs of several streams)
     static const uint32_t REQ_FLAG = 0x80000000u;         // order[] entry: the request half of a division
@@ -1215,6 +1413,35 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         const bool tie_reverse = getenv("CWC_SCHED_TIE_REVERSE") != nullptr;
         const bool ride_along = !getenv("CWC_NO_RIDE_ALONG");
+        // Scan chains: a step is scheduled as a unit (its OUT node stands for both), consecutive steps of a chain go into
+        // consecutive pairs of ONE bundle.  A bundle's steps share kind and shift: one ready heap per (kind, shift).
+        const bool has_scans = st.n_scan_steps != 0;
+        std::vector<uint32_t> scan_keys;             // distinct (kind << 8 | shift)
+        std::vector<uint32_t> scan_next;             // ACC node -> OUT node of the step that continues its chain
+        auto scan_shift_of = [&](uint32_t i) -> uint32_t {
+            if (!(g.nodes[i].op & SCAN_OP_DIV)) return scan_imm[i];
+            const Fr& v = g.const_values[g.nodes[scan_imm[i]].a];  // the constant 2^k
+            for (int w = 0; w < 8; ++w)
+                if (v.v[w]) return 32u * w + (uint32_t)__builtin_ctz(v.v[w]);
+            return 0;
+        };
+        auto scan_key_of = [&](uint32_t i) -> uint32_t { return ((g.nodes[i].op & SCAN_OP_DIV) ? 256u : 0u) | scan_shift_of(i); };
+        auto scan_key_index = [&](uint32_t key) -> int {
+            for (size_t k = 0; k < scan_keys.size(); ++k)
+                if (scan_keys[k] == key) return (int)k;
+            return -1;
+        };
+        if (has_scans) {
+            scan_next.assign(N, 0xffffffffu);
+            for (size_t i = 0; i < N; ++i) {
+                const Node& n = g.nodes[i];
+                if (n.kind != N_SCAN || (n.op & SCAN_OP_ACC)) continue;
+                const uint32_t key = scan_key_of((uint32_t)i);
+                if (scan_key_index(key) < 0) scan_keys.push_back(key);
+                const Node& pr = g.nodes[n.b];
+                if (pr.kind == N_SCAN && (pr.op & SCAN_OP_ACC) && scan_key_of(n.b) == key && scan_next[n.b] == 0xffffffffu) scan_next[n.b] = (uint32_t)i;
+            }
+        }
         // Narrow multiplication bundles: when no more multiplications are ready than four-lane products fit a wave, the
         // bundle is compiled for the lane-cooperative multiplier (about half the cycles of a full-width multiplication
         // bundle).
@@ -1230,8 +1457,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         // One stream's bundle sequence (bundle indices relative to the stream's first bundle).
         struct StreamSched {
             std::vector<uint32_t> order, bundle_start, div_lanes;
-            std::vector<uint32_t> order_pos;     // record position of every entry of `order` inside its bundle (merge_macros)
-            std::vector<uint8_t> bundle_coop;    // 0 full-width, 1 narrow multiplication bundle, 2 fused narrow bundle, 3 macro bundle
+            std::vector<uint32_t> order_pos;     // record position of every entry of `order` inside its bundle
+            std::vector<uint8_t> bundle_coop;    // 0 full-width, 1 narrow multiplication bundle, 2 fused narrow bundle
             std::vector<uint32_t> bundle_flags;  // HDR_POST / HDR_WAIT: the bundle is a C_SYNC bundle
             uint64_t class_bundles[C_COUNT] = {0};
             uint32_t n_div_requests = 0;
@@ -1257,10 +1484,19 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             // ready heaps per class, keyed by (height, -index)
             typedef std::pair<uint64_t, uint32_t> Key;  // (height, ~index) so that ties prefer file order
             // (integer-class nodes: one heap per combination of operand / result forms, a bundle's header bits are uniform)
-            const int NH = (int)C_COUNT * 17;
+            const int NH = (int)C_COUNT * (17 + (int)scan_keys.size());  // (scan steps: heap C_SCAN + C_COUNT * (17 + key index))
             std::vector<std::vector<Key>> heap(NH);
+            std::vector<uint8_t> placed;  // scan nodes that sit in a bundle already (a step's successor inside its own bundle is released with it)
+            if (has_scans) placed.assign(N, 0);
             auto push = [&](uint32_t i) {
                 int hc = class_of(g.nodes[i]);
+                if (hc == C_SCAN) {  // the step's OUT node stands for the pair
+                    if ((g.nodes[i].op & SCAN_OP_ACC) || placed[i]) return;
+                    auto& hs = heap[(int)C_SCAN + (int)C_COUNT * (17 + scan_key_index(scan_key_of(i)))];
+                    hs.push_back(Key(std::max(height[i], height[scan_partner[i]]) + (prologue[i] ? kPrologueBoost : 0ull), tie_reverse ? i : ~i));
+                    std::push_heap(hs.begin(), hs.end());
+                    return;
+                }
                 if (hc == C_BIT) hc += (int)C_COUNT * (1 + node_vflags[i] + 8 * (g.nodes[i].op == OP_SHR || g.nodes[i].op == OP_BAND ? 1 : 0));  // (bundles of Shr / Band nodes take a straight path)
                 else if (is_integer_class(hc)) hc += (int)C_COUNT * (1 + node_vflags[i]);
                 else if (hc == C_CMPZ) hc += (int)C_COUNT * (1 + (node_vflags[i] & VF_OUT_CANON));
@@ -1305,7 +1541,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 }
                 if (request) return;
                 remaining -= nodes.size();
-                for (uint32_t i : nodes)  // release users only now: a bundle never reads its own results
+                for (uint32_t i : nodes)  // release users only now: a bundle never reads its own results (but for the steps of a scan bundle: push skips them)
                     for (uint32_t u : users[i])
                         if (so[u] == s && --indeg[u] == 0) push(u);
             };
@@ -1365,6 +1601,35 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 if (!heap[C_INPUT].empty()) best = C_INPUT;
                 picked.clear();
                 auto& h = heap[best];
+                if (best % (int)C_COUNT == (int)C_SCAN && best >= (int)C_COUNT * 17) {
+                    // the most urgent ready step and, pair after pair, the steps that continue its chain -- as far as every other
+                    // operand of theirs was produced by an earlier bundle --, then the next ready chain of the same kind
+                    const size_t cap_steps = G / 2;
+                    auto in_bundle = [&](uint32_t x) { return std::find(picked.begin(), picked.end(), x) != picked.end(); };
+                    uint32_t longest = 0;
+                    while (picked.size() / 2 < cap_steps && !h.empty()) {
+                        std::pop_heap(h.begin(), h.end());
+                        uint32_t cur = tie_reverse ? h.back().second : ~h.back().second;
+                        h.pop_back();
+                        uint32_t run = 0;
+                        for (;;) {
+                            picked.push_back(cur);
+                            picked.push_back(scan_partner[cur]);
+                            placed[cur] = placed[scan_partner[cur]] = 1;
+                            ++run;
+                            if (picked.size() / 2 >= cap_steps) break;
+                            const uint32_t nx = scan_next[scan_partner[cur]];
+                            if (nx == 0xffffffffu || so[nx] != s || placed[nx] || indeg[nx] != 1 || indeg[scan_partner[nx]] != 1) break;
+                            const Node& nn = g.nodes[nx];
+                            if (in_bundle(nn.a) || ((nn.op & SCAN_OP_DIV) && in_bundle(nn.c))) break;  // (x or the divisor comes out of this very bundle)
+                            cur = nx;
+                        }
+                        longest = std::max(longest, run);
+                    }
+                    emit_bundle(picked, false, false);
+                    clock += 14 + (uint64_t)longest * scan_cost50(g.nodes[picked[0]].op);
+                    continue;
+                }
                 // a request must fit the interpreter's mailbox (mbox_lanes active lanes = node slots x T)
                 const bool fused = best >= (int)C_COUNT && best % (int)C_COUNT == (int)C_MULF;  // fused narrow bundle: at most coop_nodes(T) nodes
                 const size_t cap = best == C_DIV && divider ? std::max<size_t>(1, std::min<size_t>(G, mbox_lanes(divider) / T)) : fused ? (size_t)coop_nodes(T) : G;
@@ -1441,141 +1706,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         };
 
 
-        // ---- macro bundles: runs of consecutive narrow bundles become the stages of one bundle (program_dev.h C_MACRO) ----
-        // A post-pass over a stream's schedule (the list scheduler above decides what runs when): up to MACRO_STAGES
-        // consecutive bundles that are narrow -- a multiplication bundle or a linear bundle of at most coop_nodes(T) nodes --
-        // merge (opt-in, CWC_MACRO).  Stage k of lane group g is record position 4g + k; a node goes to the group whose accumulator
-        // holds one of its operands where it can.
-        auto merge_macros = [&](uint32_t s, StreamSched& ss) {
+        // record positions: a bundle's nodes sit at positions 0, 1, .. in the order the scheduler picked them
+        auto number_positions = [&](StreamSched& ss) {
             const uint32_t nb = (uint32_t)ss.bundle_start.size();
-            const uint32_t cap = coop_nodes(T);
-            auto b_end = [&](uint32_t b) { return b + 1 < nb ? ss.bundle_start[b + 1] : (uint32_t)ss.order.size(); };
             ss.order_pos.resize(ss.order.size());
-            for (uint32_t b = 0; b < nb; ++b)
-                for (uint32_t k = ss.bundle_start[b]; k < b_end(b); ++k) ss.order_pos[k] = k - ss.bundle_start[b];
-            if (!policy.macro || cap == 0 || T > COOP_FUSE_MAX_T) return;
-            // (with the measured stage cycles no run of the bench graphs is cheaper merged: the opt-in merges every run it can,
-            // CWC_MACRO=2 only where the cycle table says it pays)
-            const bool macro_always = !(getenv("CWC_MACRO") && atoi(getenv("CWC_MACRO")) == 2);
-            auto stage_kind = [&](uint32_t b) -> uint32_t {
-                const uint32_t k0 = ss.bundle_start[b], k1 = b_end(b);
-                if (ss.bundle_flags[b] || k1 == k0 || k1 - k0 > cap || ss.bundle_coop[b] > 1) return MSK_NONE;
-                bool mul = false, lin = false;
-                for (uint32_t k = k0; k < k1; ++k) {
-                    if (ss.order[k] & REQ_FLAG) return MSK_NONE;
-                    const int c = class_of(g.nodes[ss.order[k]]);
-                    if (c == C_MUL) mul = true;
-                    else if (c == C_LIN) lin = true;
-                    else return MSK_NONE;
-                }
-                return mul ? (lin ? MSK_MIXED : MSK_MUL) : MSK_LIN;
-            };
-            auto separate_cycles = [&](uint32_t b, uint32_t kind) {
-                return kind == MSK_LIN ? kCycles[C_LIN] : ss.bundle_coop[b] ? kCycles[C_MULQ] + (kind == MSK_MIXED ? kCyclesCoopRiders : 0.0) : kCycles[C_MUL];
-            };
-            std::vector<uint32_t> order2, pos2, start2, flags2, remap(nb, 0);
-            std::vector<uint8_t> coop2;
-            order2.reserve(ss.order.size());
-            pos2.reserve(ss.order.size());
-            std::vector<uint32_t> latest(cap), grp;
-            std::vector<uint8_t> used(cap);
-            std::vector<uint32_t> run_pos;  // positions of the run's nodes, stage after stage
-            for (uint32_t b = 0; b < nb;) {
-                uint32_t len = 0;
-                double best_saving = 0;
-                if (stage_kind(b) != MSK_NONE) {
-                    // positions stage by stage; the cheapest prefix of the run wins
-                    std::fill(latest.begin(), latest.end(), 0xffffffffu);
-                    run_pos.clear();
-                    double separate = 0, merged = kCyclesMacroFront;
-                    for (uint32_t k = 0; k < MACRO_STAGES && b + k < nb; ++k) {
-                        const uint32_t kind = stage_kind(b + k);
-                        if (kind == MSK_NONE) break;
-                        const uint32_t k0 = ss.bundle_start[b + k], n = b_end(b + k) - k0;
-                        grp.assign(n, 0xffffffffu);
-                        std::fill(used.begin(), used.end(), 0);
-                        for (uint32_t x = 0; x < n; ++x) {  // first the nodes that continue a group's chain
-                            const Node& nd = g.nodes[ss.order[k0 + x]];
-                            const uint32_t ops[2] = {nd.a, nd.kind == N_UNO ? nd.a : nd.b};
-                            for (uint32_t q = 0; q < cap && grp[x] == 0xffffffffu; ++q)
-                                if (!used[q] && latest[q] != 0xffffffffu && (latest[q] == ops[0] || latest[q] == ops[1])) {
-                                    grp[x] = q;
-                                    used[q] = 1;
-                                }
-                        }
-                        bool late = false, gather = false;
-                        for (uint32_t x = 0, q = 0; x < n; ++x) {
-                            if (grp[x] == 0xffffffffu) {
-                                while (used[q]) ++q;
-                                grp[x] = q;
-                                used[q] = 1;
-                            }
-                            const uint32_t i = ss.order[k0 + x];
-                            const Node& nd = g.nodes[i];
-                            const uint32_t ops[2] = {nd.a, nd.kind == N_UNO ? nd.a : nd.b};
-                            for (int o = 0; o < (nd.kind == N_UNO ? 1 : 2); ++o) {
-                                const uint32_t pr = ops[o];
-                                const bool same = g.nodes[pr].kind != N_CONST && stream_of[pr] == s && bundle_of[pr] >= b && bundle_of[pr] < b + k;  // an earlier stage of this run
-                                if (same && latest[grp[x]] != pr) late = true;
-                            }
-                            if (class_of(nd) == C_MUL && nd.a == nd.b && latest[grp[x]] == nd.a) gather = true;
-                        }
-                        for (uint32_t x = 0; x < n; ++x) {
-                            latest[grp[x]] = ss.order[k0 + x];
-                            run_pos.push_back(grp[x] * MACRO_STAGES + k);
-                        }
-                        separate += separate_cycles(b + k, kind);
-                        merged += kCyclesMacroStage[kind] + (late ? kCyclesMacroLate : 0.0) + (gather ? kCyclesMacroGather : 0.0);
-                        if (k >= 1 && (macro_always || separate - merged > best_saving)) {
-                            best_saving = separate - merged;
-                            len = k + 1;
-                        }
-                    }
-                }
-                const uint32_t nbnew = (uint32_t)start2.size();
-                if (len >= 2) {
-                    start2.push_back((uint32_t)order2.size());
-                    coop2.push_back(3);
-                    flags2.push_back(0);
-                    size_t rp = 0;
-                    for (uint32_t k = 0; k < len; ++k) {
-                        remap[b + k] = nbnew;
-                        for (uint32_t e = ss.bundle_start[b + k]; e < b_end(b + k); ++e) {
-                            order2.push_back(ss.order[e]);
-                            pos2.push_back(run_pos[rp++]);
-                        }
-                        const uint32_t kind = stage_kind(b + k);
-                        ss.class_bundles[kind == MSK_LIN ? (int)C_LIN : ss.bundle_coop[b + k] ? (int)C_MULQ : (int)C_MUL]--;
-                    }
-                    ss.class_bundles[C_MACRO]++;
-                    b += len;
-                } else {
-                    remap[b] = nbnew;
-                    start2.push_back((uint32_t)order2.size());
-                    coop2.push_back(ss.bundle_coop[b]);
-                    flags2.push_back(ss.bundle_flags[b]);
-                    for (uint32_t e = ss.bundle_start[b]; e < b_end(b); ++e) {
-                        order2.push_back(ss.order[e]);
-                        pos2.push_back(ss.order_pos[e]);
-                    }
-                    ++b;
-                }
+            for (uint32_t b = 0; b < nb; ++b) {
+                const uint32_t e = b + 1 < nb ? ss.bundle_start[b + 1] : (uint32_t)ss.order.size();
+                for (uint32_t k = ss.bundle_start[b]; k < e; ++k) ss.order_pos[k] = k - ss.bundle_start[b];
             }
-            // bundle indices of the stream's nodes (relative to the stream's first bundle, like the scheduler wrote them)
-            for (uint32_t e : ss.order) {
-                const uint32_t i = e & ~REQ_FLAG;
-                if (e & REQ_FLAG) {
-                    use_bundle_of[i] = remap[use_bundle_of[i]];
-                } else {
-                    bundle_of[i] = remap[bundle_of[i]];
-                    if (!(divider && class_of(g.nodes[i]) == C_DIV)) use_bundle_of[i] = remap[use_bundle_of[i]];
-                }
-            }
-            ss.order.swap(order2);
-            ss.order_pos.swap(pos2);
-            ss.bundle_start.swap(start2);
-            ss.bundle_coop.swap(coop2);
-            ss.bundle_flags.swap(flags2);
         };
 
         // ---- partition into streams ----
@@ -1595,6 +1733,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             auto node_cycles = [&](int c) -> double {
                 if (c == C_MUL) return narrow ? kCycles[C_MULQ] : kCycles[C_MUL];
                 if (c == C_MULF) return kCycles[C_MULF];
+                if (c == C_SCAN) return 0.5 * (kCyclesScanStepCarry + kCyclesScanStepDiv);  // (a step's round of the loop)
                 if (c == C_DIV && divider) return kCycles[C_DIV] + kCycles[C_DIVREQ] + kCycles[C_DIVGET];
                 return kCycles[c];
             };
@@ -1620,6 +1759,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         const uint32_t ra = find((uint32_t)i), rb = find(ops[q]);
                         if (ra != rb) parent[ra] = rb;
                     }
+                if (n.kind == N_SCAN) {  // the two nodes of a step sit in one bundle: one part (their operands may all be prologue values)
+                    const uint32_t ra = find((uint32_t)i), rb = find(scan_partner[i]);
+                    if (ra != rb) parent[ra] = rb;
+                }
             }
             struct Comp { uint32_t root; double cp = 0, work = 0, alone = 0; uint64_t nodes = 0; };
             std::unordered_map<uint32_t, uint32_t> comp_index;
@@ -1694,7 +1837,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 continue;
             }
             if (!schedule_stream(s, stream_of, ss, true, P > 1)) return false;
-            merge_macros(s, ss);
+            number_positions(ss);
             const uint32_t nb = (uint32_t)ss.bundle_start.size();
             const uint32_t base = (uint32_t)bundle_start.size();
             s_first[s] = base;
@@ -1748,14 +1891,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (uint32_t k = bundle_start[b]; k < bundle_start[b + 1]; ++k) pos_in_bundle[order[k] & ~REQ_FLAG] = order_pos[k];
     enum { SRC_MEM = 0, SRC_RING = 1 };
     auto route = [&](uint32_t producer, uint32_t consumer, int q) -> uint32_t {
-        if ((q >= 2 && g.nodes[consumer].kind != N_FUSED) || g.nodes[producer].kind == N_CONST) return SRC_MEM;  // (TernCond reads its third operand in place)
+        if ((q >= 2 && g.nodes[consumer].kind != N_FUSED && g.nodes[consumer].kind != N_SCAN) || g.nodes[producer].kind == N_CONST) return SRC_MEM;  // (TernCond reads its third operand in place)
         if (stream_of[producer] != stream_of[consumer]) return SRC_MEM;  // (another wave's ring)
         const uint32_t d = use_bundle_of[consumer] - bundle_of[producer];
-        if (d == 0) return SRC_RING;  // an earlier stage of the consumer's macro bundle (nothing else reads inside its own bundle)
-        // (a macro bundle writes its ring slot stage by stage: what it reads from the slot it is about to overwrite would have to be
-        // told from its own stages' results -- it reads the three younger slots only)
-        const uint32_t reach = bundle_coop[use_bundle_of[consumer]] == 3 ? RING_BUNDLES - 1 : RING_BUNDLES;
-        return (d >= 1 && d <= reach) ? SRC_RING : SRC_MEM;
+        return (d >= 1 && d <= RING_BUNDLES) ? SRC_RING : SRC_MEM;
     };
     std::vector<uint32_t> last_mem_use(N, 0);  // last bundle that reads the value from memory
     std::vector<uint8_t> needs_slot(N, 0);
@@ -1772,6 +1911,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         const uint32_t ops[3] = {n.a, n.b, n.c};
         for (int q = 0; q < arity_of(n); ++q) {
             const uint32_t o = ops[q];
+            if (n.kind == N_SCAN && q == 1 && g.nodes[o].kind != N_CONST && stream_of[o] == stream_of[i] && bundle_of[o] == use_bundle_of[i]) continue;  // (the accumulator arrives inside the bundle)
             if (g.nodes[o].kind == N_CONST || route(o, i, q) != SRC_MEM) continue;
             if (!needs_slot[o]) needs_slot[o] = 1;
             if (stream_of[o] != stream_of[i]) needs_slot[o] = 2;  // read by another stream: the slot is never reused
@@ -1812,6 +1952,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         if (g.nodes[producer].kind == N_CONST) return (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes;
         return ((uint64_t)NC + ref[producer]) * slot_bytes;
     };
+    auto scan_shift_of_node = [&](uint32_t i) -> uint32_t {  // CARRY: n; DIV: k of the constant 2^k
+        if (!(g.nodes[i].op & SCAN_OP_DIV)) return scan_imm[i];
+        const Fr& v = g.const_values[g.nodes[scan_imm[i]].a];
+        for (int w = 0; w < 8; ++w)
+            if (v.v[w]) return 32u * w + (uint32_t)__builtin_ctz(v.v[w]);
+        return 0;
+    };
     auto sub_of = [&](uint8_t op) -> uint32_t {
         switch (op) {
             case OP_ADD: return SUB_ADD;   case OP_SUB: return SUB_SUB;   case OP_MUL: return SUB_MULT;
@@ -1829,12 +1976,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         const uint32_t k0 = bundle_start[b], k1 = bundle_start[b + 1], cnt = k1 - k0;
         const bool idle = cnt == 0;  // (programs of several streams: padding around the posts and waits; an Add of zeros into the trash slot)
         const bool request = !idle && (order[k0] & REQ_FLAG) != 0, collect = !idle && is_collect(order[k0]);
-        const bool coop = bundle_coop[b] == 1 || bundle_coop[b] == 2, fusedb = bundle_coop[b] == 2, macrob = bundle_coop[b] == 3;
+        const bool coop = bundle_coop[b] == 1 || bundle_coop[b] == 2, fusedb = bundle_coop[b] == 2;
         const uint32_t rep = coop ? COOP_LANES : 1u;  // a C_MULQ / C_MULF node's records take COOP_LANES positions (4j .. 4j+3)
-        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : macrob ? (int)C_MACRO : fusedb ? (int)C_MULF : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
-        // macro bundles: the node in each lane group's accumulator so far, and what the stages hold (header bits)
-        uint32_t m_latest[16], m_mul = 0, m_lin = 0, m_late = 0, m_gather = 0;
-        for (uint32_t& x : m_latest) x = 0xffffffffu;
+        const int cl = idle ? (bundle_flags[b] ? (int)C_SYNC : (int)C_LIN) : request ? (int)C_DIVREQ : collect ? (int)C_DIVGET : fusedb ? (int)C_MULF : coop ? (int)C_MULQ : class_of(g.nodes[order[k0]]);
         uint32_t stream = 0;
         while (stream + 1 < P && b >= s_first[stream + 1]) ++stream;
         if (b == s_first[stream]) free_slots.clear();  // a slot is reused inside the stream that freed it only (the others run at their own pace)
@@ -1863,6 +2007,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             form_bits |= f0 & VF_OUT_CANON ? HDR_OUT_CANON : 0u;
         }
         double form_saved = 0;  // (priced below, once the bundle is known to be all bit extracts or not)
+        uint32_t scan_run = 0, scan_longest = 0, scan_bits = 0;  // scan bundles: the current / the longest chain segment, kind and shift
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = order[k] & ~REQ_FLAG;
             const Node& n = g.nodes[i];
@@ -1922,40 +2067,6 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     if (needs_slot[fops[q]] == 1 && last_mem_use[fops[q]] == b) dying.push_back(fops[q]);
                 continue;
             }
-            if (macrob) {
-                const uint32_t grp = js / MACRO_STAGES, stg = js % MACRO_STAGES, acc = m_latest[grp];
-                const bool mul = class_of(n) == C_MUL;
-                uint32_t mc = MCTRL_ACTIVE;
-                // operand `producer` into position `w` (0: a, 1: b); q names the node's operand for the constant form
-                auto macro_operand = [&](uint32_t producer, int q, int w) {
-                    enc_to(producer, q, off[w], lds[w]);
-                    if (g.nodes[producer].kind == N_CONST || stream_of[producer] != stream_of[i] || bundle_of[producer] != b) return;
-                    if (producer == acc) mc |= w ? MCTRL_B_ACC : MCTRL_A_ACC;
-                    else m_late |= 1u << stg;
-                };
-                if (n.kind == N_UNO) {  // Neg(a) = 0 - a
-                    mc |= SUB_SUB;
-                    macro_operand(n.a, 1, 1);
-                } else if (mul && n.a == acc && n.b != acc) {  // the accumulator is the factor the lanes hold in parts: b
-                    mc |= SUB_MULT;
-                    macro_operand(n.b, 1, 0);
-                    macro_operand(n.a, 0, 1);
-                } else {
-                    mc |= mul ? (uint32_t)SUB_MULT : sub_of(n.op);
-                    macro_operand(n.a, 0, 0);
-                    macro_operand(n.b, 1, 1);
-                }
-                if (mul && (mc & MCTRL_A_ACC)) m_gather |= 1u << stg;
-                (mul ? m_mul : m_lin) |= 1u << stg;
-                m_latest[grp] = i;
-                const uint32_t rm[4] = {off[0], off[1], slot, lds[0] | (lds[1] << 16)};
-                memcpy(&out.recs[((size_t)b * G + js) * 4], rm, sizeof rm);
-                ctrl_of[(size_t)b * G + js] = (uint8_t)mc;
-                const uint32_t mops[2] = {n.a, n.kind == N_UNO ? n.a : n.b};
-                for (int q = 0; q < 2; ++q)
-                    if (needs_slot[mops[q]] == 1 && last_mem_use[mops[q]] == b) dying.push_back(mops[q]);
-                continue;
-            }
             if (!collect)
             switch (n.kind) {
                 case N_INPUT:
@@ -1978,6 +2089,28 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     }
                     enc_operand(n.b, 1);
                     break;
+                case N_SCAN: {
+                    // position 2p: the step's OUT record {x, accumulator at a chain's head}; 2p + 1: its ACC record {divisor, 2^k in Montgomery form} (DIV)
+                    const bool is_acc = (n.op & SCAN_OP_ACC) != 0, is_div = (n.op & SCAN_OP_DIV) != 0;
+                    if ((js & 1u) != (is_acc ? 1u : 0u)) {
+                        err = "internal error: scan records out of place";
+                        return false;
+                    }
+                    const uint32_t pair = js / 2;
+                    const bool start = pair == 0 || (order[k0 + 2 * pair - 1] & ~REQ_FLAG) != n.b;
+                    ctrl |= (is_acc ? SCAN_ROLE_ACC : 0u) | (start ? SCAN_START : 0u);
+                    if (!is_acc) {
+                        enc_operand(n.a, 0);
+                        if (start) enc_operand(n.b, 1);
+                        scan_run = start ? 1u : scan_run + 1u;
+                        scan_longest = std::max(scan_longest, scan_run);
+                        scan_bits = (is_div ? HDR_SCAN_DIV : 0u) | (scan_shift_of_node(i) << HDR_SCAN_SHIFT_SHIFT);
+                    } else if (is_div) {
+                        enc_to(n.c, 2, off[0], lds[0]);
+                        off[1] = (uint32_t)mem_off(scan_imm[i]);
+                    }
+                    break;
+                }
                 case N_TRES:
                     enc_operand(n.a, 0);
                     enc_operand(n.b, 1);
@@ -2006,16 +2139,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             }
             form_saved = (lin_bits & HDR_F_S2MUL ? 0.0 : kCyclesFusedStageMul) + ((lin_bits & (HDR_F_S2LIN | HDR_F_S3LIN)) ? 0.0 : kCyclesFusedStageLin);
         }
-        if (cl == C_MACRO) {
-            double cyc = kCyclesMacroFront;
-            for (uint32_t stg = 0; stg < MACRO_STAGES; ++stg) {
-                const uint32_t kind = (m_mul >> stg & 1u) ? ((m_lin >> stg & 1u) ? MSK_MIXED : MSK_MUL) : (m_lin >> stg & 1u) ? MSK_LIN : MSK_NONE;
-                lin_bits |= kind << (HDR_M_KIND_SHIFT + 2 * (int)stg);
-                if (stg && (m_late >> stg & 1u)) lin_bits |= 1u << (HDR_M_LATE_SHIFT + (int)stg);
-                if (stg && (m_gather >> stg & 1u)) lin_bits |= 1u << (HDR_M_GATHER_SHIFT + (int)stg);
-                cyc += kCyclesMacroStage[kind] + ((m_late >> stg & 1u) ? kCyclesMacroLate : 0.0) + ((m_gather >> stg & 1u) ? kCyclesMacroGather : 0.0);
-            }
-            form_saved = kCycles[C_MACRO] - cyc;
+        if (cl == C_SCAN) {
+            lin_bits = scan_bits | ((scan_longest - 1u) << HDR_SCAN_ITER_SHIFT);
+            form_saved = kCycles[C_SCAN] - (kCyclesScanFront + (double)scan_longest * ((scan_bits & HDR_SCAN_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry));
         }
         if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {
@@ -2070,18 +2196,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // second pass: destination byte offsets (trash slot = n_slots) + ctrl, and inactive padding records
     const uint32_t trash_off = (uint32_t)(((uint64_t)NC + n_slots) * slot_bytes);
     for (uint32_t b = 0; b < NB; ++b) {
-        const bool macrob = bundle_coop[b] == 3;  // (its nodes sit at positions 4 * group + stage: the active bit tells)
         const uint32_t rep = bundle_coop[b] == 1 || bundle_coop[b] == 2 ? COOP_LANES : 1u;
-        const uint32_t cnt = macrob ? G : (bundle_start[b + 1] - bundle_start[b]) * rep;  // record positions in use
+        const uint32_t cnt = (bundle_start[b + 1] - bundle_start[b]) * rep;  // record positions in use
         const uint32_t stage = LDS_STAGE_OFF + (b % OPND_AHEAD) * STAGE_BYTES;
         for (uint32_t q = 0; q < cnt; ++q) {
             uint32_t* r = &out.recs[((size_t)b * G + q) * 4];
-            if (macrob && !(ctrl_of[(size_t)b * G + q] & MCTRL_ACTIVE)) {  // a group idle in this stage: zeros in, trash out
-                r[0] = r[1] = zero_off;
-                r[2] = trash_off;
-                r[3] = (stage + q * T * 16u) | ((stage + 2u * LDS_HALF_BYTES + q * T * 16u) << 16);
-                continue;
-            }
             const uint32_t d = r[2] == 0xffffffffu ? trash_off : (uint32_t)(((uint64_t)NC + r[2]) * slot_bytes);
             r[2] = d | ctrl_of[(size_t)b * G + q];
         }
@@ -2165,16 +2284,10 @@ bool validate_program(const Program& p, std::string& err) {
         if (b == p.stream_first[stream] && p.stream_count[stream] && p.stream_cref_first[stream] != cref_row) return bad("third-operand rows of stream " + std::to_string(stream));
         const bool executed = b < p.stream_first[stream] + p.stream_count[stream];
         const uint32_t h = p.hdr[b], cls = h & HDR_CLASS_MASK, cnt = (h >> HDR_COUNT_SHIFT) & 0x7f;
-        if (cls >= C_COUNT || (cls != C_MACRO && (h >> 19) != 0) || (h >> 30) != 0) return bad("bundle " + std::to_string(b) + ": header");
-        if (cls == C_MACRO) {  // stages: kinds without a gap, flags of stages that exist only; never in a program with fused bundles (one interpreter instance each)
-            if (T > COOP_FUSE_MAX_T || cnt > G) return bad("bundle " + std::to_string(b) + ": macro bundle");
-            bool ended = false;
-            for (uint32_t k = 0; k < MACRO_STAGES; ++k) {
-                const uint32_t kind = (h >> (HDR_M_KIND_SHIFT + 2 * (int)k)) & 3u;
-                const bool fl = k && ((h >> (HDR_M_LATE_SHIFT + (int)k)) & 1u || (h >> (HDR_M_GATHER_SHIFT + (int)k)) & 1u);
-                if ((kind != MSK_NONE && ended) || (kind == MSK_NONE && fl) || (k == 0 && kind == MSK_NONE)) return bad("bundle " + std::to_string(b) + ": macro stages");
-                ended = ended || kind == MSK_NONE;
-            }
+        if (cls >= C_COUNT || (cls != C_SCAN && (h >> 19) != 0)) return bad("bundle " + std::to_string(b) + ": header");
+        if (cls == C_SCAN) {  // pairs of record positions, an iteration count that covers the longest chain segment, a shift below 254
+            const uint32_t iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u, sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu;
+            if (T > SCAN_MAX_T || (cnt & 1u) || cnt == 0 || iters > cnt / 2 || sh >= 254u || (h & 0x7f000u)) return bad("bundle " + std::to_string(b) + ": scan bundle");
         }
         // posts and waits are C_SYNC bundles without nodes: stream 0 posts once, every other stream waits in its first bundle
         // (nothing else is compiled)
@@ -2213,13 +2326,12 @@ bool validate_program(const Program& p, std::string& err) {
                 if ((q & 1u) ? (code == FOP_MUL || code > FOP_RSUB || (r[2] & ~CTRL_MASK) != trash_off) : code > FOP_RSUB) return bad("bundle " + std::to_string(b) + ": fused stage code");
                 if ((code == FOP_MUL && !(h & HDR_F_S2MUL)) || (code > FOP_MUL && !(h & ((q & 1u) ? HDR_F_S3LIN : HDR_F_S2LIN)))) return bad("bundle " + std::to_string(b) + ": fused stage bits");
             }
-            if (cls == C_MACRO && (r[2] & MCTRL_ACTIVE)) {  // the record's operation must be one its stage runs
-                const uint32_t kind = (h >> (HDR_M_KIND_SHIFT + 2 * (int)(q % MACRO_STAGES))) & 3u, op = r[2] & MCTRL_OP_MASK;
-                if (kind == MSK_NONE || op > SUB_MULT || (kind == MSK_MUL && op != SUB_MULT) || (kind == MSK_LIN && op == SUB_MULT) ||
-                    ((q % MACRO_STAGES) == 0 && (r[2] & (MCTRL_A_ACC | MCTRL_B_ACC))))
-                    return bad("bundle " + std::to_string(b) + ": macro record");
+            if (cls == C_SCAN && q < cnt) {  // position 2p: the step's OUT record, 2p + 1: its ACC record, same START bit; the first pair starts a chain
+                const uint32_t sub = r[2] & CTRL_SUB_MASK, sub0 = p.recs[((size_t)b * G + (q & ~1u)) * 4 + 2] & CTRL_SUB_MASK;
+                if ((sub & SCAN_ROLE_ACC) != (q & 1u) || (sub & ~(SCAN_ROLE_ACC | SCAN_START)) || ((sub ^ sub0) & SCAN_START) || (q < 2 && !(sub & SCAN_START)) || !(r[2] & CTRL_ACTIVE))
+                    return bad("bundle " + std::to_string(b) + ": scan record");
             }
-            const uint32_t dst = r[2] & ~(cls == C_MACRO ? MCTRL_MASK : CTRL_MASK);
+            const uint32_t dst = r[2] & ~CTRL_MASK;
             if ((dst % slot_bytes) != 0 || dst < (uint64_t)p.n_const * slot_bytes || dst > trash_off) return bad("bundle " + std::to_string(b) + ": destination");
             const uint32_t la = r[3] & 0xffffu, lb = r[3] >> 16;
             const bool bitx = cls == C_BIT && (r[2] & CTRL_SUB_MASK) == SUB_BITX;
@@ -2237,12 +2349,12 @@ bool validate_program(const Program& p, std::string& err) {
         cref_row += cls == C_INPUT || cls == C_TERN;
     }
     if (cref_row != p.n_cref_rows) return bad("third-operand rows");
-    bool any_fused = false, any_macro = false;  // (one interpreter instance each: a program has one kind or the other)
+    bool any_fused = false, any_scan = false;  // (one interpreter instance each: a program has one kind or the other)
     for (uint32_t h : p.hdr) {
         any_fused = any_fused || (h & HDR_CLASS_MASK) == C_MULF;
-        any_macro = any_macro || (h & HDR_CLASS_MASK) == C_MACRO;
+        any_scan = any_scan || (h & HDR_CLASS_MASK) == C_SCAN;
     }
-    if (any_fused && any_macro) return bad("fused and macro bundles in one program");
+    if (any_fused && any_scan) return bad("fused and scan bundles in one program");
     if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
     if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)
@@ -2269,7 +2381,7 @@ void program_blob_write(const Program& p, uint8_t* dst) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 15;  // (15: the exported image's trailer carries blob_checksum instead of FNV-1a; the program layout is 14's)
+    h.version = 16;  // (16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -2299,7 +2411,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 15 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 16 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

@@ -20,7 +20,13 @@ enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES
                           // compiler-internal, never in a file: a fused chain of a product and up to two more steps
                           // (compile.cc fuse_narrow_chains).  op = sq | op2 << 1 | op3 << 4 (FusedOp codes);
                           // sq: (a * a) op2 b op3 c, else (a * b) op2 c
-                          N_FUSED = 5 };
+                          N_FUSED = 5,
+                          // compiler-internal, never in a file: one output of a step of a serial limb recurrence (compile.cc
+                          // detect_scans, class C_SCAN).  op = ScanOp bits: kind (carry chain / long division by one limb) and
+                          // role (the step's OUT value: limb / quotient digit; its ACC value: carry / remainder).  Both nodes
+                          // of a step name the same operands: a = x, b = the accumulator coming in, c = the divisor (DIV).
+                          N_SCAN = 6 };
+enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2 };
 
 // graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into
 // Graph::const_values (canonical value, already reduced mod r as storage.rs:28 does on load).

@@ -79,11 +79,55 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t byte
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
+// ---- scan bundles (class C_SCAN, program_dev.h): helpers -------------------------------------------------------------
+// Lane l takes lane l - D's value across the whole wave (DPP wave_shr:1, a gfx9 control; the first D lanes take zero).
+template <int D>
+__device__ __forceinline__ uint32_t wave_shr_lanes(uint32_t v) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    return v;
+}
+template <int QP>
+__device__ __forceinline__ Fr fr_quad_perm(const Fr& a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], QP, 0xf, 0xf, false);
+    return r;
+}
+// word k of 2^n - 1 (wave-uniform n)
+__device__ __forceinline__ uint32_t mask_word(uint32_t n, uint32_t k) { return n >= 32u * (k + 1u) ? 0xffffffffu : n > 32u * k ? (1u << (n - 32u * k)) - 1u : 0u; }
+// The carry chain's limb-sized rounds: x < 2^128 and every accumulator < 2^128 (so t = x + acc < 2^129), 1 <= n <= 128 with
+// n = 32 WS + bs.  acc' = t >> n, limb = t & (2^n - 1); the accumulator moves D lanes up the wave between rounds.
+template <int WS, int D>
+__device__ __forceinline__ void scan_carry_rounds(uint32_t iters, uint32_t bs, const uint32_t (&m)[4], bool start, const uint32_t (&x)[4], const uint32_t (&a0)[4],
+                                                  uint32_t (&limb)[4], uint32_t (&carry)[4]) {
+    uint32_t c[4] = {0, 0, 0, 0};
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t in[4], t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t sft = wave_shr_lanes<D>(c[k]);
+            in[k] = start ? a0[k] : sft;
+        }
+        uint32_t cy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = adc32(x[k], in[k], cy);
+        t[4] = cy;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            limb[k] = t[k] & m[k];
+            c[k] = __builtin_amdgcn_alignbit(t[k + WS + 1], t[k + WS], bs);  // (t >> n, word k)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) carry[k] = c[k];
+}
+
 // W = interpreter waves that share one divider wave (0: no divider waves).  PACK = such units per workgroup: PACK
 // interpreter waves (W = 0), or PACK x (W interpreters + their divider) with the interpreters first.  The waves of a
 // workgroup are dealt round the CU's four SIMDs, so four-wave workgroups put one wave on every SIMD where single-wave
 // (or two-wave) workgroups land unevenly: 1024 tiles without dividers take 23.2 ms as 256 x 4 waves, 31.4 ms as 1024 x 1.
-// MODE 1: the program has fused narrow bundles (class C_MULF), MODE 2: macro bundles (class C_MACRO).  Their paths are compiled into instances of their own: inside the
+// MODE 1: the program has fused narrow bundles (class C_MULF).  Their path is compiled into instances of their own: inside the
 // one interpreter loop it cost every other program 5 % (register allocation and layout of the hot paths; same-box A/B on
 // the authV2-class graph, 1024 sets: 12.55 against 11.93 ms, profiles/r03_regress_ab.txt).
 template <int T, bool PROF, int W, int PACK, int MODE = 0>
@@ -244,8 +288,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     const uint32_t trash_doff = (p.n_const + p.n_slots) * 2u * HI | t16;
     constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
     unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
-    unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67]) / C_MACRO (prof[68], prof[71])
-    unsigned long long pm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // sections of the macro bundles (prof[72..79])
+    unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67]) / C_SCAN (prof[68], prof[71])
     if (PROF) {
 #pragma unroll
         for (int c = 0; c < C_PROF; ++c) pf[c][0] = pf[c][1] = 0;
@@ -292,7 +335,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         if constexpr (COOP) {
             uint32_t cls_q = h & HDR_CLASS_MASK;
             asm volatile("" : "+s"(cls_q));
-            static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_MACRO == 14 && C_COUNT == 15, "one compare (class >= C_MULQ) leads to the narrow classes");
+            static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_SCAN == 14 && C_COUNT == 15, "one compare (class >= C_MULQ) leads to the narrow classes");
             if (cls_q >= C_MULQ) {
             if (cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
                 // (laid out behind the loop's main line: a taken branch costs a lone wave ~50 cycles, and two of three bundles are not narrow)
@@ -404,123 +447,6 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 continue;
             }
             }
-            if constexpr (MODE == 2 && (uint32_t)T <= COOP_FUSE_MAX_T) {
-            if (cls_q == C_MACRO) {  // macro bundle: up to four narrow bundles of the schedule as the stages of one (program_dev.h)
-                // record position 4g + k is stage k of this lane's group g (lane 4v + q, v = t + T * g); the REC image is indexed by
-                // lane, position p sits at lanes pT .. pT + T - 1
-                const uint32_t gp = (cv / (uint32_t)T) * MACRO_STAGES;
-                const char* const recb = ldsb + LDS_REC_OFF + (b % REC_AHEAD) * REC_BYTES + 16u * T * gp + 8u;
-                uint2 rk[MACRO_STAGES];
-#pragma unroll
-                for (uint32_t k = 0; k < MACRO_STAGES; ++k) rk[k] = *reinterpret_cast<const uint2*>(recb + 16u * T * k);
-                const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
-                const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(rk[0].x), "v"(rk[1].x), "v"(rk[2].x), "v"(rk[3].x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
-                uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
-                asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-                hdr_off_n2 += 4u;
-                CWC_STAMP(m1);
-                // the operands of every stage (what an earlier stage of this bundle produces comes from the accumulator, or is
-                // read again in front of its stage): the staging loads of bundle b + 2 overwrite this bundle's cells below
-                Fr af[MACRO_STAGES];
-                uint2 aq[MACRO_STAGES], bq[MACRO_STAGES];
-#pragma unroll
-                for (uint32_t k = 0; k < MACRO_STAGES; ++k) {
-                    const uint32_t la = rk[k].y + (t16c | (t16c << 16));
-                    af[k] = ld_lds(la & 0xffffu);
-                    aq[k] = *reinterpret_cast<const uint2*>(ldsb + (la & 0xffffu) + coop_chunk);
-                    bq[k] = *reinterpret_cast<const uint2*>(ldsb + (la >> 16) + coop_chunk);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(af[0].v[0]), "v"(af[0].v[4]), "v"(af[1].v[0]), "v"(af[1].v[4]), "v"(af[2].v[0]), "v"(af[2].v[4]), "v"(af[3].v[0]), "v"(af[3].v[4]),
-                             "v"(aq[0].x), "v"(aq[1].x), "v"(aq[2].x), "v"(aq[3].x), "v"(bq[0].x), "v"(bq[1].x), "v"(bq[2].x), "v"(bq[3].x) : "memory");
-                CWC_STAMP(m2);
-                stage_operands(b + 2, rec_n2);
-                stage_rec(b + 4);
-                CWC_STAMP(m3);
-                if (PROF) {
-                    pm[0] += m1 - st0;
-                    pm[1] += m2 - m1;
-                    pm[2] += m3 - m2;
-                }
-                const uint32_t ring_b = LDS_RING_OFF + (b % RING_BUNDLES) * RING_SLOT_BYTES;
-                uint32_t acc0 = 0, acc1 = 0;  // the group's accumulator: the lane's two limbs of its most recent result
-#pragma unroll
-                for (uint32_t k = 0; k < MACRO_STAGES; ++k) {
-                    const uint32_t kind = (h >> (HDR_M_KIND_SHIFT + 2 * (int)k)) & 3u;
-                    if (kind == MSK_NONE) break;
-                    CWC_STAMP(ms0);
-                    if (k > 0 && ((h >> (HDR_M_LATE_SHIFT + (int)k)) & 1u)) {  // operands an earlier stage wrote into this bundle's ring slot
-                        const uint32_t la = rk[k].y + (t16c | (t16c << 16));
-                        const uint32_t a_ad = la & 0xffffu, b_ad = la >> 16;
-                        const Fr a2 = ld_lds(a_ad);
-                        const uint2 aq2 = *reinterpret_cast<const uint2*>(ldsb + a_ad + coop_chunk), bq2 = *reinterpret_cast<const uint2*>(ldsb + b_ad + coop_chunk);
-                        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a2.v[0]), "v"(a2.v[4]), "v"(aq2.x), "v"(bq2.x) : "memory");
-                        const bool a_new = a_ad - ring_b < RING_SLOT_BYTES, b_new = b_ad - ring_b < RING_SLOT_BYTES;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) af[k].v[i] = a_new ? a2.v[i] : af[k].v[i];
-                        aq[k] = a_new ? aq2 : aq[k];
-                        bq[k] = b_new ? bq2 : bq[k];
-                        if (PROF) {
-                            CWC_STAMP(ms1);
-                            pm[5] += ms1 - ms0;
-                            pm[6] += 1;
-                        }
-                    }
-                    const uint32_t c = rk[k].x;
-                    const bool a_acc = (c & MCTRL_A_ACC) != 0, b_acc = (c & MCTRL_B_ACC) != 0;
-                    const uint32_t b0 = b_acc ? acc0 : bq[k].x, b1 = b_acc ? acc1 : bq[k].y;
-                    const uint32_t a0 = a_acc ? acc0 : aq[k].x, a1 = a_acc ? acc1 : aq[k].y;
-                    uint32_t o[2];
-                    if (kind == MSK_LIN) {  // graph.rs:110-111
-                        fr_addsub_coop4(a0, a1, b0, b1, nq0, nq1, c & 1u, o);
-                    } else {                // graph.rs:105 (and linear nodes in groups of their own)
-                        if (k > 0 && ((h >> (HDR_M_GATHER_SHIFT + (int)k)) & 1u)) {  // the accumulator as the full-width factor: the group's lanes exchange their limbs
-                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0x00, 0xf, 0xf, false), g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0x00, 0xf, 0xf, false);
-                            const uint32_t g2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0x55, 0xf, 0xf, false), g3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0x55, 0xf, 0xf, false);
-                            const uint32_t g4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0xAA, 0xf, 0xf, false), g5 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0xAA, 0xf, 0xf, false);
-                            const uint32_t g6 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc0, 0xFF, 0xf, 0xf, false), g7 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc1, 0xFF, 0xf, 0xf, false);
-                            const uint32_t gv[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) af[k].v[i] = a_acc ? gv[i] : af[k].v[i];
-                        }
-                        if (kind == MSK_MUL) fr_mul_coop4(af[k], b0, b1, nq0, nq1, o);
-                        else fr_mul_coop4r(af[k], a0, a1, b0, b1, nq0, nq1, c & MCTRL_OP_MASK, o);
-                    }
-                    const bool act = (c & MCTRL_ACTIVE) != 0;
-                    acc0 = act ? o[0] : acc0;
-                    acc1 = act ? o[1] : acc1;
-                    // the stage's results: ring cell 4g + k of this bundle (an idle group's cell is nobody's operand) and the slot
-                    *reinterpret_cast<uint2*>(ldsb + ring_b + 16u * T * (gp + k) + t16c + coop_chunk) = make_uint2(o[0], o[1]);
-                    {
-                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[0], o[1]}, rsrc, (int)((c & ~MCTRL_MASK) + coop_dst_off), 0, 0);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (PROF) {
-                        CWC_STAMP(ms2);
-                        pm[3] += ms2 - ms0;
-                        pm[4] += 1;
-                    }
-                }
-                CWC_STAMP(m4);
-                doff_prev = trash_doff;
-                rec_hi = rec_hi_n1;
-                rec_hi_n1 = rec_hi_n2;
-                h_cur = h_n1;
-                h_n1 = h_n2;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (PROF) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const unsigned long long t_now = __builtin_amdgcn_s_memtime();
-                    pf_fused[0] += t_now - st0;
-                    pf_fused[1] += 1;
-                    pm[7] += t_now - m4;
-                }
-                continue;
-            }
-            }
             }  // (C_SYNC: the main path)
         }
         const uint32_t ctrl = rec_hi.x & CTRL_MASK;
@@ -587,6 +513,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                         pf[c][0] += t_now - st0;  // cycles of this bundle in the pipelined loop (stamp bookkeeping excluded)
                         pf[c][1] += 1;
                     }
+                if (MODE == 2 && cls == C_SCAN) {
+                    pf_fused[0] += t_now - st0;
+                    pf_fused[1] += 1;
+                }
                 if (cls == C_MUL || cls == C_LIN) {
                     unsigned long long* q = psec[cls == C_MUL ? 0 : 1];
                     q[0] += st1 - st0;    // top of the loop + counted wait for the staged operands
@@ -802,6 +732,99 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 }
                 break;
             }
+            case C_SCAN: {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
+                r = fr_zero();
+                if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
+                    // lanes of a pair: the OUT record's lanes, then the ACC record's (T each); both compute the whole step
+                    constexpr int QP_OUT = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x44 /* [0,1,0,1] */, QP_ACC = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xEE /* [2,3,2,3] */;
+                    constexpr int D = 2 * T;  // lanes from a pair to the next
+                    const uint32_t sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu, iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
+                    const bool start = (sub & SCAN_START) != 0, role_acc = (sub & SCAN_ROLE_ACC) != 0;
+                    const Fr x = fr_quad_perm<QP_OUT>(a_op), acc0 = fr_quad_perm<QP_OUT>(b_op);
+                    if (!(h & HDR_SCAN_DIV)) {
+                        // ---- carry chain: t = x + acc; limb = t & (2^n - 1); acc' = t >> n
+                        const bool small = !wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7]) != 0u) && sh >= 1u && sh <= 128u;
+                        if (small) {
+                            const uint32_t m[4] = {mask_word(sh, 0), mask_word(sh, 1), mask_word(sh, 2), mask_word(sh, 3)};
+                            const uint32_t xs[4] = {x.v[0], x.v[1], x.v[2], x.v[3]}, as[4] = {acc0.v[0], acc0.v[1], acc0.v[2], acc0.v[3]};
+                            uint32_t limb[4], carry[4];
+                            const uint32_t bs = sh & 31u;
+                            switch (sh >> 5) {
+                                case 0: scan_carry_rounds<0, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                case 1: scan_carry_rounds<1, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                case 2: scan_carry_rounds<2, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                case 3: scan_carry_rounds<3, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                default: scan_carry_rounds<4, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r.v[k] = role_acc ? carry[k] : limb[k];
+                        } else {
+                            Fr c = fr_zero(), limb = fr_zero();
+                            for (uint32_t it = 0; it < iters; ++it) {
+                                Fr in;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const uint32_t sft = wave_shr_lanes<D>(c.v[k]);
+                                    in.v[k] = start ? acc0.v[k] : sft;
+                                }
+                                const Fr t = fr_add_wave(x, in, pv);
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) limb.v[k] = t.v[k] & mask_word(sh, (uint32_t)k);
+                                c = u256_shr(t, sh);
+                            }
+                            r = u256_select(role_acc, c, limb);
+                        }
+                    } else {
+                        // ---- long division by one limb: t = acc * 2^k + x; q = t idiv d; acc' = t mod d (d == 0: both 0)
+                        const Fr d = fr_quad_perm<QP_ACC>(a_op), bm = fr_quad_perm<QP_ACC>(b_op);
+                        const bool dz = u256_is_zero(d);
+                        Fr ds = d;
+                        ds.v[0] |= dz ? 1u : 0u;
+                        const bool small = !wave_any((x.v[2] | x.v[3] | x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[2] | acc0.v[3] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7] |
+                                                      d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) != 0u) && sh >= 1u && sh <= 64u;
+                        Fr quo = fr_zero(), rem = fr_zero();
+                        if (small) {
+                            // every remainder stays below 2^64 (below d, or 0), so t = rem * 2^k + x < 2^128
+                            for (uint32_t it = 0; it < iters; ++it) {
+                                const uint32_t s0 = wave_shr_lanes<D>(rem.v[0]), s1 = wave_shr_lanes<D>(rem.v[1]);
+                                const unsigned long long in = ((unsigned long long)(start ? acc0.v[1] : s1) << 32) | (start ? acc0.v[0] : s0);
+                                // in * 2^k (k <= 64) + x as four words
+                                const unsigned long long lo = sh == 64u ? 0ull : in << sh, hi = sh == 64u ? in : (in >> 1) >> (63u - sh);
+                                const unsigned long long xl = ((unsigned long long)x.v[1] << 32) | x.v[0];
+                                const unsigned long long tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
+                                Fr t = fr_zero();
+                                t.v[0] = (uint32_t)tl; t.v[1] = (uint32_t)(tl >> 32); t.v[2] = (uint32_t)th; t.v[3] = (uint32_t)(th >> 32);
+                                Fr q1, r1;
+                                u128_divrem_64(q1, r1, t, ds);
+                                quo = u256_select(dz, fr_zero(), q1);
+                                rem = u256_select(dz, fr_zero(), r1);
+                            }
+                        } else {
+                            for (uint32_t it = 0; it < iters; ++it) {
+                                Fr in;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const uint32_t sft = wave_shr_lanes<D>(rem.v[k]);
+                                    in.v[k] = start ? acc0.v[k] : sft;
+                                }
+                                // (acc canonical) x (2^k in Montgomery form) = acc * 2^k mod r, canonical; any acc < 2^256 is reduced
+                                const Fr t = fr_add_wave(fr_mul_wave(in, bm, pv), x, pv);
+                                const uint32_t lx = u256_bitlen(t), ly = u256_bitlen(ds);
+                                const uint32_t my_dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;
+                                uint32_t dig = 0;
+#pragma unroll
+                                for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
+                                Fr q1, r1;
+                                u256_divrem_digits(q1, r1, t, ds, dig, ly);
+                                quo = u256_select(dz, fr_zero(), q1);
+                                rem = u256_select(dz, fr_zero(), r1);
+                            }
+                        }
+                        r = u256_select(role_acc, rem, quo);
+                    }
+                }
+                break;
+            }
             default: r = fr_zero(); break;
         }
         finish(r);
@@ -822,12 +845,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             atomicAdd(&prof[c * 4 + 0], pf[c][0]);
             atomicAdd(&prof[c * 4 + 3], pf[c][1]);
         }
-        atomicAdd(&prof[MODE == 2 ? 68 : 64], pf_fused[0]);
+        atomicAdd(&prof[MODE == 2 ? 68 : 64], pf_fused[0]);  // C_MULF / C_SCAN
         atomicAdd(&prof[MODE == 2 ? 71 : 67], pf_fused[1]);
-        if (MODE == 2) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) atomicAdd(&prof[72 + q], pm[q]);
-        }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -978,7 +997,8 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
         dims.stream_div_requests[0] = n_div_requests;
     }
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-    const uint32_t mode = p.has_fused;  // 0, 1: fused narrow bundles, 2: macro bundles (validate_program: never both)
+    const uint32_t mode = p.has_fused;  // 0, 1: fused narrow bundles, 2: scan bundles (validate_program: never both)
+    static_assert(SCAN_MAX_T == COOP_FUSE_MAX_T, "the instances with a MODE are made for tile widths up to COOP_FUSE_MAX_T");
     if (mode > 2 || (mode && T > COOP_FUSE_MAX_T)) return hipErrorInvalidValue;
 #define CWC_LAUNCH3(TT, PP, WW, KK)                                                                                                     \
     do {                                                                                                                                \
@@ -999,20 +1019,31 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     else if (W == 3 && pack == 1) CWC_LAUNCH3(TT, PP, 3, 1); \
     else if (W == 4 && pack == 1) CWC_LAUNCH3(TT, PP, 4, 1); \
     else return hipErrorInvalidValue;
+    // The stamped (PROF) instances exist in the diagnostic library only (make diag: -DCWC_DIAG, libcircom_witnesscalc_amd_diag.so,
+    // what tools/gpu_classprof.py and tools/gpu_calibrate.py load): they doubled the product's code object and its load time.
+#ifdef CWC_DIAG
+#define CWC_LAUNCH_PROF(TT, WW, KK) CWC_LAUNCH3(TT, true, WW, KK)
+#define CWC_LAUNCH2_PROF(TT) CWC_LAUNCH2(TT, true)
+#else
+#define CWC_LAUNCH_PROF(TT, WW, KK) return hipErrorNotSupported
+#define CWC_LAUNCH2_PROF(TT) return hipErrorNotSupported;
+#endif
 #define CWC_LAUNCH(TT)                                    \
     case TT:                                              \
-        if (prof) { CWC_LAUNCH2(TT, true) } else { CWC_LAUNCH2(TT, false) } \
+        if (prof) { CWC_LAUNCH2_PROF(TT) } else { CWC_LAUNCH2(TT, false) } \
         break;
     switch (T) {
         CWC_LAUNCH(1) CWC_LAUNCH(2) CWC_LAUNCH(4) CWC_LAUNCH(8) CWC_LAUNCH(16) CWC_LAUNCH(32)
         case 64:
             if (W != 0) return hipErrorInvalidValue;
-            if (pack == 4) { if (prof) CWC_LAUNCH3(64, true, 0, 4); else CWC_LAUNCH3(64, false, 0, 4); }
-            else if (pack == 1) { if (prof) CWC_LAUNCH3(64, true, 0, 1); else CWC_LAUNCH3(64, false, 0, 1); }
+            if (pack == 4) { if (prof) { CWC_LAUNCH_PROF(64, 0, 4); } else CWC_LAUNCH3(64, false, 0, 4); }
+            else if (pack == 1) { if (prof) { CWC_LAUNCH_PROF(64, 0, 1); } else CWC_LAUNCH3(64, false, 0, 1); }
             else return hipErrorInvalidValue;
             break;
         default: return hipErrorInvalidValue;
     }
+#undef CWC_LAUNCH_PROF
+#undef CWC_LAUNCH2_PROF
 #undef CWC_LAUNCH
 #undef CWC_LAUNCH2
 #undef CWC_LAUNCH3
@@ -1026,6 +1057,14 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
 #define CWC_KSRC_HASH "unstamped"
 #endif
 extern "C" const char* gwb_kernel_source_hash() { return CWC_KSRC_HASH; }
+// 1: this code object has the stamped (PROF) interpreter instances -- the diagnostic library (make diag)
+extern "C" int gwb_kernels_have_diagnostics() {
+#ifdef CWC_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 // An empty kernel of this code object: its first launch makes the runtime load the object (every interpreter instance) --
 // the single-shot entry point does that on a thread of its own while the host parses and compiles (runtime.cc warm_device).

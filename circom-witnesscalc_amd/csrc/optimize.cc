@@ -129,8 +129,8 @@ struct FrEq {
 // ---- the reference's PROBABILISTIC passes (src/graph.rs:499-583), opt-in (CWC_RANDOM_EVAL=1) -------------------------------
 // random_eval (:500-533): the graph evaluated on random field elements -- Add / Sub / Mul (and Neg) algebraically, every Input
 // and every other operation as a random function of its operand VALUES.  By Schwartz-Zippel two nodes with the same value
-// are the same polynomial in the inputs and the non-algebraic results (error probability ~ degree / r, below 2^-200 for any
-// graph that fits a file), which sees what structural value numbering cannot: (a + b) * c against a * c + b * c, sums in
+// are the same polynomial in the inputs and the non-algebraic results (error probability ~ degree / r for the algebraic
+// part, ~N^2 / 2^257 for collisions of the random functions: below 2^-200 for any graph that fits a file), which sees what structural value numbering cannot: (a + b) * c against a * c + b * c, sums in
 // another association, x - x.
 //   value_numbering (:536-562): every reference to a node goes to the FIRST node with its value.
 //   constants       (:565-583): a node with the same value under two independent evaluations is a constant.
@@ -145,16 +145,24 @@ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
+// The random function of (tag, operand values): FOUR independently keyed 64-bit lanes absorb every operand word, so two
+// different operand tuples collide only if all four lanes do (~N^2 / 2^257 over a graph's nodes; one 64-bit state expanded to
+// 256 bits -- the first version -- made unrelated nodes collide with probability N^2 / 2^65, 3e-6 for a 10 M-node graph, and
+// value numbering then merged them).  The reference draws fresh 256-bit randoms memoised on the operand tuple (graph.rs:523-532).
 Fr prf(uint64_t seed, uint64_t tag, const Fr* a, const Fr* b, const Fr* c) {
-    uint64_t h = mix64(seed ^ mix64(tag));
+    uint64_t h[4];
+    for (int k = 0; k < 4; ++k) h[k] = mix64((seed + 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1)) ^ mix64(tag + 0xd1b54a32d192ed03ull * (uint64_t)k));
     for (const Fr* x : {a, b, c}) {
         if (!x) continue;
-        for (int i = 0; i < 8; i += 2) h = mix64(h ^ ((uint64_t)x->v[i] | ((uint64_t)x->v[i + 1] << 32)));
-        h = mix64(h + 0x51);
+        for (int i = 0; i < 8; i += 2) {
+            const uint64_t w = (uint64_t)x->v[i] | ((uint64_t)x->v[i + 1] << 32);
+            for (int k = 0; k < 4; ++k) h[k] = mix64(h[k] ^ w);
+        }
+        for (int k = 0; k < 4; ++k) h[k] = mix64(h[k] + 0x51);
     }
     uint8_t bytes[32];
     for (int k = 0; k < 4; ++k) {
-        const uint64_t w = mix64(h + 0x1000193ull * (uint64_t)(k + 1));
+        const uint64_t w = mix64(h[k] + 0x1000193ull * (uint64_t)(k + 1));
         memcpy(bytes + 8 * k, &w, 8);
     }
     return u256_from_le_bytes_mod_order(bytes, 32);  // a field element, read as a Montgomery residue

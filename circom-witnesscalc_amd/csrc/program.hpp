@@ -29,6 +29,7 @@ struct ProgramStats {
     uint64_t n_conversions = 0, n_canonical = 0, form_cycles_saved = 0;  // representation inference: inserted conversions, operations whose value is kept as a canonical integer
     uint64_t n_folded = 0, n_numbered = 0, n_shaken = 0;  // load-time optimiser: operations folded to constants / aliases, nodes merged by value numbering, unused nodes dropped
     uint64_t n_fused_nodes = 0;         // fused narrow chains made by the compiler (class C_MULF)
+    uint64_t n_scan_steps = 0;          // steps of serial limb recurrences run inside scan bundles (class C_SCAN)
 };
 
 struct Program {

@@ -46,25 +46,26 @@ enum BundleClass : uint32_t {
     // trash | op3, x2_lds | x3_lds << 16}; header bits HDR_F_* say which stages any node of the bundle has.  Plain
     // multiplications ride as nodes with op2 = op3 = none.
     C_MULF = 13,
-    // macro bundle (round 3, tile widths up to COOP_FUSE_MAX_T): up to four consecutive narrow bundles of the schedule
-    // (narrow multiplication bundles and short linear bundles, typically a dependent chain) run as the STAGES of one bundle:
-    // one fetch / staging / bookkeeping front end instead of four, and a stage reads the result of the stage before it
-    // from the registers of its four lanes (the group's accumulator) instead of the ring.  Record position 4g + k is stage k
-    // of lane group g: {a_off, b_off, dst | ctrl, a_lds | b_lds << 16} as everywhere, ctrl = bits 0-1 operation (SUB_ADD,
-    // SUB_SUB, SUB_MULT), bit 2 operand a is the accumulator, bit 3 active, bit 4 operand b is the accumulator.  Every
-    // stage's result goes to ring cell 4g + k of the bundle and to its slot; an operand produced by an earlier stage of the
-    // same bundle that is not the accumulator is re-read from the ring in front of its stage (header bit HDR_M_LATE).
-    // Exact: the stages are the nodes' own field operations (graph.rs:105, 110-111) in dependency order.
-    C_MACRO = 14,
+    // scan bundle (round 4, tile widths up to SCAN_MAX_T): the steps of a serial limb recurrence -- the carry chain of a
+    // multi-limb sum, the remainder chain of a long division by one limb -- in consecutive PAIRS of node slots, run by a
+    // loop of `iterations` rounds inside ONE bundle: every round each pair computes its step from its own operand x and the
+    // accumulator that arrives from the pair in front of it (lane shift), so after round s the first s + 1 steps of every
+    // chain segment are final (a systolic fixed point: a finished step recomputes the same values).  The unfused graph pays
+    // two or three bundles of ~600 cycles of front end for each step.
+    //   CARRY  t = x + acc (graph.rs:110);  out = t & (2^n - 1) (Band, :674-687; Mod 2^n, :117-121);  acc' = t >> n (Shr, :637-672; Idiv 2^n, :112-116)
+    //   DIV    t = acc * 2^k + x (:105, :110);  out = t idiv d (:112-116);  acc' = t mod d (:117-121)   [d == 0 -> both 0]
+    // all on canonical integers with the reference's modular semantics (t is reduced mod r; a wave-uniform test picks the
+    // straight limb-sized path or the general 256-bit one).  Position 2p = the step's OUT record {x_off, acc_in_off (chain
+    // start only), dst | ACTIVE | START?, x_lds | acc_lds << 16}, position 2p + 1 = its ACC record {d_off, (2^k)_Montgomery_off,
+    // dst | ACTIVE | ROLE_ACC | START?, d_lds | B_lds << 16} (CARRY: both unused).  Header: bit 11 kind (0 CARRY, 1 DIV), bits
+    // 19-26 the shift n / k (< 254), bits 27-31 iterations - 1 (the longest chain segment of the bundle), count = positions in use.
+    C_SCAN = 14,
     C_COUNT = 15
 };
-static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4, COOP_FUSE_MAX_T = 2, MACRO_STAGES = 4;
-// C_MACRO header: two bits per stage (0 none -- the bundle ends, 1 products only, 2 products and linear nodes, 3 linear
-// nodes only); stage k >= 1: some lane re-reads a ring operand written by an earlier stage (LATE), some lane's full-width
-// factor a is the accumulator (GATHER: the group's four lanes exchange their limbs)
-enum MacroStageKind : uint32_t { MSK_NONE = 0, MSK_MUL = 1, MSK_MIXED = 2, MSK_LIN = 3 };
-static const int HDR_M_KIND_SHIFT = 19, HDR_M_LATE_SHIFT = 26, HDR_M_GATHER_SHIFT = 10;  // kinds: bits 19-26; LATE of stage k: bit 26 + k; GATHER: bit 10 + k
-static const uint32_t MCTRL_OP_MASK = 3u, MCTRL_A_ACC = 4u, MCTRL_ACTIVE = 8u, MCTRL_B_ACC = 16u, MCTRL_MASK = 31u;
+static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4, COOP_FUSE_MAX_T = 2, SCAN_MAX_T = 2;
+static const uint32_t HDR_SCAN_DIV = 1u << 11;
+static const int HDR_SCAN_SHIFT_SHIFT = 19, HDR_SCAN_ITER_SHIFT = 27;
+static const uint32_t SCAN_ROLE_ACC = 1u, SCAN_START = 2u;  // sub-op bits of a scan record
 // stage codes of a fused node (C_MULF): op2 in the low three bits of the main record's ctrl, op3 in the extra record's
 enum FusedOp : uint32_t { FOP_NONE = 0, FOP_MUL = 1, FOP_ADD = 2, FOP_SUB = 3 /* acc - x */, FOP_RSUB = 4 /* x - acc */ };
 static const uint32_t HDR_F_S2MUL = 1u << 11, HDR_F_S2LIN = 1u << 12, HDR_F_S3LIN = 1u << 13;  // C_MULF: stages present in the bundle
@@ -152,7 +153,7 @@ struct ProgramDev {
     const uint32_t* witness_refs;  // [n_witness]
     const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
-    uint32_t has_fused;            // bit 0: the program has C_MULF bundles, bit 1: C_MACRO bundles (the interpreter instance with their path is launched)
+    uint32_t has_fused;            // 1: the program has C_MULF bundles, 2: C_SCAN bundles (the interpreter instance with their path is launched)
     uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4], stream_cref_first[4];  // (program.hpp; MAX_STREAMS entries)
 };
 

@@ -25,6 +25,9 @@
 #include <vector>
 
 #define GW_NO_INLINE_FREE_STATUS
+#ifndef CWC_TREE_HASH
+#define CWC_TREE_HASH "unstamped"
+#endif
 #include "../../include/graph_witness_batch.h"
 #include "graph.hpp"
 #include "program.hpp"
@@ -116,7 +119,7 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
     dp.dev.has_fused = 0;  // (from the bundle headers themselves: an imported program's statistics are not what the kernel runs)
-    for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : (h & HDR_CLASS_MASK) == C_MACRO ? 2u : 0u;
+    for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : (h & HDR_CLASS_MASK) == C_SCAN ? 2u : 0u;
     dp.dev.n_streams = p.n_streams;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dp.dev.stream_first[s] = p.stream_first[s];
@@ -415,6 +418,7 @@ std::vector<uint8_t> exported_bytes(const Program& p, const std::vector<InputSig
     return b;
 }
 void write_file_atomically(const std::string& path, const void* data, size_t n);
+std::vector<uint8_t> cache_wrap(const std::string& path, const void* blob, size_t n);
 
 // the full choice for a batch size, on a thread of its own (reads the graph only): every candidate compiled with the
 // search over schedule variants, priced by the cost model
@@ -443,7 +447,9 @@ gwb_graph::Refined refine_choice(const Graph& graph, const ProgramStats& stats, 
 
 // The program key for a batch: forced / environment override, else the static rule's width and its neighbours
 // compiled (host only) and priced with the cost model; the choice is remembered per batch size.
-uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
+// allow_quick = false: the caller wants the searched program now (the program that is exported / broadcast to other ranks:
+// imported handles are never refined, a provisional single-schedule program would stay with them for good).
+uint32_t pick_tile_width(gwb_graph* g, size_t batch, bool allow_quick = true) {
     if (!g->has_graph && !g->progs.empty()) return g->progs.begin()->first;  // imported: the one program it has
     if (g->forced_T) return g->forced_T;
     if (const char* e = getenv("CWC_TILE_WIDTH")) {  // width, or width + 256 for the asynchronous divider
@@ -471,6 +477,10 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
     if (batch < 64 && g->graph.nodes.size() <= 2000000 && !getenv("CWC_NO_QUICK_FIRST_CALL")) {
         auto job = g->refining.find(batch);
         if (job != g->refining.end()) {
+            if (!allow_quick) {  // wait for the search that is under way
+                if (g->refine_gate) g->refine_gate->store(true);
+                job->second.wait();
+            }
             if (job->second.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return g->provisional[batch];
             gwb_graph::Refined r = job->second.get();
             g->refining.erase(job);
@@ -494,12 +504,12 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
         const bool has_div0 = g->stats.class_nodes[C_DIV] > 0;
         const uint32_t t1 = std::max(1u, min_t);
         const uint32_t quick_key = t1 | (has_div0 && t1 < 64 ? KEY_DIVIDER : 0u) | (t1 < 64 && !getenv("CWC_NO_STREAMS") ? KEY_STREAMS4 : 0u);
-        if (!g->progs.count(quick_key) && !g->compiled.count(quick_key)) {
+        if (allow_quick && !g->progs.count(quick_key) && !g->compiled.count(quick_key)) {
             std::unique_ptr<Program> p(new Program());
             std::string err;
             if (compile_program(g->graph, quick_key & ~KEY_MODE_MASK, key_divider_waves(quick_key), *p, err, key_streams(quick_key), true)) g->compiled[quick_key] = std::move(p);
         }
-        if (g->progs.count(quick_key) || g->compiled.count(quick_key)) {
+        if (allow_quick && (g->progs.count(quick_key) || g->compiled.count(quick_key))) {
             const Graph* graph = &g->graph;
             const ProgramStats stats = g->stats;
             g->provisional[batch] = quick_key;
@@ -516,7 +526,7 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch) {
                 auto best = r.programs.find(r.best);
                 if (!cache_file.empty() && r.best && best != r.programs.end()) {
                     try {
-                        const std::vector<uint8_t> b = exported_bytes(*best->second, inputs);
+                        const std::vector<uint8_t> b0 = exported_bytes(*best->second, inputs), b = cache_wrap(cache_file, b0.data(), b0.size());
                         write_file_atomically(cache_file, b.data(), b.size());
                         if (getenv("CWC_DEBUG_CACHE")) fprintf(stderr, "program cache: wrote %s (program key %#x, %zu bytes)\n", cache_file.c_str(), r.best, b.size());
                     } catch (...) {
@@ -601,6 +611,12 @@ std::string run_device(gwb_graph* g, const void* d_inputs, size_t batch, void* d
     auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_0 = dbg_steps ? now_ms() : 0.0;
     const uint32_t key = pick_tile_width(g, batch);
+    struct OpenGate {  // every way out of this call (errors included) lets a waiting background search start
+        gwb_graph* g;
+        ~OpenGate() {
+            if (g->refine_gate) g->refine_gate->store(true);
+        }
+    } open_gate{g};
     const double t_1 = dbg_steps ? now_ms() : 0.0;
     DeviceProgram* dp = nullptr;
     std::string err = get_program(g, key, &dp);
@@ -1035,12 +1051,41 @@ std::string program_cache_file(const void* graph_data, size_t len) {
         if (!home || !*home) return "";
         dir = std::string(home) + "/.cache/circom-witnesscalc-amd";
     }
-    // (this build, the program format, the cost model's cycle table: a program is chosen under one table)
+    // (this build -- the content hash of every source under csrc/ as the Makefile stamped it, not a timestamp: the compiler
+    // and the kernels that give a program its meaning are compiled separately from this file --, the program format, the
+    // cost model's cycle table: a program is chosen under one table)
     static const std::string build = []() {
-        const std::string id = std::string(__DATE__ " " __TIME__ " format 15 table ") + std::to_string((unsigned long long)model_table_id());
-        return sha256_hex((const uint8_t*)id.data(), id.size()).substr(0, 12);
+        const std::string id = std::string(CWC_TREE_HASH " format 16 table ") + std::to_string((unsigned long long)model_table_id());
+        return sha256_hex((const uint8_t*)id.data(), id.size()).substr(0, 16);
     }();
     return dir + "/" + sha256_hex((const uint8_t*)graph_data, len) + "-" + build + ".cwcprog";
+}
+// A cache file = 96 bytes that name what it is for -- "CWCPROG2", then <sha256 of the graph image>-<build> as in its file name,
+// zero-padded -- followed by the blob of gwb_graph_export: a file that was renamed or copied over another entry, or written
+// by another build under a colliding name, does not pass for this graph's program.
+static const size_t kCacheHeader = 96;
+std::string cache_entry_name(const std::string& path) {
+    const size_t slash = path.rfind('/'), dot = path.rfind(".cwcprog");
+    const size_t a = slash == std::string::npos ? 0 : slash + 1;
+    return dot == std::string::npos || dot < a ? path.substr(a) : path.substr(a, dot - a);
+}
+std::vector<uint8_t> cache_wrap(const std::string& path, const void* blob, size_t n) {
+    std::vector<uint8_t> out(kCacheHeader + n, 0);
+    memcpy(out.data(), "CWCPROG2", 8);
+    const std::string name = cache_entry_name(path);
+    memcpy(out.data() + 8, name.data(), std::min(name.size(), kCacheHeader - 8));
+    memcpy(out.data() + kCacheHeader, blob, n);
+    return out;
+}
+bool cache_unwrap(const std::string& path, const std::vector<uint8_t>& file, const uint8_t** blob, size_t* n) {
+    if (file.size() < kCacheHeader || memcmp(file.data(), "CWCPROG2", 8) != 0) return false;
+    const std::string name = cache_entry_name(path);
+    uint8_t want[kCacheHeader - 8] = {0};
+    memcpy(want, name.data(), std::min(name.size(), sizeof want));
+    if (name.size() > sizeof want || memcmp(file.data() + 8, want, sizeof want) != 0) return false;
+    *blob = file.data() + kCacheHeader;
+    *n = file.size() - kCacheHeader;
+    return true;
 }
 bool read_file(const std::string& path, std::vector<uint8_t>& out) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -1096,6 +1141,8 @@ bool quirks() {
 // =====================================================================================================
 // exported C symbols
 // =====================================================================================================
+extern "C" int gwb_kernels_have_diagnostics();  // kernels.hip
+
 extern "C" {
 
 void gwb_free_status(gw_status_t* status) {
@@ -1429,7 +1476,15 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
     std::string drain_err, parse_err;
     size_t parse_bad = (size_t)-1;
     std::vector<uint32_t> st_host(B, 0);
-    std::thread drains[2];
+    // (joined on every way out of this function: an exception that unwinds past a joinable std::thread ends the process)
+    struct Drains {
+        std::thread t[2];
+        ~Drains() {
+            for (auto& d : t)
+                if (d.joinable()) d.join();
+        }
+    } drain_threads;
+    std::thread* const drains = drain_threads.t;
     auto drain = [&](size_t k) {  // witness rows of sub-batch k: HBM -> staging -> files
         const int par = (int)(k & 1);
         const size_t lo = k * S, n = std::min(S, B - lo);
@@ -1455,9 +1510,21 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
             const size_t s0 = i * slice_sets, m = std::min(slice_sets, n - s0);
             okc = okc && hipEventSynchronize(slice_done[par][bb]) == hipSuccess;
             if (!okc) break;
-            pending[par][bb].store((int)m, std::memory_order_release);
-            for (size_t q = 0; q < m; ++q)
-                pool.push(WriterPool::Task{(const uint8_t*)bf.stage[par][bb] + q * row_b, first_index + lo + s0 + q, &pending[par][bb]});
+            // a set whose status word is not zero (the reference panics there: Shl overflow, bit operation == r) gets NO file --
+            // a well-formed `.wtns` of a failed evaluation could not be told from a valid one -- and a file of that name left by
+            // an earlier run is removed
+            size_t m_ok = 0;
+            for (size_t q = 0; q < m; ++q) m_ok += st_host[lo + s0 + q] == 0;
+            pending[par][bb].store((int)m_ok, std::memory_order_release);
+            for (size_t q = 0; q < m; ++q) {
+                if (st_host[lo + s0 + q] == 0) {
+                    pool.push(WriterPool::Task{(const uint8_t*)bf.stage[par][bb] + q * row_b, first_index + lo + s0 + q, &pending[par][bb]});
+                } else {
+                    char path[4096];
+                    const int pn = snprintf(path, sizeof path, path_pattern, (unsigned long)(first_index + lo + s0 + q));
+                    if (pn > 0 && (size_t)pn < sizeof path) (void)remove(path);
+                }
+            }
         }
         if (!okc) {
             (void)hipStreamSynchronize(bf.copy[par]);
@@ -1534,15 +1601,30 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
             err = "hipEventRecord failed";
             break;
         }
-        drains[par] = std::thread(drain, k);
+        try {
+            drains[par] = std::thread(drain, k);
+        } catch (const std::system_error&) {  // no thread to be had: this sub-batch is drained by the calling thread
+            drain(k);
+        }
     }
-    for (auto& d : drains)
-        if (d.joinable()) d.join();
+    for (int q = 0; q < 2; ++q)
+        if (drains[q].joinable()) drains[q].join();
     pool.finish();
     if (err.empty()) err = drain_err;
     if (err.empty()) err = pool.err;
     if (!err.empty()) return fail(status, err);
     if (set_status_out) memcpy(set_status_out, st_host.data(), B * 4);
+    size_t n_failed = 0, first_failed = 0;
+    for (size_t i = B; i-- > 0;)
+        if (st_host[i]) {
+            ++n_failed;
+            first_failed = i;
+        }
+    if (stats) stats->failed_sets = n_failed;
+    // without a status buffer nobody could tell which sets have no file: the call itself fails (as the reference's single call does)
+    if (n_failed && !set_status_out)
+        return fail(status, "Failed to calculate witness: input set " + std::to_string(first_failed) + ": " + set_status_text(st_host[first_failed]) + " (" +
+                                std::to_string(n_failed) + " of " + std::to_string(B) + " input sets failed; no file was written for them)");
     if (stats) {
         stats->n_sets = B;
         stats->sub_batch = S;
@@ -1573,7 +1655,7 @@ uint32_t gwb_graph_pick_tile_width(gwb_graph_t* g, size_t batch) {
     if (!g) return 0;
     try {
         std::lock_guard<std::mutex> lk(g->mu);
-        return pick_tile_width(g, batch);
+        return pick_tile_width(g, batch, false);  // (what is asked for here is exported / broadcast: the searched program, not the quick first one)
     } catch (...) {
         return 0;
     }
@@ -1749,6 +1831,9 @@ int gwb_profile_classes(gwb_graph_t* g, const void* d_inputs, size_t batch, void
     // Diagnostic: one batch through the stamped interpreter build; out36[class*4 + {load, compute, store, count}]
     // in shader cycles, summed over the sampled waves (lane 0 of every 64th tile).
     if (!g || !out36) return fail(status, "null argument");
+    if (!gwb_kernels_have_diagnostics())
+        return fail(status, "class profiling needs the diagnostic library (make -C circom-witnesscalc_amd/csrc diag; load it with CWC_LIB_PATH=<path of "
+                            "libcircom_witnesscalc_amd_diag.so>): the product library carries no stamped interpreter instances");
     std::lock_guard<std::mutex> lk(g->mu);
     std::string err = check_device();
     if (!err.empty()) return fail(status, err);
@@ -1985,7 +2070,10 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
         if (!cf.empty() && read_file(cf, blob)) {  // a program an earlier process compiled for this very image (the import checks for a device behind its host work)
             gwb_graph_t* imported = nullptr;
             gw_status_t st2{OK, nullptr};
-            if (gwb_graph_import(blob.data(), blob.size(), &imported, &st2) == 0) g.reset(imported);
+            const uint8_t* body = nullptr;
+            size_t body_len = 0;
+            if (!cache_unwrap(cf, blob, &body, &body_len)) set_status(&st2, ERROR, "not this graph's / this build's cache entry");
+            else if (gwb_graph_import(body, body_len, &imported, &st2) == 0) g.reset(imported);
             if (getenv("CWC_DEBUG_CACHE")) fprintf(stderr, "program cache: %s %s%s%s\n", g ? "hit" : "ignored", cf.c_str(), g ? "" : ": ", g ? "" : (st2.error_msg ? st2.error_msg : "?"));
             gwb_free_status(&st2);  // (a damaged / stale file: fall through to the compiler, the file is rewritten)
         }
@@ -2043,7 +2131,8 @@ int gw_calc_witness(const char* inputs, const void* graph_data, const size_t gra
             size_t blob_len = 0;
             gw_status_t st2{OK, nullptr};
             if (gwb_graph_export(g.get(), key, &blob, &blob_len, &st2) == 0) {
-                write_file_atomically(cf, blob, blob_len);
+                const std::vector<uint8_t> wrapped = cache_wrap(cf, blob, blob_len);
+                write_file_atomically(cf, wrapped.data(), wrapped.size());
                 if (getenv("CWC_DEBUG_CACHE")) fprintf(stderr, "program cache: wrote %s (program key %#x, %zu bytes)\n", cf.c_str(), key, blob_len);
             }
             gwb_free_status(&st2);

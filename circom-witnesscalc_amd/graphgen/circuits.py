@@ -782,3 +782,42 @@ def build_chain_heavy(seed, n_chains=12, n_inputs=5):
         if rnd.random() < 0.7:
             b.signal(acc)
     return b
+
+
+def build_limb_chains(n_bits=64, k_bits=64, steps=10, chains=2, mask_inputs=False, fork=False):
+    """Serial limb recurrences on operands that come straight from the inputs (any field element, unless mask_inputs): per
+    chain a carry chain `t = x + carry; limb = t % 2^n; carry = t \\ 2^n` and a remainder chain `t = rem * 2^k + x;
+    q = t \\ d; rem = t % d` -- the idioms of limb-wise big-integer circuits that the compiler runs as scan bundles, here
+    with every shift / base width and with operands outside the limb range (the general paths of the kernels).  fork:
+    some accumulators feed two steps (a chain that splits), and a step's x is another step's output."""
+    b = Builder()
+    xs = b.input("x", steps * chains)
+    acc0 = b.input("acc", chains)
+    ds = b.input("d", chains)
+    base_n, base_k = b.const(1 << n_bits), b.const(1 << k_bits)
+    if mask_inputs:
+        m = b.const((1 << min(n_bits, k_bits, 64)) - 1)
+        xs = [b.op("Band", v, m) for v in xs]
+        acc0 = [b.op("Band", v, m) for v in acc0]
+        ds = [b.op("Band", v, m) for v in ds]
+    for ch in range(chains):
+        carry = acc0[ch]
+        limbs = []
+        for c in range(steps):
+            x = xs[ch * steps + c]
+            if fork and c == steps // 2 and limbs:
+                x = limbs[0]                      # (an earlier step's output as this step's x)
+            t = b.add(x, carry)
+            limbs.append(b.signal(b.op("Mod", t, base_n)))
+            nxt = b.signal(b.op("Idiv", t, base_n))
+            if fork and c == steps // 3:
+                t2 = b.add(xs[ch * steps], nxt)   # a second step on the same accumulator
+                b.signal(b.op("Mod", t2, base_n))
+                b.signal(b.op("Idiv", t2, base_n))
+            carry = nxt
+        rem = acc0[ch]
+        for c in range(steps):
+            t = b.add(b.mul(rem, base_k), xs[ch * steps + (steps - 1 - c)])
+            b.signal(b.op("Idiv", t, ds[ch]))
+            rem = b.signal(b.op("Mod", t, ds[ch]))
+    return b

@@ -92,8 +92,12 @@ int gwb_wtns_save_batch(const void *witness, size_t n_witness, size_t batch, con
  * set, path_pattern with one %lu conversion for first_index + the set's position.  Sub-batches move through a pipeline: the
  * next one is parsed (host threads) and evaluated while the witness rows of the previous one leave HBM in slices through
  * pinned staging and writer threads frame them as files (lib.rs:114-123).  *n_sets = input sets found; set_status (NULL or
- * max_sets words) takes the per-set status words.  CWC_E2E_SUBBATCH (default 1024), CWC_PARSE_THREADS (default all cores),
- * CWC_WRITE_THREADS (default min(cores, 16)), CWC_E2E_SLICE_MB (default 96) tune it. */
+ * max_sets words) takes the per-set status words.  A set whose status word is not zero -- the cases in which the
+ * reference's evaluate() panics (src/graph.rs:634, :701, :716) -- gets NO file (one of that name from an earlier run is
+ * removed): with a status buffer the call returns 0 and the words say which sets failed (stats->failed_sets counts them);
+ * with set_status == NULL a failed set makes the call return 1 with a message naming the first one.  CWC_E2E_SUBBATCH
+ * (default 1024), CWC_PARSE_THREADS (default all cores), CWC_WRITE_THREADS (default min(cores, 16)), CWC_E2E_SLICE_MB
+ * (default 96) tune it. */
 typedef struct {
   size_t n_sets, sub_batch;
   uint32_t parse_threads, write_threads;
@@ -101,6 +105,7 @@ typedef struct {
   double wait_for_drain_seconds;   /* the calling thread waiting for copies / file writes before it could reuse buffers */
   double total_seconds;
   uint64_t witness_bytes;
+  uint64_t failed_sets;            /* input sets with a non-zero status word: no file written */
 } gwb_e2e_stats_t;
 int gwb_calc_witness_json_to_wtns(gwb_graph_t *g, const char *text, size_t text_len, const char *path_pattern, size_t first_index,
                                   size_t *n_sets, uint32_t *set_status, size_t max_sets, gwb_e2e_stats_t *stats, gw_status_t *status);

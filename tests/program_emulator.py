@@ -21,19 +21,18 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d48Q"
+HDR_FMT = "<12I12I6I12d49Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
-CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "MACRO"]
+CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "SCAN"]
 N_CLASSES = len(CLASS_NAMES)
 FOP_NONE, FOP_MUL, FOP_ADD, FOP_SUB, FOP_RSUB = range(5)  # stage codes of a fused node (class MULF)
 HDR_F_S2MUL, HDR_F_S2LIN, HDR_F_S3LIN = 1 << 11, 1 << 12, 1 << 13
 COOP_FUSE_MAX_T = 2
 COOP_LANES, COOP_MAX_T = 4, 4
-# macro bundles (class MACRO): record position 4g + k = stage k of lane group g; header: two bits per stage from bit 19
-# (0 none, 1 products, 2 products and linear nodes, 3 linear nodes), LATE of stage k at bit 26 + k, GATHER at bit 10 + k
-MACRO_STAGES, HDR_M_KIND_SHIFT, HDR_M_LATE_SHIFT, HDR_M_GATHER_SHIFT = 4, 19, 26, 10
-MCTRL_OP_MASK, MCTRL_A_ACC, MCTRL_ACTIVE, MCTRL_B_ACC, MCTRL_MASK = 3, 4, 8, 16, 31
+# scan bundles (class SCAN): pairs of record positions (2p: the step's OUT record, 2p + 1: its ACC record); header bit 11
+# kind (0 carry chain, 1 long division by one limb), bits 19-26 the shift, bits 27-31 iterations - 1; sub-op bit 0 role, bit 1 START
+SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_ACC, SCAN_START = 2, 1 << 11, 19, 27, 1, 2
 
 
 def blob_checksum(body):
@@ -65,7 +64,7 @@ class Blob:
         st = h[42:]
         c0, c1, c2 = 6, 6 + N_CLASSES, 6 + 2 * N_CLASSES
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11])
+                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -147,7 +146,7 @@ def run(blob: Blob, inputs_row):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         name = CLASS_NAMES[cls]
-        assert (h >> 19 == 0 or name == "MACRO") and h >> 30 == 0 and (1 <= cnt <= G or (cnt == 0 and name in ("LIN", "SYNC")))
+        assert (h >> 19 == 0 or name == "SCAN") and (1 <= cnt <= G or (cnt == 0 and name in ("LIN", "SYNC")))
         assert (name == "SYNC") == bool(h & (HDR_POST | HDR_WAIT)) and not (name == "SYNC" and cnt)
         a_canon, b_canon, out_canon = bool(h & HDR_A_CANON), bool(h & HDR_B_CANON), bool(h & HDR_OUT_CANON)
         assert not (a_canon or b_canon) or name in ("BIT", "IDIVMOD", "CMPS")
@@ -169,74 +168,54 @@ def run(blob: Blob, inputs_row):
             request = {}
         if name == "DIVGET":
             assert blob.divider and mailbox is not None and len(mailbox) == cnt, "collect must mirror the request"
-        macro_cells = None
-        if name == "MACRO":
-            # The stages in order; within a stage every lane group reads its operands -- memory operands from its own stage
-            # cells, results of the three bundles before from the ring (read before the first stage writes), results of
-            # earlier stages of this bundle from the group's accumulator (ctrl bits) or from this bundle's own ring cells,
-            # which needs the stage's LATE bit -- then the stage's results become visible.
-            assert T <= COOP_FUSE_MAX_T and blob.stats["class_bundles"][CLASS_NAMES.index("MULF")] == 0 and (h >> 14) & 0x1F == 0
-            kinds = [(h >> (HDR_M_KIND_SHIFT + 2 * k)) & 3 for k in range(MACRO_STAGES)]
-            late = [k > 0 and bool((h >> (HDR_M_LATE_SHIFT + k)) & 1) for k in range(MACRO_STAGES)]
-            gather = [k > 0 and bool((h >> (HDR_M_GATHER_SHIFT + k)) & 1) for k in range(MACRO_STAGES)]
-            n_st = kinds.index(0) if 0 in kinds else MACRO_STAGES
-            assert n_st >= 2 and not any(kinds[n_st:]) and not any(late[n_st:]) and not any(gather[n_st:]), "stages without a gap, at least two"
-            acc, macro_cells, n_active = {}, {}, 0
-            for k in range(MACRO_STAGES):
-                seen = {"mul": False, "lin": False, "late": False, "gather": False}
-                out_k = []
-                for grp in range(G // MACRO_STAGES):
-                    pos = MACRO_STAGES * grp + k
-                    a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
-                    ctrl, dst = dctl & MCTRL_MASK, dctl & ~MCTRL_MASK
-                    if not ctrl & MCTRL_ACTIVE:
-                        assert ctrl == 0 and dst == trash and a_off == zero_off and b_off == zero_off, "idle group of a stage"
-                        continue
-                    assert k < n_st, "a node in a stage the header does not have"
-                    n_active += 1
-
-                    def mfetch(off, la, q, is_acc):
-                        if is_acc:
-                            assert k > 0 and grp in acc and off == zero_off, "accumulator operand without a result in the group"
-                            rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
-                            assert rs == b % RING_BUNDLES and macro_cells[rem // (16 * T)] == acc[grp], "the accumulator operand names the producer's cell"
-                            return acc[grp]
-                        if la == stage + 2 * q * LDS_HALF_BYTES + pos * T * 16:
-                            return mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD)
-                        assert off == zero_off, "ring operand must stage the zero constant"
-                        rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
-                        assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
-                        cell = rem // (16 * T)
-                        if rs == b % RING_BUNDLES:  # this bundle's own ring slot: a result of an earlier stage, read again
-                            assert late[k] and cell in macro_cells, "operand from an earlier stage without the LATE bit"
-                            seen["late"] = True
-                            return macro_cells[cell]
-                        wb, val = ring[(rs, cell)]
-                        assert 1 <= b - wb <= RING_BUNDLES - 1, "ring cell too old for a macro bundle"
-                        return val
-                    x = mfetch(a_off, lds & 0xFFFF, 0, bool(ctrl & MCTRL_A_ACC))
-                    y = mfetch(b_off, lds >> 16, 1, bool(ctrl & MCTRL_B_ACC))
-                    op = ctrl & MCTRL_OP_MASK
-                    assert op <= 2
-                    if op == 2:
-                        seen["mul"] = True
-                        if ctrl & MCTRL_A_ACC:
-                            assert gather[k], "the accumulator as the full-width factor needs the GATHER bit"
-                            seen["gather"] = True
-                        v = x * y * R_INV % model.M
-                    else:
-                        seen["lin"] = True
-                        v = (x + y) % model.M if op == 0 else (x - y) % model.M
-                    out_k.append((grp, pos, dst, v))
-                if k < n_st:
-                    assert kinds[k] == (2 if seen["mul"] and seen["lin"] else 1 if seen["mul"] else 3), "stage kind must describe the records"
-                    assert late[k] == seen["late"] and gather[k] == seen["gather"], "LATE / GATHER bits must describe the records"
-                for grp, pos, dst, v in out_k:
-                    acc[grp] = v
-                    macro_cells[pos] = v
-                    results.append((dst, v))
-            assert n_active == cnt
-        for pos in range(0 if name == "MACRO" else G):
+        def fetch(off, la, q, rec_pos):
+            """operand q (0: a fields, 1: b fields) of the record at position rec_pos: its own stage cell or a ring cell"""
+            own_cell = stage + 2 * q * LDS_HALF_BYTES + rec_pos * T * 16
+            if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
+                return mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD)
+            assert off == zero_off, "ring operand must stage the zero constant"
+            rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
+            assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
+            wb, val = ring[(rs, rem // (16 * T))]
+            assert 1 <= b - wb <= RING_BUNDLES, "ring cell too old"
+            return val
+        if name == "SCAN":
+            # The steps of serial limb recurrences in consecutive pairs of positions, chain segments one behind the other: a
+            # step takes the accumulator of the pair in front of it unless its START bit says "my own operand".  All values
+            # are canonical integers; the arithmetic is the unfused nodes' (x + acc, Band / Shr; acc * 2^k + x, Idiv / Mod).
+            assert T <= SCAN_MAX_T and cnt % 2 == 0 and blob.stats["class_bundles"][CLASS_NAMES.index("MULF")] == 0 and (h & 0x7F000) == 0
+            is_div, sh, iters = bool(h & HDR_SCAN_DIV), (h >> HDR_SCAN_SHIFT_SHIFT) & 0xFF, (h >> HDR_SCAN_ITER_SHIFT) + 1
+            assert sh < 254
+            acc, seg, longest = None, 0, 0
+            for pr in range(cnt // 2):
+                ro = blob.recs[(b * G + 2 * pr) * 4:(b * G + 2 * pr) * 4 + 4]
+                ra = blob.recs[(b * G + 2 * pr + 1) * 4:(b * G + 2 * pr + 1) * 4 + 4]
+                co, ca = ro[2] & CTRL_MASK, ra[2] & CTRL_MASK
+                assert co & CTRL_ACTIVE and ca & CTRL_ACTIVE and not (co & SCAN_ROLE_ACC) and (ca & SCAN_ROLE_ACC) and not ((co | ca) & 4) and (co ^ ca) & SCAN_START == 0
+                x = fetch(ro[0], ro[3] & 0xFFFF, 0, 2 * pr)
+                if co & SCAN_START:
+                    acc, seg = fetch(ro[1], ro[3] >> 16, 1, 2 * pr), 1
+                else:
+                    assert acc is not None and ro[1] == zero_off, "a step without a chain in front of it"
+                    seg += 1
+                longest = max(longest, seg)
+                assert x < model.M and acc < model.M
+                if is_div:
+                    d, bm = fetch(ra[0], ra[3] & 0xFFFF, 0, 2 * pr + 1), fetch(ra[1], ra[3] >> 16, 1, 2 * pr + 1)
+                    assert bm == (1 << sh) * R_MONT % model.M, "the base operand is 2^k in Montgomery form"
+                    t = (acc * (1 << sh) + x) % model.M
+                    out, acc = (t // d, t % d) if d else (0, 0)
+                else:
+                    assert ra[0] == zero_off and ra[1] == zero_off
+                    t = (x + acc) % model.M
+                    out, acc = t & ((1 << sh) - 1), t >> sh
+                results.append((ro[2] & ~CTRL_MASK, out))
+                results.append((ra[2] & ~CTRL_MASK, acc))
+            assert iters == longest, "the iteration count is the longest chain segment"
+            for pos in range(cnt, G):
+                a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
+                assert not (dctl & CTRL_ACTIVE) and (dctl & ~CTRL_MASK) == trash and a_off == zero_off and b_off == zero_off
+        for pos in range(0 if name == "SCAN" else G):
             j = pos // rep
             a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
             if name == "MULF" and pos % rep:
@@ -250,18 +229,6 @@ def run(blob: Blob, inputs_row):
             assert bool(ctrl & CTRL_ACTIVE) == (j < cnt)
             ops = []
             bitx = name == "BIT" and (ctrl & CTRL_SUB_MASK) == 5 and j < cnt  # (a >> k) & 1 with k = b_lds / 16
-
-            def fetch(off, la, q, rec_pos):
-                """operand q (0: a fields, 1: b fields) of the record at position rec_pos: its own stage cell or a ring cell"""
-                own_cell = stage + 2 * q * LDS_HALF_BYTES + rec_pos * T * 16
-                if la == own_cell:  # memory operand, staged OPND_AHEAD bundles ahead
-                    return mem_at(off, b - OPND_AHEAD - 1, stream, b - OPND_AHEAD)
-                assert off == zero_off, "ring operand must stage the zero constant"
-                rs, rem = divmod(la - LDS_RING_OFF, RING_SLOT_BYTES)
-                assert 0 <= rs < RING_BUNDLES and rem < LDS_HALF_BYTES and rem % (16 * T) == 0
-                wb, val = ring[(rs, rem // (16 * T))]
-                assert 1 <= b - wb <= RING_BUNDLES, "ring cell too old"
-                return val
             for q, (off, la) in enumerate(((a_off, lds & 0xFFFF), (b_off, lds >> 16))):
                 if bitx and q == 1:
                     assert off == zero_off and la % 16 == 0 and la // 16 < 254
@@ -347,7 +314,7 @@ def run(blob: Blob, inputs_row):
             mailbox = None
         else:
             assert name != "DIV" or not blob.divider
-        if name in ("MULF", "MACRO"):
+        if name in ("MULF", "SCAN"):
             pass
         elif name == "BIT":
             all_x = all((blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK) == 5 for jj in range(cnt))
@@ -359,7 +326,7 @@ def run(blob: Blob, inputs_row):
             assert ((h >> 13) & 1) == 0
         if name == "MULF":
             assert (h & (HDR_F_S2MUL | HDR_F_S2LIN | HDR_F_S3LIN)) == fused_bits, "stage bits of a fused bundle must describe its records"
-        elif name != "MACRO":
+        elif name != "SCAN":
             assert ((h >> 11) & 3) == (lin_seen >> 11), "LIN header bits must describe the records"
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
@@ -369,16 +336,10 @@ def run(blob: Blob, inputs_row):
                 hist = history.setdefault(d // slot_bytes - NC, [])
                 assert not hist or hist[0][0] == stream, "a slot is written by one stream only"
                 hist.append((stream, b, v))
-        if macro_cells is not None:
-            for j in range(G):  # (cells of idle groups hold garbage)
-                ring.pop((b % RING_BUNDLES, j), None)
-            for j, v in macro_cells.items():
-                ring[(b % RING_BUNDLES, j)] = (b, v)
-        else:
-            for j, (_, v) in enumerate(results):
-                ring[(b % RING_BUNDLES, j)] = (b, v)
-            for j in range(cnt if name != "DIVREQ" else 0, G):
-                ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
+        for j, (_, v) in enumerate(results):
+            ring[(b % RING_BUNDLES, j)] = (b, v)
+        for j in range(cnt if name != "DIVREQ" else 0, G):
+            ring.pop((b % RING_BUNDLES, j), None)  # inactive lanes overwrite the cell with garbage
 
         if b == blob.stream_first[stream] + blob.stream_count[stream] - 1:
             assert mailbox is None and n_requests == blob.stream_div_requests[stream]

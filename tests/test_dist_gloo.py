@@ -142,3 +142,40 @@ def test_config4_flow_world2_digest_matches_single_process():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == res[0][2]                      # both ranks see the same digest = the single-process digest
     assert (res[0][4], res[0][5], res[1][4], res[1][5]) == (0, 7, 7, 14) and res[0][3] == res[1][3]
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_two_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher around it must start its two ranks itself (a child
+    torch.distributed.run) and print ONE line that says n_gpus == 2: the 8-GPU scaling run cannot silently record one
+    GPU.  --dry-run: gloo + the program emulator, no GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["group_ranks"] == 2 and j["dry_run"] is True
+    assert j["matches_single_gpu_digest"] is True and j["sets_with_error_status"] == 0
+    assert "x2" in j["config"]["parallelism"]
+
+
+def test_bench_rejects_world_size_mismatch():
+    """a launcher with fewer ranks than --gpus says (or none, with RANK set) is an error, not a silent one-GPU run"""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in r.stderr
+
+
+def test_bench_watchdog_exits_nonzero():
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(0.3, 'test block'):\n"
+            "    time.sleep(30)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "watchdog: test block did not finish" in r.stderr

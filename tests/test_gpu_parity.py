@@ -187,20 +187,6 @@ def test_compiler_rewrites_on_chain_heavy_graphs(pkg):
         _check(pkg, b.to_bin(), rows, tiles=(1, 2, 16, 64, 2 | DIVIDER, 8 | DIVIDER, 1 | GROUP, 8 | GROUP))
 
 
-def test_macro_bundles_opt_in_on_the_gpu(pkg, monkeypatch):
-    """CWC_MACRO=1: runs of narrow bundles as the stages of macro bundles (class C_MACRO, its own interpreter instances) --
-    measured slower than the separate bundles and therefore opt-in, but exact: Poseidon, chain-heavy and random graphs at
-    tile widths 1 and 2, with divider waves and as stream programs, against the oracle."""
-    monkeypatch.setenv("CWC_MACRO", "1")
-    rnd = random.Random(78)
-    n_macro = 0
-    for b, n_in in [(C.build_poseidon(2), 3), (C.build_chain_heavy(5), 6), (C.build_chain_heavy(9, n_chains=16), 6)] + \
-                   [(C.build_random_dag(s, n_ops=300, panic_free=True, parts=1 + s % 3), 7) for s in range(6)]:
-        g = _check(pkg, b.to_bin(), [_rand_row(rnd, n_in) for _ in range(37)], tiles=(1, 2, 1 | DIVIDER, 2 | DIVIDER, 2 | 0x1000))
-        n_macro += g.program_stats()["class_bundles"].get("MACRO", 0)
-    assert n_macro > 50
-
-
 def test_short_soak_random_graphs_batches_programs(pkg):
     """120 random graphs (every op, panic edges, chain-heavy) x random batch sizes x random program keys."""
     from tools import gpu_soak
@@ -538,6 +524,60 @@ def test_config5_class_bigint_graph_one_million_nodes(pkg):
     assert np.array_equal(st != 0, wst != 0) and np.array_equal(got[wst == 0], want[wst == 0])
 
 
+def test_scan_bundles_on_the_gpu(pkg):
+    """Round 4, class C_SCAN: carry chains and remainder chains of limb arithmetic as loops inside one bundle (pairs of node
+    slots, the accumulator moving up the wave by DPP).  Every shift / base width (word-aligned and not, up to 253), chains
+    longer than a bundle, forks, operands outside the limb range (the general 256-bit rounds), limb-sized ones (the straight
+    rounds), d == 0; 70 input sets through tile widths 1 and 2 with and without divider waves, against the oracle."""
+    from test_host_formats import SCAN_CASES, scan_rows
+    rnd = random.Random(21)
+    steps = 0
+    for case in SCAN_CASES + [(64, 64, 64, 1, True, False), (121, 121, 20, 2, False, False), (31, 1, 12, 2, True, True)]:
+        data = C.build_limb_chains(*case).to_bin()
+        g = pkg.Graph(data)
+        rows = scan_rows(rnd, g.n_inputs, 70)
+        g = _check(pkg, data, rows, tiles=(1, 2, 1 | DIVIDER, 2 | DIVIDER, 4))
+        g.set_tile_width(1)
+        steps += g.program_stats(1)["class_bundles"].get("SCAN", 0)
+    assert steps > 20
+    # the bigint-class graph with inputs of every size (its own masks make limbs of them)
+    data = C.build_bigint_class(k=8, rounds=12).to_bin()
+    g = pkg.Graph(data)
+    _check(pkg, data, scan_rows(rnd, g.n_inputs, 40), tiles=(1, 2, 4))
+
+
+@pytest.mark.timeout(900)
+def test_config5_named_size_ten_million_nodes_all_sets(pkg):
+    """BASELINE config 5 at its NAMED size: the 10.5 M-node bigint / long_div-class graph (32 limbs x 4000 rounds), the
+    library's own program for 32 sets (the per-GPU share of 256 over 8 GPUs), EVERY set against the oracle as a whole
+    witness.  Graphs above two million nodes take compile branches of their own (one schedule, no all-Montgomery
+    competitor): this is what covers them on hardware.  Inputs mix uniform field elements (what bench.py feeds) with
+    limb-sized and edge values."""
+    b = C.build_bigint_class(k=32, rounds=4000)
+    data = b.to_bin()
+    g = pkg.Graph(data)
+    assert g.n_nodes >= 10000000
+    rnd = random.Random(5)
+    rows = []
+    for s in range(32):
+        if s % 3 == 0:
+            rows.append([1] + [rnd.randrange(M) for _ in range(g.n_inputs - 1)])
+        elif s % 3 == 1:
+            rows.append([1] + [rnd.randrange(1 << 64) for _ in range(g.n_inputs - 1)])
+        else:
+            rows.append([1] + [rnd.choice(EDGE + [(1 << 64) - 1, (1 << 64) - 2, 0]) for _ in range(g.n_inputs - 1)])
+    inp = cbind.ints_to_array(rows)
+    og = cbind.Graph(data)
+    _, want, wst = cbind.time_batch_threads(og, inp, min(32, os.cpu_count() or 1))
+    key = g.pick_tile_width(32)
+    g.set_tile_width(key)
+    got, st = g.calc_witness_batch(inp)
+    assert np.array_equal(st != 0, wst != 0)
+    assert np.array_equal(got[wst == 0], want[wst == 0])
+    tm = g.last_timing()
+    assert tm["n_bundles"] > 100000 and g.depth > 1000000
+
+
 # BabyJubjub in twisted Edwards form a x^2 + y^2 = 1 + d x^2 y^2 (a = 168700, d = 168696), independent of the generator's
 # Montgomery-form gadgets: the unified addition law and double-and-add on Python integers.
 _BJ_A, _BJ_D = 168700, 168696
@@ -685,9 +725,10 @@ def test_load_time_optimiser_on_and_off_on_the_gpu(pkg, monkeypatch):
 def test_streaming_json_to_wtns_pipeline(pkg, tmp_path, monkeypatch):
     """The streaming end-to-end entry point (gwb_calc_witness_json_to_wtns): sub-batches parsed on host threads and evaluated
     while the previous one's witness rows leave HBM in slices and writer threads frame them as `.wtns` files.  Ragged sizes
-    (a last sub-batch of 3 sets, a last slice of one set), a JSON array instead of NDJSON, a set that panics in the
-    reference (status word, file still written), an unparsable set (the call fails and names it); every file byte-equal
-    to the oracle's `.wtns`."""
+    (a last sub-batch of 3 sets, a last slice of one set), a JSON array instead of NDJSON, sets that panic in the
+    reference (status word, NO file -- a stale file of that name is removed; without a status buffer the call fails and
+    names the first such set), an unparsable set (the call fails and names it); every file byte-equal to the oracle's
+    `.wtns`."""
     bld = C.build_gadgets()
     nodes, wit, inputs = bld.finalize()
     data = bld.to_bin()
@@ -704,9 +745,16 @@ def test_streaming_json_to_wtns_pipeline(pkg, tmp_path, monkeypatch):
         monkeypatch.setenv("CWC_E2E_SUBBATCH", sub)
         d = tmp_path / ("out" + sub)
         d.mkdir()
+        assert wst.any() and not wst.all()
+        first_bad = int(np.nonzero(wst)[0][0])
+        (d / ("w_%05d.wtns" % (40 + first_bad))).write_bytes(b"stale file of an earlier run")
         st, stats = g.json_to_wtns(text, str(d / "w_%05lu.wtns"), first_index=40)
         assert len(st) == B and stats["n_sets"] == B and np.array_equal(st != 0, wst != 0)
-        assert sorted(os.listdir(d)) == ["w_%05d.wtns" % (40 + i) for i in range(B)]
+        assert stats["failed_sets"] == int((wst != 0).sum())
+        assert sorted(os.listdir(d)) == ["w_%05d.wtns" % (40 + i) for i in range(B) if not wst[i]]
+        with pytest.raises(pkg.WitnessCalcError, match="input set %d: .* of %d input sets failed" % (first_bad, B)):
+            g.json_to_wtns(text, str(d / "n_%05lu.wtns"), first_index=0, with_status=False)
+        assert sorted(f for f in os.listdir(d) if f.startswith("n_")) == ["n_%05d.wtns" % i for i in range(B) if not wst[i]]
         for i in range(B):
             if not wst[i]:
                 assert (d / ("w_%05d.wtns" % (40 + i))).read_bytes() == model.wtns_from_witness(cbind.array_to_ints(want[i])), (sub, i)
@@ -868,6 +916,14 @@ def test_single_shot_quick_first_call_background_search_and_disk_cache(pkg, tmp_
     err4 = run(12, 0.5)
     assert "program cache: ignored" in err4 and "program cache: wrote" in err4, err4[-800:]
     assert "program cache: hit" in run(1, 0.0)
+    # an intact entry of ANOTHER graph (or build) under this graph's file name: the file says what it is for and is refused
+    good = files[0].read_bytes()
+    assert good[:8] == b"CWCPROG2" and good[8:8 + 64].decode() == hashlib.sha256(data).hexdigest()
+    forged = bytearray(good)
+    forged[8] = ord("0") if forged[8] != ord("0") else ord("1")   # (header names a different graph image)
+    files[0].write_bytes(bytes(forged))
+    err5 = run(12, 0.5)
+    assert "program cache: ignored" in err5 and "not this graph's" in err5 and "program cache: wrote" in err5, err5[-800:]
 
 
 STREAMS2, STREAMS4 = 0x800, 0x1000  # GWB_TILE_STREAMS2 / GWB_TILE_STREAMS4

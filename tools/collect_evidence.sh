@@ -38,10 +38,6 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
     > $O/bench_dist1_$R.json 2> $O/bench_dist1_$R.err
 python tools/gpu_host_path.py > $O/hostpath_$R.log 2>&1
 python tools/gpu_calibrate.py > $O/calibration_$R.log 2>&1
-CWC_MACRO=1 SOAK_SEEDS=1500 SOAK_BASE=20261005 python tools/gpu_soak.py > $O/soak_macro_$R.log 2>&1
-bash tools/gpu_policies.sh "X=0 --" "CWC_MACRO=1 --" "X=0 -- --batch-per-gpu 256" "CWC_MACRO=1 -- --batch-per-gpu 256" "X=0 -- --batch-per-gpu 512" "CWC_MACRO=1 -- --batch-per-gpu 512" > $O/macro_ab_$R.log 2>&1
-CWC_MACRO=1 PROBE_T=258 python tools/gpu_classprof.py > $O/classprof_macro_$R.log 2>&1
-CWC_MACRO=1 PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_macro_$R.log 2>&1
 rm -rf /tmp/cwc_cache_$R; CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 python tools/gpu_single_shot.py > $O/single_shot_$R.log 2>&1
 echo "---- second process, program cache warm" >> $O/single_shot_$R.log
 CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 SHOTS=6 python tools/gpu_single_shot.py >> $O/single_shot_$R.log 2>&1

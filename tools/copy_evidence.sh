@@ -25,9 +25,6 @@ cp $O/soak_fused_$R.log $P/${R}_soak_fused.txt
 cp $O/policies_$R.log $P/${R}_policies.txt
 cp $O/calibration_$R.log $P/${R}_calibration.txt
 cp $O/cache_counters_$R.log $P/${R}_cache_counters.txt
-cp $O/soak_macro_$R.log $P/${R}_soak_macro.txt
 [ -f $O/soak_100k_$R.log ] && (head -3 $O/soak_100k_$R.log; echo ...; tail -4 $O/soak_100k_$R.log) > $P/${R}_soak_100k.txt  # (SOAK_SEEDS=100000 python tools/gpu_soak.py, run on its own)
-cp $O/macro_ab_$R.log $P/${R}_macro_ab.txt
-cp $O/classprof_macro_$R.log $P/${R}_classprof_macro.txt
 tail -3 $O/gputest_$R.log > $P/${R}_gputest_tail.txt
 ls -la $P | grep ${R}_

@@ -9,20 +9,25 @@ file); without it nothing changes.
 
     python tools/gpu_calibrate.py [--write [PATH]]
 
-Classes priced with operand-form / stage adjustments (BIT, IDIVMOD, CMPS, MULF, MACRO) are reported but not written: their
+Classes priced with operand-form / stage adjustments (BIT, IDIVMOD, CMPS, MULF, SCAN) are reported but not written: their
 table entries are the all-conversions / all-stages price, not what a mixed program measures."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
+import subprocess
+# the stamped interpreter instances live in the diagnostic library (make diag): built on demand, loaded in place of the product's
+_PKG = os.path.join(ROOT, "circom-witnesscalc_amd")
+subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "diag"])
+os.environ["CWC_LIB_PATH"] = os.path.join(_PKG, "libcircom_witnesscalc_amd_diag.so")
 import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
 
-STAMPS = {"MULF": 2, "MACRO": 2}   # time stamps of ~40 cycles inside a bundle's measured span (every other class path: 5)
+STAMPS = {"MULF": 2}   # time stamps of ~40 cycles inside a bundle's measured span (every other class path: 5)
 STAMP_CYCLES = 40
-ADJUSTED = ("BIT", "IDIVMOD", "CMPS", "MULF", "MACRO")
+ADJUSTED = ("BIT", "IDIVMOD", "CMPS", "MULF", "SCAN")
 M = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
 

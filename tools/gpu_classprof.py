@@ -3,6 +3,11 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
+import subprocess
+# the stamped interpreter instances live in the diagnostic library (make diag): built on demand, loaded in place of the product's
+_PKG = os.path.join(ROOT, "circom-witnesscalc_amd")
+subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "diag"])
+os.environ["CWC_LIB_PATH"] = os.path.join(_PKG, "libcircom_witnesscalc_amd_diag.so")
 import cwc_import
 pkg = cwc_import.load()
 from tools.graphgen import circuits as C
@@ -28,7 +33,6 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     tiles = (B + (tw & 0xff) - 1) // (tw & 0xff)
     nw = max(1, tiles // 64 + (1 if tiles % 64 else 0))
     sections = prof.pop("_sections")
-    msec = prof.pop("_macro_sections")
     wv = prof.pop("_waves")
     tot = sum(v[0] for v in prof.values())
     print("T=%d%s B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw & 0xff, " + divider wave" if tw & 0x100 else "", B, t["interp_ms"], nw, tot / nw))
@@ -40,7 +44,3 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
         if v[5]:
             print("   %s sections (cycles/bundle, each includes one ~40-cycle stamp): top+vmcnt wait %.0f | LDS reads + previous stores %.0f | staging issue %.0f | arithmetic %.0f | ring write %.0f" % (
                 (k,) + tuple(x / v[5] for x in v[:5])))
-    if prof.get("MACRO", (0, 0, 0, 0))[3]:
-        n = prof["MACRO"][3]
-        print("   MACRO sections (cycles/bundle, each stamp ~40 cycles): up to the records %.0f | up to the operands %.0f | staging issue %.0f | behind the last stage %.0f | stages/bundle %.2f, cycles/stage %.0f (two stamps)"
-              " | stages that re-read: %.2f/bundle, %.0f cycles each (inside the stage's cycles)" % (msec[0] / n, msec[1] / n, msec[2] / n, msec[7] / n, msec[4] / n, msec[3] / max(1, msec[4]), msec[6] / n, msec[5] / max(1, msec[6])))

@@ -8,4 +8,4 @@ B=CWC_LIB_PATH=/root/repo/circom-witnesscalc_amd/libcwc_base.so
 bash tools/gpu_policies.sh "X=0 --" "$B --" "X=0 -- --batch-per-gpu 256" "$B -- --batch-per-gpu 256" "X=0 -- --batch-per-gpu 512" "$B -- --batch-per-gpu 512" "X=0 -- --config 3" "$B -- --config 3" "X=0 -- --config 4" "$B -- --config 4" "X=0 --" "$B --" > $O/lib_ab.log 2>&1; cat $O/lib_ab.log
 python bench.py --config 5 --cpu-sample 0 2>/dev/null | python tools/show_bench.py /dev/stdin | head -1
 CWC_LIB_PATH=/root/repo/circom-witnesscalc_amd/libcwc_base.so python bench.py --config 5 --cpu-sample 0 2>/dev/null | python tools/show_bench.py /dev/stdin | head -1
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "fuzz or streams or authv2 or macro or soak or gadgets or edge" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "fuzz or streams or authv2 or scan or soak or gadgets or edge" 2>&1 | tail -2
