@@ -433,8 +433,14 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
 // Graphs without integer chains come out all-Montgomery, as before.
 static const uint8_t REP_M = 0, REP_C = 1;
 static const uint8_t VF_A_CANON = 1, VF_B_CANON = 2, VF_OUT_CANON = 4;
+static const uint8_t VF_MUL_CC = 8;  // a multiplication of two canonical integers that stays canonical (C_MUL bundles with HDR_MUL_CC)
 static bool is_integer_class(int c) { return c == C_BIT || c == C_IDIVMOD || c == C_CMPS; }
-static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery) {
+// allow_cc (limb-arithmetic graphs, tile widths with the MODE 2 interpreter instances): the product of two canonical values
+// stays a node of its own kind -- both factors canonical, result canonical (VF_MUL_CC) -- instead of converting one factor:
+// limb products are far below r, and the kernel multiplies limb-sized integers directly (general operands: two Montgomery
+// products).
+static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery,
+                                  bool allow_cc, uint64_t& n_cc) {
     const size_t N = g.nodes.size();
     const bool off = all_montgomery || getenv("CWC_NO_REP_INFERENCE") != nullptr;
     // what the users of a value would rather read: > 0 canonical
@@ -525,7 +531,10 @@ static void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vect
                     n.a = at[n.a];
                     n.b = at[n.b];
                 } else {
-                    if (ra == REP_C && rb == REP_C) {  // one factor into Montgomery form: the one that is already converted, else the second
+                    if (ra == REP_C && rb == REP_C && allow_cc && !is_const(n.a) && !is_const(n.b)) {
+                        f |= VF_MUL_CC;
+                        ++n_cc;
+                    } else if (ra == REP_C && rb == REP_C) {  // one factor into Montgomery form: the one that is already converted, else the second
                         if (!is_const(n.a) && converted[n.a] != 0xffffffffu) ra = REP_M;
                         else rb = REP_M;
                     }
@@ -876,6 +885,7 @@ static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<
 static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400, 48900};
 // a scan bundle (C_SCAN) is priced as its front end plus the rounds of its loop (the table entry is 32 rounds of the
 // division step; a bundle books what it costs less): the limb-sized paths, measured on MI355X (profiles/r04_class_profile.txt)
+static const double kCyclesMulCC = 760;  // a bundle of canonical limb products (HDR_MUL_CC)
 static const double kCyclesScanFront = 900, kCyclesScanStepCarry = 260, kCyclesScanStepDiv = 1500;
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves
@@ -1195,6 +1205,33 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         depth = std::max(depth, l + 1);
     }
     st.depth = depth;
+    // The same with the steps of limb recurrences -- an Idiv / Mod / Shr / Band of a sum, that sum, a product under it -- at a
+    // tenth of a level: what the dependency depth comes to once such chains run as scan bundles (tile widths up to
+    // SCAN_MAX_T; an estimate, used by the runtime to bound a program's size before anything is compiled).
+    {
+        std::vector<uint8_t> step(N, 0);
+        for (size_t i = N; i-- > 0;) {
+            const Node& n = g.nodes[i];
+            if (n.kind != N_DUO) continue;
+            if ((n.op == OP_IDIV || n.op == OP_MOD || n.op == OP_SHR || n.op == OP_BAND) && g.nodes[n.a].kind == N_DUO && g.nodes[n.a].op == OP_ADD) step[i] = step[n.a] = 1;
+            if (n.op == OP_ADD && step[i])
+                for (uint32_t o : {n.a, n.b})
+                    if (g.nodes[o].kind == N_DUO && g.nodes[o].op == OP_MUL) step[o] = 1;
+        }
+        std::vector<float> lf(N, 0.0f);
+        float deepest = 0.0f;
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            const int ar = arity_of(n);
+            if (!ar) continue;
+            float l = lf[n.a];
+            if (ar >= 2) l = std::max(l, lf[n.b]);
+            if (ar >= 3) l = std::max(l, lf[n.c]);
+            lf[i] = l + (step[i] ? 0.1f : 1.0f);
+            deepest = std::max(deepest, lf[i]);
+        }
+        st.depth_scan = (uint64_t)deepest + 1;
+    }
 
     phase("levels");
     if (probe_only) {
@@ -1255,7 +1292,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     phase("rewrites");
     // ---- one form per value: Montgomery or canonical (inserts the conversions; see infer_representations) ----
     std::vector<uint8_t> node_rep, node_vflags;
-    infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery);
+    // (limb-arithmetic graphs -- the probe's scan-aware depth is well below the plain one -- at tile widths with the MODE 2 instances)
+    const bool limb_graph = T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_SCAN") && st.depth_scan * 10 < st.depth * 8;
+    uint64_t n_mul_cc = 0;
+    infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery, limb_graph && !getenv("CWC_NO_MUL_CC"), n_mul_cc);
     N = g.nodes.size();
     phase("representation inference");
     // ---- scan chains: the steps of serial limb recurrences as pairs of N_SCAN nodes (class C_SCAN) ----
@@ -1265,7 +1305,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         N = g.nodes.size();
         phase("scan chains");
     }
-    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1 && st.n_scan_steps == 0) {  // (a program has fused bundles or scan bundles: one interpreter instance each)
+    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1 && st.n_scan_steps == 0 && n_mul_cc == 0) {  // (a program has fused bundles or scan bundles: one interpreter instance each)
         fuse_narrow_chains(g, node_rep, node_vflags, class_cost, (policy.fuse & 0xffffu) - 1, (policy.fuse & 0x10000u) != 0, st.n_fused_nodes);
         N = g.nodes.size();
         phase("fused narrow chains");
@@ -1497,7 +1537,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     std::push_heap(hs.begin(), hs.end());
                     return;
                 }
-                if (hc == C_BIT) hc += (int)C_COUNT * (1 + node_vflags[i] + 8 * (g.nodes[i].op == OP_SHR || g.nodes[i].op == OP_BAND ? 1 : 0));  // (bundles of Shr / Band nodes take a straight path)
+                if (hc == C_MUL && (node_vflags[i] & VF_MUL_CC)) hc += (int)C_COUNT;  // (canonical products: bundles of their own, never narrow)
+                else if (hc == C_BIT) hc += (int)C_COUNT * (1 + node_vflags[i] + 8 * (g.nodes[i].op == OP_SHR || g.nodes[i].op == OP_BAND ? 1 : 0));  // (bundles of Shr / Band nodes take a straight path)
                 else if (is_integer_class(hc)) hc += (int)C_COUNT * (1 + node_vflags[i]);
                 else if (hc == C_CMPZ) hc += (int)C_COUNT * (1 + (node_vflags[i] & VF_OUT_CANON));
                 else if (hc == C_MULF) {  // fused nodes: one heap per combination of stages (a bundle runs every stage one of its nodes has)
@@ -2148,6 +2189,15 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 const uint32_t sub = ctrl_of[(size_t)b * G + (k - k0) * rep] & CTRL_SUB_MASK;
                 lin_bits |= sub == SUB_SUB ? HDR_LIN_SUB : sub == SUB_ADD ? HDR_LIN_ADD : 0u;
             }
+        if (cl == C_MUL && !idle && (node_vflags[order[k0] & ~REQ_FLAG] & VF_MUL_CC)) {  // canonical products (a heap of their own: all or none)
+            for (uint32_t k = k0; k < k1; ++k)
+                if (!(node_vflags[order[k] & ~REQ_FLAG] & VF_MUL_CC) || class_of(g.nodes[order[k] & ~REQ_FLAG]) != C_MUL) {
+                    err = "internal error: canonical and Montgomery products in one bundle";
+                    return false;
+                }
+            lin_bits |= HDR_MUL_CC;
+            form_saved = kCycles[C_MUL] - kCyclesMulCC;
+        }
         if (cl == C_BIT) {
             bool all = true;
             for (uint32_t k = k0; k < k1; ++k) all = all && (ctrl_of[(size_t)b * G + (k - k0)] & CTRL_SUB_MASK) == SUB_BITX;
@@ -2352,9 +2402,10 @@ bool validate_program(const Program& p, std::string& err) {
     bool any_fused = false, any_scan = false;  // (one interpreter instance each: a program has one kind or the other)
     for (uint32_t h : p.hdr) {
         any_fused = any_fused || (h & HDR_CLASS_MASK) == C_MULF;
-        any_scan = any_scan || (h & HDR_CLASS_MASK) == C_SCAN;
+        any_scan = any_scan || (h & HDR_CLASS_MASK) == C_SCAN || ((h & HDR_CLASS_MASK) == C_MUL && (h & HDR_MUL_CC));
+        if ((h & HDR_CLASS_MASK) == C_MUL && (h & HDR_MUL_CC) && (T > SCAN_MAX_T || (h & (HDR_LIN_ADD | HDR_LIN_SUB)))) return bad("canonical-product bundle");
     }
-    if (any_fused && any_scan) return bad("fused and scan bundles in one program");
+    if (any_fused && any_scan) return bad("fused and scan / canonical-product bundles in one program");
     if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
     if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)

@@ -863,4 +863,62 @@ FRD void u128_divrem_64(Fr& q, Fr& rem, const Fr& a, const Fr& b) {
     rem.v[1] = (uint32_t)(r64 >> 32);
 }
 
+// ---- division by an invariant limb (the long-division chains of scan bundles: one divisor for the rounds of a loop) ----------
+// Moeller & Granlund, "Improved division by invariant integers" (IEEE TC 2011), algorithms 3 and 4: for a NORMALISED divisor dn
+// (top bit set) the 64-bit reciprocal v = floor((2^128 - 1) / dn) - 2^64 turns (u1:u0) / dn with u1 < dn into two
+// multiplications and two corrections.
+FRD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+FRD uint32_t clz64_nonzero(uint64_t x) {  // x != 0
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    return hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo | 1u);
+}
+FRD uint64_t recip64(uint64_t dn) {  // floor((2^128 - 1) / dn) - 2^64 = floor(((2^64 - 1 - dn) : (2^64 - 1)) / dn); once per divisor
+    Fr a = fr_zero(), b = fr_zero(), q, r;
+    const uint64_t nd = ~dn;
+    a.v[0] = a.v[1] = 0xffffffffu;
+    a.v[2] = (uint32_t)nd;
+    a.v[3] = (uint32_t)(nd >> 32);
+    b.v[0] = (uint32_t)dn;
+    b.v[1] = (uint32_t)(dn >> 32);
+    u128_divrem_64(q, r, a, b);
+    return ((uint64_t)q.v[1] << 32) | q.v[0];
+}
+FRD void div2by1(uint64_t u1, uint64_t u0, uint64_t dn, uint64_t v, uint64_t& q, uint64_t& r) {  // u1 < dn, dn normalised, v = recip64(dn)
+    const uint64_t lo = v * u1, hi = mulhi64(v, u1);
+    const uint64_t q0 = lo + u0;
+    uint64_t q1 = hi + u1 + (q0 < lo ? 1ull : 0ull) + 1ull;
+    uint64_t rr = u0 - q1 * dn;
+    if (rr > q0) {
+        --q1;
+        rr += dn;
+    }
+    if (rr >= dn) {
+        ++q1;
+        rr -= dn;
+    }
+    q = q1;
+    r = rr;
+}
+// (th:tl) / d for any th, tl and d != 0 given s = clz(d), dn = d << s, v = recip64(dn): quotient (qh:ql), remainder.
+// `high`: whether the high word needs a division of its own (th >= d somewhere; callers test it wave-wide).
+FRD void u128_divrem_64_recip(uint64_t th, uint64_t tl, uint64_t d, uint32_t s, uint64_t dn, uint64_t v, bool high, uint64_t& qh, uint64_t& ql, uint64_t& rem) {
+    uint64_t rh = th;  // th mod d
+    qh = 0;
+    if (high) {  // (0:th) << s: the top word (th >> (64 - s)) is below 2^s <= dn
+        uint64_t rn;
+        div2by1((th >> 1) >> (63u - s), th << s, dn, v, qh, rn);
+        rh = rn >> s;
+    }
+    (void)d;
+    uint64_t rn;
+    div2by1((rh << s) | ((tl >> 1) >> (63u - s)), tl << s, dn, v, ql, rn);
+    rem = rn >> s;
+}
+
 }  // namespace cwc

@@ -551,6 +551,24 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         }
         wait_and_stage();
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
+            if constexpr (MODE == 2) {
+                if (h & HDR_MUL_CC) {  // canonical x canonical -> canonical: limb-sized factors (below 2^64 everywhere in the wave) multiply as integers
+                    if (!wave_any((a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
+                        const uint64_t p00 = (uint64_t)a_op.v[0] * b_op.v[0], p01 = (uint64_t)a_op.v[0] * b_op.v[1], p10 = (uint64_t)a_op.v[1] * b_op.v[0], p11 = (uint64_t)a_op.v[1] * b_op.v[1];
+                        const uint64_t m1 = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
+                        const uint64_t m2 = (m1 >> 32) + (p01 >> 32) + (p10 >> 32) + (uint32_t)p11;
+                        r = fr_zero();
+                        r.v[0] = (uint32_t)p00;
+                        r.v[1] = (uint32_t)m1;
+                        r.v[2] = (uint32_t)m2;
+                        r.v[3] = (uint32_t)((m2 >> 32) + (p11 >> 32));
+                    } else {  // any operands: a into Montgomery form, then Montgomery x canonical = the canonical product
+                        r = fr_mul_wave(fr_mul_wave(a_op, fr_r2(), pv), b_op, pv);
+                    }
+                    finish(r);
+                    continue;
+                }
+            }
             r = fr_mul_wave(a_op, b_op, pv);
             // linear nodes riding in this bundle's free node slots (graph.rs:110-111)
             if ((h & (HDR_LIN_ADD | HDR_LIN_SUB)) == (HDR_LIN_ADD | HDR_LIN_SUB)) {
@@ -784,21 +802,29 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                                                       d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) != 0u) && sh >= 1u && sh <= 64u;
                         Fr quo = fr_zero(), rem = fr_zero();
                         if (small) {
-                            // every remainder stays below 2^64 (below d, or 0), so t = rem * 2^k + x < 2^128
+                            // every remainder stays below 2^64 (below d, or 0), so t = rem * 2^k + x < 2^128.  The divisor is the
+                            // lane's own for all rounds: its normalisation shift and reciprocal are computed once
+                            // (fr_gfx950.hpp u128_divrem_64_recip), a round is two multiplications and two corrections.
+                            const uint64_t dv = ((uint64_t)ds.v[1] << 32) | ds.v[0];
+                            const uint32_t s = clz64_nonzero(dv);
+                            const uint64_t dn = dv << s, rv = recip64(dn);
+                            const uint64_t xl = ((uint64_t)x.v[1] << 32) | x.v[0];
+                            const uint64_t a0 = ((uint64_t)acc0.v[1] << 32) | acc0.v[0];
+                            uint64_t r64 = 0, qh = 0, ql = 0;
                             for (uint32_t it = 0; it < iters; ++it) {
-                                const uint32_t s0 = wave_shr_lanes<D>(rem.v[0]), s1 = wave_shr_lanes<D>(rem.v[1]);
-                                const unsigned long long in = ((unsigned long long)(start ? acc0.v[1] : s1) << 32) | (start ? acc0.v[0] : s0);
-                                // in * 2^k (k <= 64) + x as four words
-                                const unsigned long long lo = sh == 64u ? 0ull : in << sh, hi = sh == 64u ? in : (in >> 1) >> (63u - sh);
-                                const unsigned long long xl = ((unsigned long long)x.v[1] << 32) | x.v[0];
-                                const unsigned long long tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
-                                Fr t = fr_zero();
-                                t.v[0] = (uint32_t)tl; t.v[1] = (uint32_t)(tl >> 32); t.v[2] = (uint32_t)th; t.v[3] = (uint32_t)(th >> 32);
-                                Fr q1, r1;
-                                u128_divrem_64(q1, r1, t, ds);
-                                quo = u256_select(dz, fr_zero(), q1);
-                                rem = u256_select(dz, fr_zero(), r1);
+                                const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
+                                const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
+                                // in * 2^k (1 <= k <= 64) + x
+                                const uint64_t lo = sh == 64u ? 0ull : in << sh, hi = sh == 64u ? in : (in >> 1) >> (63u - sh);
+                                const uint64_t tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
+                                uint64_t q_h, q_l, rr;
+                                u128_divrem_64_recip(th, tl, dv, s, dn, rv, wave_any(th >= dv), q_h, q_l, rr);
+                                qh = dz ? 0ull : q_h;
+                                ql = dz ? 0ull : q_l;
+                                r64 = dz ? 0ull : rr;
                             }
+                            quo.v[0] = (uint32_t)ql; quo.v[1] = (uint32_t)(ql >> 32); quo.v[2] = (uint32_t)qh; quo.v[3] = (uint32_t)(qh >> 32);
+                            rem.v[0] = (uint32_t)r64; rem.v[1] = (uint32_t)(r64 >> 32);
                         } else {
                             for (uint32_t it = 0; it < iters; ++it) {
                                 Fr in;

@@ -99,6 +99,9 @@ CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_L
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
 static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
+// C_MUL (the same bit as HDR_BITX_ALL): every node multiplies two canonical integers and keeps the canonical product
+// (a * b mod r, graph.rs:105, without a trip through Montgomery form when the factors are limb-sized); MODE 2 instances only
+static const uint32_t HDR_MUL_CC = 1u << 13;
 // C_BIT (the same two bits): every node of the bundle is a Shr or a Band (SHR: some shift; BAND alone: none does) -- limb arithmetic (Idiv / Mod by 2^n after the
 // compiler's strength reduction, masks) takes a straight path instead of the per-lane select over all five operations
 static const uint32_t HDR_BIT_ALL_SHR = 1u << 11, HDR_BIT_ALL_BAND = 1u << 12;

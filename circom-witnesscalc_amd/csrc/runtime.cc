@@ -119,7 +119,7 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
     dp.dev.has_fused = 0;  // (from the bundle headers themselves: an imported program's statistics are not what the kernel runs)
-    for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : (h & HDR_CLASS_MASK) == C_SCAN ? 2u : 0u;
+    for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : ((h & HDR_CLASS_MASK) == C_SCAN || ((h & HDR_CLASS_MASK) == C_MUL && (h & HDR_MUL_CC))) ? 2u : 0u;
     dp.dev.n_streams = p.n_streams;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dp.dev.stream_first[s] = p.stream_first[s];
@@ -466,7 +466,9 @@ uint32_t pick_tile_width(gwb_graph* g, size_t batch, bool allow_quick = true) {
         double budget = 960.0;
         if (const char* e = getenv("CWC_PROGRAM_MB")) budget = atof(e);
         const double per_bundle_t1 = 4.0 + 64.0 * 16.0;
-        while (min_t < 16 && (double)g->stats.depth * 1.25 * (4.0 + (per_bundle_t1 - 4.0) / min_t) > budget * 1048576.0) min_t *= 2;
+        // (tile widths with scan bundles: limb recurrences take a tenth of their depth in bundles)
+        auto levels = [&](uint32_t t) { return (double)(t <= SCAN_MAX_T && !getenv("CWC_NO_SCAN") && g->stats.depth_scan ? g->stats.depth_scan : g->stats.depth); };
+        while (min_t < 16 && levels(min_t) * 1.25 * (4.0 + (per_bundle_t1 - 4.0) / min_t) > budget * 1048576.0) min_t *= 2;
         if ((rule & ~KEY_MODE_MASK) < min_t) rule = min_t | ((rule & KEY_MODE_MASK) && min_t < 64 ? (rule & KEY_MODE_MASK) : 0u);
     }
     if (getenv("CWC_STATIC_TILE_RULE") || !g->has_graph) return rule;

@@ -21,7 +21,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d49Q"
+HDR_FMT = "<12I12I6I12d50Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "SCAN"]
@@ -32,6 +32,7 @@ COOP_FUSE_MAX_T = 2
 COOP_LANES, COOP_MAX_T = 4, 4
 # scan bundles (class SCAN): pairs of record positions (2p: the step's OUT record, 2p + 1: its ACC record); header bit 11
 # kind (0 carry chain, 1 long division by one limb), bits 19-26 the shift, bits 27-31 iterations - 1; sub-op bit 0 role, bit 1 START
+HDR_MUL_CC = 1 << 13
 SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_ACC, SCAN_START = 2, 1 << 11, 19, 27, 1, 2
 
 
@@ -64,7 +65,7 @@ class Blob:
         st = h[42:]
         c0, c1, c2 = 6, 6 + N_CLASSES, 6 + 2 * N_CLASSES
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12])
+                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12], depth_scan=st[c2 + 13])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -285,6 +286,8 @@ def run(blob: Blob, inputs_row):
                     if op != "Mul":
                         lin_seen |= (1 << 11) if op == "Sub" else (1 << 12)
                         v = model.eval_duo(op, ops[0], ops[1])  # (a +- b mod r: the same words in either form)
+                    elif name == "MUL" and h & HDR_MUL_CC:
+                        v = ops[0] * ops[1] % model.M            # canonical x canonical -> canonical
                     else:
                         v = ops[0] * ops[1] * R_INV % model.M    # Montgomery product
                 elif name == "DIV":
@@ -322,6 +325,8 @@ def run(blob: Blob, inputs_row):
             subs = [blob.recs[(b * G + jj) * 4 + 2] & CTRL_SUB_MASK for jj in range(cnt)]
             limb = all(s_ in (1, 3) for s_ in subs)  # Shr and Band nodes only: bit 11 if any shifts, else bit 12
             lin_seen = 0 if not limb else (1 << 11) if 1 in subs else (1 << 12)
+        elif name == "MUL":
+            assert not (h & HDR_MUL_CC) or (lin_seen == 0 and T <= SCAN_MAX_T), "canonical products: no riders, tile widths with the MODE 2 instances"
         else:
             assert ((h >> 13) & 1) == 0
         if name == "MULF":

@@ -586,10 +586,11 @@ def test_loader_and_compiler_under_sanitizers(tmp_path):
 
 
 @pytest.mark.parametrize("perturb", [None, 1, -1])
-@pytest.mark.parametrize("which", ["div_digits_test", "div_short_test"])
+@pytest.mark.parametrize("which", ["div_digits_test", "div_short_test", "div_recip_test"])
 def test_digitwise_division_on_host(tmp_path, perturb, which):
     """u256_divrem_digits and u128_divrem_64 (Idiv / Mod bundles) == the bit-serial division, also when the
-    floating-point quotient-digit estimate is off by one in either direction."""
+    floating-point quotient-digit estimate is off by one in either direction; the division by an invariant limb of the
+    scan bundles (reciprocal + two-by-one steps, its reciprocal made with u128_divrem_64) == unsigned __int128 division."""
     import subprocess
     exe = str(tmp_path / which)
     flags = [] if perturb is None else ["-DCWC_TEST_PERTURB_QHAT=%d" % perturb]
