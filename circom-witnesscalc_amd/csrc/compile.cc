@@ -181,7 +181,7 @@ static inline uint64_t fused_cost50(uint8_t op) {
     return 12u + 15u + (fused_op2(op) == FOP_MUL ? 15u : fused_op2(op) ? 6u : 0u) + (fused_op3(op) ? 6u : 0u);
 }
 // a step of a scan bundle: its share of the bundle's front end and one round of the loop (cycles / 50; kCyclesScan* below)
-static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 30u : 5u; }
+static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 10u : 4u; }
 static inline uint64_t node_cost(const uint32_t* table, const Node& n) {
     return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : cost_of(table, class_of(n));
 }
@@ -274,11 +274,14 @@ static void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* clas
         for (uint32_t w : g.witness_signals) n_users[w] += 2;
         // (only where whole chains are flattened -- T = 1 -- : with the 8-leaf trees of wider tiles the inner nodes' own
         // trees are what keeps a long chain balanced)
-        // Used for multi-million-node graphs only, where the compile time counts: the trees come out the same but are
-        // emitted in another order, and the list scheduler then packs the bigint-class graph into 12 % more linear bundles
-        // (1 M nodes: rewrites 1.17 -> 0.27 s; CWC_TREE_INNER_SKIP=1 / 0 forces either way).
+        // Used for graphs beyond 16 M nodes only, where the compile time counts: the trees come out the same but are
+        // emitted in another order, and the list scheduler then packs the bigint-class graph into more linear bundles
+        // (round 3: 12 % more bundles, taken for the 10.5 M-node graph because it saved 4 of 10 compile seconds; round 4: with
+        // the limb chains in scan bundles those linear bundles are 34 of 62 bundles per round instead of 19 of 49, 15 % of
+        // the run time, and the rest of the compile got cheaper -- 1 M nodes: rewrites 1.17 -> 0.27 s;
+        // CWC_TREE_INNER_SKIP=1 / 0 forces either way).
         const char* force = getenv("CWC_TREE_INNER_SKIP");
-        if (kMaxLeaves >= 64 && (force ? atoi(force) != 0 : N > 2000000)) {
+        if (kMaxLeaves >= 64 && (force ? atoi(force) != 0 : N > 16000000)) {
             for (size_t i = 0; i < N; ++i) inner[i] = n_users[i] == 1 && same_op_users[i] == 1;
             kMaxLeaves = 1u << 16;
         }
@@ -882,11 +885,14 @@ static void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<
 // Integer-class bundles (BIT, IDIVMOD, CMPS) are priced with every operand and the result converted (the bigint-class
 // profile: BIT 6 585, IDIVMOD 7 054); a bundle whose operands / result stay canonical integers (representation
 // inference) saves kCyclesOperandForm per operand and kCyclesResultForm for the result.
-static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400, 48900};
+static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 4700, 6400, 6850, 1450, 1490, 3700, 1306, 900, 2400, 16920};
 // a scan bundle (C_SCAN) is priced as its front end plus the rounds of its loop (the table entry is 32 rounds of the
-// division step; a bundle books what it costs less): the limb-sized paths, measured on MI355X (profiles/r04_class_profile.txt)
+// division step, 2 200 + 32 x 460; a bundle books what it costs less): the limb-sized paths, measured on MI355X
+// (profiles/r04_class_profile.txt)
 static const double kCyclesMulCC = 760;  // a bundle of canonical limb products (HDR_MUL_CC)
-static const double kCyclesScanFront = 900, kCyclesScanStepCarry = 260, kCyclesScanStepDiv = 1500;
+// (carry bundles of 32 rounds 6.3 k cycles, division bundles 17 k: 33 and 85 instructions per round on a lone wave, the
+// division bundle's reciprocal once per bundle)
+static const double kCyclesScanFront = 1000, kCyclesScanFrontDiv = 2200, kCyclesScanStepCarry = 170, kCyclesScanStepDiv = 460;
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves
 static const double kCyclesFusedStageMul = 760, kCyclesFusedStageLin = 300;
@@ -1638,6 +1644,27 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     }
                     if (other >= 0) best = other;
                 }
+                // A scan bundle costs its front end however few steps it runs, and a wave's time is the sum of its bundles: while the
+                // chain of the most urgent ready step goes on with steps whose other operands are not computed yet, anything else
+                // that is ready runs first (it has to run anyway), so that chains go into few, full bundles.
+                if (best % (int)C_COUNT == (int)C_SCAN && best >= (int)C_COUNT * 17 && !getenv("CWC_SCAN_EAGER")) {
+                    const uint32_t head = tie_reverse ? heap[best].front().second : ~heap[best].front().second;
+                    size_t len_ready = 1, len_all = 1;
+                    bool contiguous = true;
+                    for (uint32_t cur = head; len_all < G / 2; ++len_all) {
+                        const uint32_t nx = scan_next[scan_partner[cur]];
+                        if (nx == 0xffffffffu || so[nx] != s || placed[nx]) break;
+                        contiguous = contiguous && indeg[nx] == 1 && indeg[scan_partner[nx]] == 1;
+                        len_ready += contiguous;
+                        cur = nx;
+                    }
+                    if (len_ready < len_all) {
+                        int other = -1;
+                        for (int c = 0; c < NH; ++c)
+                            if (c % (int)C_COUNT != (int)C_SCAN && !heap[c].empty() && !(c == C_DIV && !in_flight.empty()) && (other < 0 || heap[c].front() > heap[other].front())) other = c;
+                        if (other >= 0) best = other;
+                    }
+                }
                 // INPUT nodes first whenever any is ready (they have no producers and feed everything)
                 if (!heap[C_INPUT].empty()) best = C_INPUT;
                 picked.clear();
@@ -2182,7 +2209,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         if (cl == C_SCAN) {
             lin_bits = scan_bits | ((scan_longest - 1u) << HDR_SCAN_ITER_SHIFT);
-            form_saved = kCycles[C_SCAN] - (kCyclesScanFront + (double)scan_longest * ((scan_bits & HDR_SCAN_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry));
+            form_saved = kCycles[C_SCAN] - ((scan_bits & HDR_SCAN_DIV) ? kCyclesScanFrontDiv + (double)scan_longest * kCyclesScanStepDiv : kCyclesScanFront + (double)scan_longest * kCyclesScanStepCarry);
         }
         if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {

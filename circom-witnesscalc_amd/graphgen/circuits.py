@@ -26,30 +26,77 @@ def _field_stream(tag):
         yield int.from_bytes(h, "little") % R
 
 
+def poseidon_grain_constants(t, r_f=POSEIDON_RF, r_p=None, n=254):
+    """The Poseidon round constants and MDS matrix of the reference parameter script (Grassi et al., Poseidon, USENIX
+    Security 2021, generate_params_poseidon.sage): a Grain LFSR in self-shrinking mode seeded with (field = 1, sbox = 0 i.e.
+    x^5, n, t, R_F, R_P), 160 bits discarded; round constants by rejection below r, then a Cauchy matrix 1 / (x_i + y_j)
+    from 2t more elements.  These are circomlib's (non-optimised) Poseidon constants: the published hashes come out,
+    poseidon([1, 2]) = 7853200120776062878684798364095072458815029376092732009249414926327459813530 (tests)."""
+    r_p = POSEIDON_RP[t - 2] if r_p is None else r_p
+    bits = []
+    for v, w in ((1, 2), (0, 4), (n, 12), (t, 12), (r_f, 10), (r_p, 10)):
+        bits.extend(int(c) for c in bin(v)[2:].zfill(w))
+    bits.extend([1] * 30)
+
+    def step():
+        nb = bits[62] ^ bits[51] ^ bits[38] ^ bits[23] ^ bits[13] ^ bits[0]
+        bits.pop(0)
+        bits.append(nb)
+        return nb
+    for _ in range(160):
+        step()
+
+    def next_bit():  # self-shrinking: a 1 lets the following bit through, a 0 drops it
+        while step() == 0:
+            step()
+        return step()
+
+    def element_bits():
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | next_bit()
+        return v
+    consts = []
+    while len(consts) < (r_f + r_p) * t:
+        v = element_bits()
+        if v < R:
+            consts.append(v)
+    while True:
+        xy = [element_bits() % R for _ in range(2 * t)]
+        if len(set(xy)) != 2 * t or any((x + y) % R == 0 for x in xy[:t] for y in xy[t:]):
+            continue
+        mds = [[pow((xy[i] + xy[t + j]) % R, -1, R) for j in range(t)] for i in range(t)]
+        return [consts[r * t:(r + 1) * t] for r in range(r_f + r_p)], mds
+
+
 class PoseidonParams:
     _cache = {}
 
-    def __init__(self, t):
-        s = _field_stream("poseidon-shaped/t=%d" % t)
+    def __init__(self, t, circomlib=False):
         self.t = t
         self.rp = POSEIDON_RP[t - 2]
         n = POSEIDON_RF + self.rp
+        if circomlib:  # the real constants (circomlib's Poseidon): anchors on published hashes
+            self.C, self.Mx = poseidon_grain_constants(t)
+            return
+        s = _field_stream("poseidon-shaped/t=%d" % t)
         self.C = [[next(s) for _ in range(t)] for _ in range(n)]
         self.Mx = [[next(s) for _ in range(t)] for _ in range(t)]
 
     @classmethod
-    def get(cls, t):
-        if t not in cls._cache:
-            cls._cache[t] = cls(t)
-        return cls._cache[t]
+    def get(cls, t, circomlib=False):
+        if (t, circomlib) not in cls._cache:
+            cls._cache[(t, circomlib)] = cls(t, circomlib)
+        return cls._cache[(t, circomlib)]
 
 
-def poseidon(b: Builder, inputs, signals=True):
+def poseidon(b: Builder, inputs, signals=True, circomlib=False):
     """Poseidon-shaped permutation hash of len(inputs) field elements (t = n+1), first state word out.
     Node pattern per round: Ark = Add(x, const); Sigma = 3 Mul (x^2, x^4, x^5); Mix = Mul(const, x)
-    products summed by a serial Add chain (circom `lc += M[j][i]*in[j]`)."""
+    products summed by a serial Add chain (circom `lc += M[j][i]*in[j]`).  circomlib=True: the reference constants
+    (poseidon_grain_constants) instead of the seeded ones -- circomlib's Poseidon itself."""
     t = len(inputs) + 1
-    pp = PoseidonParams.get(t)
+    pp = PoseidonParams.get(t, circomlib)
     st = [b.const(0)] + list(inputs)
     half = POSEIDON_RF // 2
     for r in range(POSEIDON_RF + pp.rp):
@@ -77,10 +124,10 @@ def poseidon(b: Builder, inputs, signals=True):
     return st[0]
 
 
-def poseidon_model(inputs):
+def poseidon_model(inputs, circomlib=False):
     """Pure-integer model of `poseidon` above (for generator self-checks)."""
     t = len(inputs) + 1
-    pp = PoseidonParams.get(t)
+    pp = PoseidonParams.get(t, circomlib)
     st = [0] + [x % R for x in inputs]
     half = POSEIDON_RF // 2
     for r in range(POSEIDON_RF + pp.rp):
@@ -432,6 +479,16 @@ def build_circuit6():
     bits = num2bits(b, a, 256)
     out = bits2num(b, bits[16:256 - 16 - 8])
     b._witness = [b._witness[0], out, a] + [w for w in b._witness[1:] if w != out]
+    return b
+
+
+def build_poseidon_circomlib(n_inputs=2):
+    """circomlib's Poseidon(n_inputs) with its real constants: witness = [1, hash, inputs...]"""
+    b = Builder()
+    ins = b.input("inputs", n_inputs)
+    b.signal(poseidon(b, ins, signals=False, circomlib=True))
+    for h in ins:
+        b.signal(h)
     return b
 
 

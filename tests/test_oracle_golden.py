@@ -212,3 +212,41 @@ def test_reference_test_circuits_shaped(name):
         assert vals == model.evaluate(nodes, row, wit)
         assert vals[1] == expect(row[1], row[2] if len(row) > 2 else 0) % model.M
     assert not st.any()
+
+
+def test_oracles_against_plain_integer_semantics_and_published_poseidon():
+    """Anchors OUTSIDE both restatements (tests/anchors.py): every comparison, bit operation, shift, integer division and
+    field operation of a graph written by the independent `.bin` writer against plain Python integers -- ordered
+    comparisons as signed integers on [-(r-1)/2, (r-1)/2], Bor / Bxor / Band / Shr / Shl on the integers with the
+    reference's reduction and panic rules -- on 3 000 operand pairs (edges of the sign boundary, of r, of the 254-bit
+    rule); and circomlib's Poseidon with constants derived here from the Poseidon paper's Grain LFSR against the
+    hashes circomlibjs publishes.  Both oracles (big-int model, C port) must agree with these."""
+    import anchors
+    from oracle import cbind
+    data = anchors.ops_graph()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    og = cbind.Graph(data)
+    pairs = anchors.operand_pairs(1, 3000)
+    out, st = og.evaluate_batch(cbind.ints_to_array([[1, a, b] for a, b in pairs]))
+    n_panic = 0
+    for (a, b), row, s in zip(pairs, out, st):
+        want = [anchors.plain(op, a, b) for op in anchors.OPS]
+        panics = any(p for _, p in want)
+        n_panic += panics
+        assert (s != 0) == panics, (a, b)
+        for k, (op, (v, p)) in enumerate(zip(anchors.OPS, want)):
+            if p:
+                with pytest.raises(model.ReferencePanic):
+                    model.eval_duo(op, a, b)
+                continue
+            assert model.eval_duo(op, a, b) == v, (op, a, b)
+            if not panics:
+                assert cbind.array_to_ints(row)[1 + k] == v, (op, a, b)
+    assert n_panic >= 5
+    from tools.graphgen import circuits as C
+    for ins, want in anchors.POSEIDON_PUBLISHED.items():
+        data = C.build_poseidon_circomlib(len(ins)).to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        assert model.evaluate(nodes, [1] + list(ins), wit)[1] == want
+        out, st = cbind.Graph(data).evaluate_batch(cbind.ints_to_array([[1] + list(ins)]))
+        assert st[0] == 0 and cbind.array_to_ints(out[0])[1] == want
