@@ -46,6 +46,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SHADER_CLOCK_GHZ = 2.4  # MI355X peak engine clock (same guide): what the per-class cycle measurements of the cost model are in
 SEED = 0xC1C00000      # + config number
 # One-lane Montgomery products a node costs: Mul and Fr::new 1; a conversion out of Montgomery form is the
 # reduction half alone (0.5); Div = safegcd inversion (round 3: 52.2 k lone-wave cycles against 1.44 k for a product,
@@ -412,7 +413,15 @@ def main():
                                               "statistics).  What a lone wave pays per bundle does not depend on either, which is why "
                                               "compute.frac is what it is",
                          "program": {"class_bundles": ps["class_bundles"], "class_nodes": ps["class_nodes"], "fused_nodes": ps["n_fused_nodes"],
-                                     "model_wave_cycles": ps["model_wave_cycles"]},
+                                     "scan_steps": ps["n_scan_steps"], "model_wave_cycles": ps["model_wave_cycles"]},
+                         # the floor of this execution model (one wave walks the whole graph): the compiled graph's longest dependent
+                         # chain priced at the BEST measured latency of each operation on a lone wavefront -- arithmetic only, no bundle
+                         # front end (four-lane product 704 cycles, addition 290, inversion 52.2 k; compile.cc) -- against the interpreter's
+                         # launch time at the shader clock
+                         "chain": {"floor_cycles": ps["chain_floor_cycles"], "clock_ghz": SHADER_CLOCK_GHZ,
+                                   "floor_ms": ps["chain_floor_cycles"] / (SHADER_CLOCK_GHZ * 1e6),
+                                   "achieved_over_floor": ps["chain_floor_cycles"] / (SHADER_CLOCK_GHZ * 1e6) / (avg_interp_s * 1e3),
+                                   "model_over_floor": ps["model_wave_cycles"] / ps["chain_floor_cycles"] if ps["chain_floor_cycles"] else None},
                          "compute": {"unit": "modmul-equivalents/s", "achieved": eq_per_set * B / avg_interp_s,
                                      "peak": peak or None, "frac": (eq_per_set * B / avg_interp_s / peak) if peak else None,
                                      "peak_source": "measured in this run, chip-wide one-lane Montgomery products/s: the best of the interpreter's own "

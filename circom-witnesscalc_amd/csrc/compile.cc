@@ -1316,6 +1316,41 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         N = g.nodes.size();
         phase("fused narrow chains");
     }
+    // ---- the floor of this execution model: the graph's longest dependent chain priced at the best measured latency of
+    // each operation on a lone wave, as pure arithmetic without any bundle's front end (bench.py roofline.chain) ----
+    {
+        // shader cycles: the four-lane product 704 (profiles/r03_ubench_coop_mul.txt), an addition 290, the safegcd inversion
+        // 52 200 + its product (r03_inv_bench.txt), Fr::new of an input = one full-width product 1 436; integer classes at their
+        // arithmetic on canonical operands; a round of a scan loop
+        auto floor_cycles = [&](const Node& n) -> double {
+            switch (class_of(n)) {
+                case C_INPUT: return 1436;
+                case C_MUL: return 704;
+                case C_LIN: return 290;
+                case C_DIV: return 52200 + 704;
+                case C_CMPZ: return 100;
+                case C_CMPS: return 400;
+                case C_BIT: return 300;
+                case C_IDIVMOD: return 1500;
+                case C_TERN: return 100;
+                case C_MULF: return 704.0 * (1 + (fused_op2(n.op) == FOP_MUL ? 1 : 0)) + 290.0 * ((fused_op2(n.op) > FOP_MUL ? 1 : 0) + (fused_op3(n.op) ? 1 : 0));
+                case C_SCAN: return (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry;
+                default: return 0;
+            }
+        };
+        std::vector<float> fin(N, 0.0f);
+        double longest = 0;
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            if (n.kind == N_CONST) continue;
+            const uint32_t ops[3] = {n.a, n.b, n.c};
+            float t = 0;
+            for (int q = 0; q < arity_of(n); ++q) t = std::max(t, fin[ops[q]]);
+            fin[i] = t + (float)floor_cycles(n);
+            longest = std::max(longest, (double)fin[i]);
+        }
+        st.chain_floor_cycles = (uint64_t)longest;
+    }
     // ---- constants -> table (Montgomery form), node -> ref ----
     std::vector<uint32_t> ref(N, 0);  // for consts: REF_CONST|idx ; for others: slot (filled later)
     for (size_t i = 0; i < N; ++i)
@@ -2009,8 +2044,12 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // halves of a line are fetched at different times, 1.56 x the algorithmic read volume measured in round 2).  The
     // interpreter's stores / staging loads of such values then scatter: fine where it is bound by instruction issue,
     // 15 % slower on the wide, memory-heavier sha256 graph (round 1) -- hence a policy.
+    // Default (round 4): on for tiles of one or two sets of graphs that are not linear-heavy -- measured neutral for the
+    // authV2-class interpreter (12.54 ms either way at 1024 sets, profiles/r03_pack_ab.txt) while the pack kernel's reads drop
+    // from 1.43 x to 1.0 x the algorithmic volume; CWC_WITNESS_SLOTS=0 / 1 forces either way.
+    const bool witness_slots = getenv("CWC_WITNESS_SLOTS") ? policy.witness_slots : (T <= 2 && class_cost != kClassCostLinHeavy);
     std::vector<uint32_t> witness_rank;
-    if (policy.witness_slots) {
+    if (witness_slots) {
         witness_rank.assign(N, 0xffffffffu);
         for (uint32_t w : g.witness_signals)
             if (g.nodes[w].kind != N_CONST && witness_rank[w] == 0xffffffffu) witness_rank[w] = n_slots++;
@@ -2082,7 +2121,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             const uint32_t js = order_pos[k];  // node slot (record position)
             uint32_t slot = 0xffffffffu;
             if (needs_slot[i] && !request) {
-                if (policy.witness_slots && witness_rank[i] != 0xffffffffu) {
+                if (witness_slots && witness_rank[i] != 0xffffffffu) {
                     slot = witness_rank[i];
                 } else if (!free_slots.empty()) {
                     slot = free_slots.back();

@@ -1807,6 +1807,8 @@ int gwb_program_stats(gwb_graph_t* g, uint32_t program_key, gwb_program_stats_t*
         out->lanes_active_mean = wsum > 0 ? lsum / wsum : 0.0;
         out->values_per_bundle_mean = wsum > 0 ? vsum / wsum : 0.0;
         out->n_fused_nodes = p->stats.n_fused_nodes;
+        out->chain_floor_cycles = (double)p->stats.chain_floor_cycles;
+        out->n_scan_steps = p->stats.n_scan_steps;
         return 0;
     } catch (...) {
         return 1;

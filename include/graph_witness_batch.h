@@ -214,6 +214,9 @@ typedef struct {
   double model_wave_cycles;     /* the cost model's lone-wave cycles for one tile */
   double lanes_active_mean;     /* of a wave's 64 lanes: mean number holding a node's work (the four lanes of a shared product all count), weighted by the bundles' modelled time */
   double values_per_bundle_mean; /* field elements (node x input set) a bundle produces, same weighting: 64 would be one per lane */
+  double chain_floor_cycles;    /* the compiled graph's longest dependent chain priced at the best measured latency of each operation on a
+                                 * lone wavefront, arithmetic only (no bundle front end): the floor of this execution model for one tile */
+  uint64_t n_scan_steps;        /* steps of serial limb recurrences that run inside scan bundles */
 } gwb_program_stats_t;
 int gwb_program_stats(gwb_graph_t *g, uint32_t program_key, gwb_program_stats_t *out);
 

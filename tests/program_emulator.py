@@ -21,7 +21,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d50Q"
+HDR_FMT = "<12I12I6I12d51Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "SCAN"]
@@ -65,7 +65,7 @@ class Blob:
         st = h[42:]
         c0, c1, c2 = 6, 6 + N_CLASSES, 6 + 2 * N_CLASSES
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12], depth_scan=st[c2 + 13])
+                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12], chain_floor_cycles=st[c2 + 13], depth_scan=st[c2 + 14])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence of one code state on one MI355X box (run through gpurun from the repository root):
-#   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r03'
-# then, back in the container:  python tools/profile_summary.py r03  and  bash tools/copy_evidence.sh r03  (the logs named in profiles/README.md).
+#   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r04'
+# then, back in the container:  python tools/profile_summary.py r04  and  bash tools/copy_evidence.sh r04  (the logs named in profiles/README.md).
 # Each rocprofv3 pass is its own command with the program directly behind `--`; counter passes carry no trace domains.
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
@@ -23,7 +23,7 @@ rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISS
 python tools/pmc_cache_summary.py $R > $O/cache_counters_$R.log 2>&1
 PROBE_T=258,2,4 python tools/gpu_classprof.py > $O/classprof_$R.log 2>&1
 PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
-PROBE_GRAPH=bigint PROBE_B=32 PROBE_T=1 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
+PROBE_GRAPH=bigint PROBE_B=32 PROBE_T=1,2 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 python tools/gpu_sweep.py > $O/sweep_$R.log 2>&1
 python tools/gpu_autopick.py > $O/autopick_$R.log 2>&1
 python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
@@ -31,6 +31,7 @@ python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
 (cd tools/ubench && for v in r02 cxx sh32 blk; do echo "== inv_bench_$v"; timeout 120 ./inv_bench_$v; done) > $O/inv_bench_$R.log 2>&1
 python tools/gpu_e2e.py > $O/e2e_$R.log 2>&1
 CWC_FUSE=1001 SOAK_SEEDS=2000 SOAK_BASE=20261004 python tools/gpu_soak.py > $O/soak_fused_$R.log 2>&1
+SOAK_KINDS=limb SOAK_SEEDS=3000 SOAK_BASE=20261104 python tools/gpu_soak.py > $O/soak_scan_$R.log 2>&1
 CWC_FUSE=11 PROBE_B=256 PROBE_T=4353 python tools/gpu_classprof.py > $O/classprof_fused_$R.log 2>&1
 python bench.py --config 3 --cpu-sample 128 > $O/bench_config3_$R.json 2> $O/bench_config3_$R.err
 python bench.py --config 4 --cpu-sample 0 > $O/bench_config4_$R.json 2> $O/bench_config4_$R.err

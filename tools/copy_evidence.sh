@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/ (scratch) -> profiles/ (tracked): the logs of tools/collect_evidence.sh under their committed names
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out
 P=profiles
 cp $O/bench_$R.json $P/${R}_bench_line.json
@@ -22,6 +22,7 @@ cp $O/config5_$R.log $P/${R}_config5_10m_nodes.txt
 cp $O/streams_$R.log $P/${R}_streams_ab.txt
 cp $O/soak_$R.log $P/${R}_soak.txt
 cp $O/soak_fused_$R.log $P/${R}_soak_fused.txt
+cp $O/soak_scan_$R.log $P/${R}_soak_scan.txt
 cp $O/policies_$R.log $P/${R}_policies.txt
 cp $O/calibration_$R.log $P/${R}_calibration.txt
 cp $O/cache_counters_$R.log $P/${R}_cache_counters.txt

@@ -17,14 +17,26 @@ EDGE = [0, 1, 2, 3, 63, 64, 65, 127, 128, 253, 254, 255, 256, M - 1, M - 2, M //
         (1 << 128) - 1, 1 << 200, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
 KEYS = [1, 2, 4, 8, 16, 32, 64, 1 | 0x100, 2 | 0x100, 8 | 0x100, 32 | 0x100, 1 | 0x200, 4 | 0x200, 16 | 0x200, 1 | 0x400, 2 | 0x400, 8 | 0x400,
         1 | 0x800, 2 | 0x1000, 1 | 0x100 | 0x1000, 4 | 0x100 | 0x800, 8 | 0x1000, 16 | 0x100 | 0x1000]  # (0x800 / 0x1000: two / four streams per tile)
+KINDS = os.environ.get("SOAK_KINDS", "dag,dag,dag_panic,chains,forest,forest_panic,limb").split(",")
+LIMB_KEYS = [1, 2, 1 | 0x100, 2 | 0x100, 1 | 0x1000, 2 | 0x100 | 0x1000, 4, 8]  # (scan bundles exist at tile widths 1 and 2)
+
+
 def run(n_seeds, base, verbose=True):
     """returns the number of mismatching (graph, program) runs"""
     rnd = random.Random(base)
     bad = 0
     t0 = time.time()
     for s in range(n_seeds):
-        kind = rnd.choice(["dag", "dag", "dag_panic", "chains", "forest", "forest_panic"])
-        if kind.startswith("forest"):  # independent parts behind shared inputs: what the stream programs split
+        kind = rnd.choice(KINDS)
+        if kind == "limb":  # serial limb recurrences: what the compiler runs as scan bundles (tile widths 1 and 2), every shift / base width
+            if rnd.random() < 0.15:
+                b = C.build_bigint_class(k=rnd.randrange(2, 12), rounds=rnd.randrange(1, 5))
+            else:
+                b = C.build_limb_chains(rnd.choice([1, 31, 32, 33, 63, 64, 65, 100, 121, 127, 128, 129, 200, 253, rnd.randrange(1, 254)]),
+                                        rnd.choice([1, 17, 32, 63, 64, 65, 121, 128, 253, rnd.randrange(1, 254)]), rnd.randrange(1, 80), rnd.randrange(1, 4),
+                                        rnd.random() < 0.5, rnd.random() < 0.4)
+            n_in = b.n_inputs
+        elif kind.startswith("forest"):  # independent parts behind shared inputs: what the stream programs split
             b, n_in = C.build_random_dag(rnd.randrange(1 << 30), n_ops=rnd.randrange(40, 250), panic_free=(kind == "forest"), parts=rnd.randrange(2, 6)), 7
         elif kind == "chains":
             b, n_in = C.build_chain_heavy(rnd.randrange(1 << 30), n_chains=rnd.randrange(4, 20)), 6
@@ -32,12 +44,13 @@ def run(n_seeds, base, verbose=True):
             b, n_in = C.build_random_dag(rnd.randrange(1 << 30), n_ops=rnd.randrange(50, 600), panic_free=(kind == "dag")), 7
         data = b.to_bin()
         B = rnd.choice([1, 2, 3, 17, 64, 65, 200])
-        rows = [[1] + [rnd.randrange(M) if rnd.random() > 0.3 else rnd.choice(EDGE + [rnd.randrange(1 << 16)]) for _ in range(n_in - 1)] for _ in range(B)]
+        small = 0.3 if kind != "limb" else rnd.choice([0.0, 0.5, 1.0])  # (limb graphs: all field-sized, mixed, all limb-sized operands)
+        rows = [[1] + [rnd.randrange(M) if rnd.random() >= small else rnd.choice(EDGE + [rnd.randrange(1 << 16), rnd.randrange(1 << 64), rnd.randrange(1 << 64)]) for _ in range(n_in - 1)] for _ in range(B)]
         inp = cbind.ints_to_array(rows)
         og = cbind.Graph(data)
         want, wst = og.evaluate_batch(inp)
         g = pkg.Graph(data)
-        for key in rnd.sample(KEYS, 3) + [0]:
+        for key in rnd.sample(KEYS if kind != "limb" else LIMB_KEYS, 3) + [0]:
             g.set_tile_width(key)
             got, st = g.calc_witness_batch(inp)
             ok = wst == 0
