@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void pack_kernel_v1(ProgramDev p, WsTable wst,
     }
 }
 
-// ---- launchers (called from runtime.cc) -----------------------------------------------------------
+// ---- launchers (called from pipeline.cc) -----------------------------------------------------------
 hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_requests, const uint32_t* div_lanes, const ProgramDev& p,
                          const WsTable& wst, const void* inputs, uint32_t* status, uint32_t batch, hipStream_t stream, unsigned long long* prof) {
     const uint32_t tiles = (batch + T - 1) / T, nw = (W ? W : 1u) * pack, ns = p.n_streams ? p.n_streams : 1u;
@@ -1093,7 +1093,7 @@ extern "C" int gwb_kernels_have_diagnostics() {
 }
 
 // An empty kernel of this code object: its first launch makes the runtime load the object (every interpreter instance) --
-// the single-shot entry point does that on a thread of its own while the host parses and compiles (runtime.cc warm_device).
+// the single-shot entry point does that on a thread of its own while the host parses and compiles (pipeline.cc warm_device).
 __global__ void warm_kernel() {}
 hipError_t launch_warm(hipStream_t stream) {
     warm_kernel<<<1, 64, 0, stream>>>();

@@ -1,0 +1,798 @@
+// Exact rewrites of a loaded graph, in pipeline order: power-of-two divisions, bit-extract fusion, tree-height
+// reduction with shared subexpressions, one form per value (Montgomery / canonical), scan chains (the steps of serial limb
+// recurrences), fused narrow chains.  Every pass keeps the witness values; nothing that can fail is dropped or reordered.
+#include "compile_internal.hpp"
+
+namespace cwc {
+
+// Exact strength reduction done before scheduling: Idiv(x, 2^k) == Shr(x, k) and Mod(x, 2^k) == Band(x, 2^k - 1) on the
+// canonical integers the reference divides (src/graph.rs:112-121 vs :637-672, :674-687), for every x < r and k <= 253.
+// The replacement constants are appended behind the last node (constants have no dependencies).
+void rewrite_pow2_divisions(Graph& g) {
+    std::unordered_map<uint32_t, uint32_t> shift_const, mask_const;  // k -> node index
+    const size_t N = g.nodes.size();
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind != N_DUO || (n.op != OP_IDIV && n.op != OP_MOD)) continue;
+        const Node& d = g.nodes[n.b];
+        if (d.kind != N_CONST) continue;
+        const Fr& v = g.const_values[d.a];
+        int k = -1, bits = 0;
+        for (int w = 0; w < 8; ++w)
+            if (v.v[w]) {
+                bits += __builtin_popcount(v.v[w]);
+                k = 32 * w + __builtin_ctz(v.v[w]);
+            }
+        if (bits != 1 || k > 253) continue;
+        auto& table = n.op == OP_IDIV ? shift_const : mask_const;
+        auto it = table.find((uint32_t)k);
+        if (it == table.end()) {
+            Fr c = fr_zero();
+            if (n.op == OP_IDIV) {
+                c.v[0] = (uint32_t)k;
+            } else {
+                for (int w = 0; w < 8; ++w) c.v[w] = k >= 32 * (w + 1) ? 0xffffffffu : (k > 32 * w ? ((1u << (k - 32 * w)) - 1u) : 0u);
+            }
+            const uint32_t idx = (uint32_t)g.nodes.size();
+            g.nodes.push_back(Node{N_CONST, 0, (uint32_t)g.const_values.size(), 0, 0});
+            g.const_values.push_back(c);
+            it = table.emplace((uint32_t)k, idx).first;
+        }
+        Node& n2 = g.nodes[i];  // (push_back may have moved the vector)
+        n2.op = n2.op == OP_IDIV ? OP_SHR : OP_BAND;
+        n2.b = it->second;
+    }
+}
+
+// Exact fusion of the bit-decomposition idiom (circomlib Num2Bits: out[i] <-- (in >> i) & 1): Band(Shr(a, k), 1) with a
+// constant k < 254 whose Shr has no other user becomes one BITX node.  The pair costs two BIT bundles with four
+// conversions out of and one into Montgomery form (graph.rs:637-672 then :674-687); the fused node converts once and
+// its result is a boolean.  Shr cannot fail, so dropping the intermediate node loses no error.
+void fuse_bit_extract(Graph& g) {
+    const size_t N = g.nodes.size();
+    std::vector<uint32_t> uses(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) uses[n.a]++;
+        if (ar >= 2) uses[n.b]++;
+        if (ar >= 3) uses[n.c]++;
+    }
+    for (uint32_t w : g.witness_signals) uses[w]++;
+    auto small_const = [&](uint32_t idx, uint32_t& value) {
+        const Node& c = g.nodes[idx];
+        if (c.kind != N_CONST) return false;
+        const Fr& v = g.const_values[c.a];
+        for (int q = 1; q < 8; ++q)
+            if (v.v[q]) return false;
+        value = v.v[0];
+        return true;
+    };
+    std::vector<uint8_t> dead(N, 0);
+    bool any = false;
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind != N_DUO || n.op != OP_BAND) continue;
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t s = side ? n.b : n.a, c = side ? n.a : n.b;
+            uint32_t one = 0, k = 0;
+            if (!small_const(c, one) || one != 1u) continue;
+            const Node& sh = g.nodes[s];
+            if (sh.kind != N_DUO || sh.op != OP_SHR || uses[s] != 1 || !small_const(sh.b, k) || k >= 254u) continue;
+            n = Node{N_DUO, OP_BITX, sh.a, sh.b, 0};
+            dead[s] = 1;
+            any = true;
+            break;
+        }
+    }
+    if (!any) return;
+    std::vector<uint32_t> pos(N, 0xffffffffu);
+    std::vector<Node> kept;
+    kept.reserve(N);
+    // (constants appended by rewrite_pow2_divisions sit behind their users: number the survivors first)
+    uint32_t next = 0;
+    for (size_t i = 0; i < N; ++i)
+        if (!dead[i]) pos[i] = next++;
+    for (size_t i = 0; i < N; ++i) {
+        if (dead[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        kept.push_back(n);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
+}
+
+// Tree-height reduction, exact in the field: Add and Mul are associative and commutative, so a node at the end of a
+// chain of the same operation (a linear combination `lc += c_j * x_j`, or c * (x^4 * x)) may be computed from the
+// chain's leaves in any order.  A wave's time is the sum of its bundles and the bundle count follows the longest
+// dependency chain, so every node whose own chain is its critical input is rebuilt as a tree over the leaves, cheapest
+// and earliest-ready first: sum chains of n terms drop from n-1 to ceil(log2 n) levels, and a constant factor is folded
+// into the early part of a product (M_ji * x^5 becomes (M_ji * x) * x^4, one multiplication level less per Poseidon
+// round).  The intermediate nodes of the chain are still computed wherever something else (a witness element, another
+// node) needs them; common subexpressions are shared; nodes that end up unused are dropped.
+// Only Add/Mul nodes are touched, so every operation that can fail (graph.rs:634, :686-716) survives unchanged.
+void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost) {
+    // <functional> comparators below
+    const size_t N = g.nodes.size();
+    Graph h;
+    h.const_values = g.const_values;
+    std::vector<uint32_t> m(N, 0xffffffffu);  // old index -> new index
+    std::vector<uint64_t> rt;                 // earliest finish time of each new node (unbounded width)
+    rt.reserve(N + N / 4);
+    h.nodes.reserve(N + N / 4);
+    // Value numbering of the Add / Mul nodes by operand pair (x <= y).  Not one big hash table: the tables of a
+    // multi-million-node graph are far larger than the caches and every probe was a miss (2.4 per node; 10.5 M nodes:
+    // 3.7 of the compile's 7.5 s).  Instead every node y heads a list, per operation, of the nodes whose larger operand
+    // it is -- y was read a moment ago (its ready time), the list's members were made after it: the lookups stay in
+    // the caches.  A list that grows beyond kListMax (one value combined with very many earlier ones) moves into a
+    // hash table of its own kind, so the walk stays bounded.
+    struct Link { uint32_t head[2], next; };
+    const uint32_t NIL = 0xffffffffu, kListMax = 24;
+    std::vector<Link> link;
+    link.reserve(N + N / 4);
+    std::vector<uint8_t> hashed;  // bit 0 / 1: node y's Add / Mul list lives in `overflow`
+    hashed.reserve(N + N / 4);
+    FlatMap64 overflow[2] = {FlatMap64(1024), FlatMap64(1024)};
+    auto emit = [&](const Node& n, uint64_t t) -> uint32_t {
+        h.nodes.push_back(n);
+        rt.push_back(t);
+        link.push_back(Link{{NIL, NIL}, NIL});
+        hashed.push_back(0);
+        return (uint32_t)(h.nodes.size() - 1);
+    };
+    for (size_t i = 0; i < N; ++i)  // constants first (rewrite_pow2_divisions appends some behind their users)
+        if (g.nodes[i].kind == N_CONST) m[i] = emit(g.nodes[i], 0);
+    auto is_ac = [&](uint32_t idx, uint8_t op) { return h.nodes[idx].kind == N_DUO && h.nodes[idx].op == op; };
+    auto combine = [&](uint8_t op, uint32_t x, uint32_t y) -> uint32_t {  // shared (op, x, y) node
+        if (x > y) std::swap(x, y);
+        const int k = op == OP_MUL;
+        const uint64_t key = ((uint64_t)x << 32) | y;
+        const uint64_t cost = class_cost[k ? C_MUL : C_LIN];
+        uint32_t idx;
+        if (hashed[y] & (1u << k)) {
+            if (overflow[k].find(key, &idx)) return idx;
+            idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
+            overflow[k].find_or_insert(key, idx, nullptr);
+            return idx;
+        }
+        uint32_t len = 0;
+        for (idx = link[y].head[k]; idx != NIL; idx = link[idx].next, ++len)
+            if (h.nodes[idx].a == x) return idx;
+        idx = emit(Node{N_DUO, op, x, y, 0}, std::max(rt[x], rt[y]) + cost);
+        if (len >= kListMax) {  // the list moves into the hash table, this node with it
+            for (uint32_t q = link[y].head[k]; q != NIL; q = link[q].next) overflow[k].find_or_insert(((uint64_t)h.nodes[q].a << 32) | y, q, nullptr);
+            overflow[k].find_or_insert(key, idx, nullptr);
+            hashed[y] |= (uint8_t)(1u << k);
+            link[y].head[k] = NIL;
+        } else {
+            link[idx].next = link[y].head[k];
+            link[y].head[k] = idx;
+        }
+        return idx;
+    };
+    // A node inside a chain -- its one user is a node of the same operation and it is no witness element -- needs no tree
+    // of its own: the chain's end is rebuilt over the leaves and the inner node dies unless something else reads it.
+    // (Without this every node of a chain of length L flattened up to kMaxLeaves leaves: most of the compile time of
+    // multi-million-node graphs.)
+    std::vector<uint8_t> inner(N, 0);
+    {
+        std::vector<uint32_t> n_users(N, 0), same_op_users(N, 0);
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            const int ar = arity_of(n);
+            const uint32_t ops[3] = {n.a, n.b, n.c};
+            for (int q = 0; q < ar; ++q) {
+                n_users[ops[q]]++;
+                const Node& o = g.nodes[ops[q]];
+                if (n.kind == N_DUO && o.kind == N_DUO && o.op == n.op && (n.op == OP_ADD || n.op == OP_MUL)) same_op_users[ops[q]]++;
+            }
+        }
+        for (uint32_t w : g.witness_signals) n_users[w] += 2;
+        // (only where whole chains are flattened -- T = 1 -- : with the 8-leaf trees of wider tiles the inner nodes' own
+        // trees are what keeps a long chain balanced)
+        // Used for graphs beyond 16 M nodes only, where the compile time counts: the trees come out the same but are
+        // emitted in another order, and the list scheduler then packs the bigint-class graph into more linear bundles
+        // (round 3: 12 % more bundles, taken for the 10.5 M-node graph because it saved 4 of 10 compile seconds; round 4: with
+        // the limb chains in scan bundles those linear bundles are 34 of 62 bundles per round instead of 19 of 49, 15 % of
+        // the run time, and the rest of the compile got cheaper -- 1 M nodes: rewrites 1.17 -> 0.27 s;
+        // CWC_TREE_INNER_SKIP=1 / 0 forces either way).
+        const char* force = getenv("CWC_TREE_INNER_SKIP");
+        if (kMaxLeaves >= 64 && (force ? atoi(force) != 0 : N > 16000000)) {
+            for (size_t i = 0; i < N; ++i) inner[i] = n_users[i] == 1 && same_op_users[i] == 1;
+            kMaxLeaves = 1u << 16;
+        }
+    }
+    std::vector<uint8_t> inner_new;  // new-graph nodes that are such inner chain nodes
+    std::vector<uint32_t> leaves;
+    typedef std::pair<uint64_t, uint32_t> LeafKey;  // (ready time, ~position in `leaves`)
+    std::vector<LeafKey> latest;
+    std::vector<std::pair<uint64_t, uint32_t>> work;
+    std::vector<uint64_t> times;
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        Node c = n;
+        const int ar = arity_of(n);
+        if (ar >= 1) c.a = m[n.a];
+        if (ar >= 2) c.b = m[n.b];
+        if (ar >= 3) c.c = m[n.c];
+        if (!(n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_MUL))) {
+            uint64_t t = 0;
+            if (ar >= 1) t = rt[c.a];
+            if (ar >= 2) t = std::max(t, rt[c.b]);
+            if (ar >= 3) t = std::max(t, rt[c.c]);
+            m[i] = emit(c, t + cost_of(class_cost, class_of(n)));
+            continue;
+        }
+        if (inner[i]) {
+            m[i] = combine(n.op, c.a, c.b);
+            if (inner_new.size() < h.nodes.size()) inner_new.resize(h.nodes.size() + h.nodes.size() / 2 + 16, 0);
+            inner_new[m[i]] = 1;
+            continue;
+        }
+        const uint64_t cost = class_cost[n.op == OP_MUL ? C_MUL : C_LIN];
+        const uint64_t direct = std::max(rt[c.a], rt[c.b]) + cost;
+        // flatten: keep opening the latest-ready leaf while it is a node of the same operation
+        // (a max-heap on (ready time, earliest position in `leaves`): the leaf a linear scan for the first maximum finds)
+        leaves.clear();
+        leaves.push_back(c.a);
+        leaves.push_back(c.b);
+        bool opened = false;
+        // the chain's own inner nodes (emitted unbalanced above) are opened whatever their ready time ...
+        for (size_t q = 0; q < leaves.size() && leaves.size() < kMaxLeaves;) {
+            const uint32_t L = leaves[q];
+            if (L < inner_new.size() && inner_new[L] && is_ac(L, n.op)) {
+                leaves[q] = h.nodes[L].a;
+                leaves.push_back(h.nodes[L].b);
+                opened = true;
+            } else {
+                ++q;
+            }
+        }
+        // ... then the latest-ready leaf while it is a node of the same operation
+        latest.clear();
+        for (size_t q = 0; q < leaves.size(); ++q) latest.push_back(LeafKey(rt[leaves[q]], ~(uint32_t)q));
+        std::make_heap(latest.begin(), latest.end());
+        while (leaves.size() < kMaxLeaves) {
+            const uint32_t worst = ~latest.front().second;
+            const uint32_t L = leaves[worst];
+            if (!is_ac(L, n.op)) break;
+            std::pop_heap(latest.begin(), latest.end());
+            latest.pop_back();
+            leaves[worst] = h.nodes[L].a;
+            latest.push_back(LeafKey(rt[h.nodes[L].a], ~worst));
+            std::push_heap(latest.begin(), latest.end());
+            latest.push_back(LeafKey(rt[h.nodes[L].b], ~(uint32_t)leaves.size()));
+            std::push_heap(latest.begin(), latest.end());
+            leaves.push_back(h.nodes[L].b);
+            opened = true;
+        }
+        uint32_t result = 0xffffffffu;
+        if (opened) {
+            // would the rebuilt tree finish earlier?  (computed on times only, nothing is emitted yet)
+            // (min-heaps on (ready time, node): the two earliest are combined until one is left)
+            times.clear();
+            for (uint32_t L : leaves) times.push_back(rt[L]);
+            std::make_heap(times.begin(), times.end(), std::greater<uint64_t>());
+            while (times.size() > 1) {
+                std::pop_heap(times.begin(), times.end(), std::greater<uint64_t>());
+                const uint64_t t0 = times.back();
+                times.pop_back();
+                std::pop_heap(times.begin(), times.end(), std::greater<uint64_t>());
+                const uint64_t t1 = times.back();
+                times.back() = std::max(t0, t1) + cost;
+                std::push_heap(times.begin(), times.end(), std::greater<uint64_t>());
+            }
+            if (times[0] < direct) {
+                typedef std::pair<uint64_t, uint32_t> W;
+                work.clear();
+                for (uint32_t L : leaves) work.emplace_back(rt[L], L);
+                std::make_heap(work.begin(), work.end(), std::greater<W>());
+                while (work.size() > 1) {
+                    std::pop_heap(work.begin(), work.end(), std::greater<W>());
+                    const uint32_t x = work.back().second;
+                    work.pop_back();
+                    std::pop_heap(work.begin(), work.end(), std::greater<W>());
+                    const uint32_t idx = combine(n.op, x, work.back().second);
+                    work.back() = W(rt[idx], idx);
+                    std::push_heap(work.begin(), work.end(), std::greater<W>());
+                }
+                result = work[0].second;
+            }
+        }
+        m[i] = result != 0xffffffffu ? result : combine(n.op, c.a, c.b);
+    }
+    // drop what nothing needs any more: roots are the witness elements and every node that is not a plain Add/Mul
+    const size_t M = h.nodes.size();
+    std::vector<uint8_t> live(M, 0);
+    for (uint32_t w : g.witness_signals) live[m[w]] = 1;
+    for (size_t i = 0; i < M; ++i) {
+        const Node& n = h.nodes[i];
+        if (n.kind != N_CONST && !(n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_MUL))) live[i] = 1;
+    }
+    for (size_t i = M; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& n = h.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) live[n.a] = 1;
+        if (ar >= 2) live[n.b] = 1;
+        if (ar >= 3) live[n.c] = 1;
+    }
+    std::vector<uint32_t> pos(M, 0xffffffffu);
+    std::vector<Node> kept;
+    kept.reserve(M);
+    for (size_t i = 0; i < M; ++i) {
+        if (!live[i]) continue;
+        Node n = h.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[m[w]];
+    g.nodes.swap(kept);
+}
+
+// ---- representation inference ------------------------------------------------------------------------------------
+// The interpreter keeps field elements in Montgomery form (x * 2^256 mod r); the integer operations of the reference
+// (shifts, bit operations, Idiv / Mod, ordered comparisons: src/graph.rs:112-133, 621-769) work on the canonical integer,
+// and a bundle of them spends most of its time converting: two operands out of Montgomery form, the result back in
+// (three products around a few dozen instructions of integer work).  Graphs that compute on limbs and bits (bigint /
+// long-division circuits, range checks) chain such operations through additions and multiplications, none of which
+// cares about the form: a + b and a - b hold in either form, and the Montgomery product of a canonical and a Montgomery
+// operand IS the canonical product.  So every value gets ONE form, Montgomery (REP_M) or canonical (REP_C):
+//   Input -> M.  Add / Sub / Neg / TernCond results: the common form of their operands.  Mul: (M, M) -> M, (M, C) -> C.
+//   Integer operations and comparisons read either form (per-bundle header bits say which operands still need the
+//   conversion) and write the form their users prefer.  Div: Montgomery operands, Montgomery result.
+// Where the forms of two operands do not fit (Add of an M and a C value, Mul of two C values, ...) one of them is
+// converted by an inserted multiplication with a constant: x_M * (2^-256)_M = x_C, x_C * (2^256)_M = x_M; a value is
+// converted at most once per direction.  Constants serve either form (the table holds canonical copies where needed).
+// Graphs without integer chains come out all-Montgomery, as before.
+// allow_cc (limb-arithmetic graphs, tile widths with the MODE 2 interpreter instances): the product of two canonical values
+// stays a node of its own kind -- both factors canonical, result canonical (VF_MUL_CC) -- instead of converting one factor:
+// limb products are far below r, and the kernel multiplies limb-sized integers directly (general operands: two Montgomery
+// products).
+void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery,
+                                  bool allow_cc, uint64_t& n_cc) {
+    const size_t N = g.nodes.size();
+    const bool off = all_montgomery || getenv("CWC_NO_REP_INFERENCE") != nullptr;
+    // what the users of a value would rather read: > 0 canonical
+    std::vector<float> pref(N, 0.0f);
+    for (size_t i = N; !off && i-- > 0;) {
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (!ar) continue;
+        const int c = class_of(n);
+        float w = 0.0f;
+        if (is_integer_class(c)) w = 1.0f;
+        else if (c == C_DIV) w = -1.0f;
+        else if (c == C_LIN || c == C_MUL || c == C_TERN) w = 0.5f * std::max(-2.0f, std::min(2.0f, pref[i]));
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = (c == C_TERN ? 1 : 0); q < ar; ++q)  // (TernCond tests its first operand for zero: either form)
+            if (!(c == C_BIT && n.op == OP_BITX && q == 1) && g.nodes[ops[q]].kind != N_CONST) pref[ops[q]] += w;
+    }
+    std::vector<Node> out;
+    out.reserve(N + N / 8);
+    std::vector<uint32_t> at(N, 0xffffffffu);            // old node -> new index
+    std::vector<uint32_t> converted(N, 0xffffffffu);     // old node -> new index of its value in the other form
+    std::vector<uint8_t> orep(N, REP_M);
+    rep.clear();
+    vflags.clear();
+    uint32_t k_to_c = 0xffffffffu, k_to_m = 0xffffffffu;  // constant nodes 2^-256 and 2^256 mod r
+    auto emit = [&](const Node& n, uint8_t r, uint8_t f) -> uint32_t {
+        out.push_back(n);
+        rep.push_back(r);
+        vflags.push_back(f);
+        return (uint32_t)out.size() - 1;
+    };
+    auto konst = [&](bool to_c) -> uint32_t {
+        uint32_t& k = to_c ? k_to_c : k_to_m;
+        if (k == 0xffffffffu) {
+            // 2^256 mod r and its inverse (canonical values; the table holds their Montgomery forms 2^512 mod r and 1)
+            const Fr r1 = Fr{{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u}};
+            const Fr rinv = fr_from_mont(fr_from_mont(r1));  // ((2^256 * 2^-256) * 2^-256) = 2^-256
+            g.const_values.push_back(to_c ? rinv : r1);
+            k = emit(Node{N_CONST, 0, (uint32_t)g.const_values.size() - 1, 0, 0}, REP_M, 0);
+        }
+        return k;
+    };
+    auto is_const = [&](uint32_t o) { return g.nodes[o].kind == N_CONST; };
+    // operand o (old index) in form `want`; constants serve either form
+    auto get = [&](uint32_t o, uint8_t want) -> uint32_t {
+        if (is_const(o) || orep[o] == want) return at[o];
+        if (converted[o] == 0xffffffffu) {
+            const uint32_t k = konst(want == REP_C);
+            converted[o] = emit(Node{N_DUO, OP_MUL, at[o], k, 0}, want, 0);
+            ++n_conversions;
+        }
+        return converted[o];
+    };
+    for (size_t i = 0; i < N; ++i)  // constants first: the rewrites append theirs behind their users
+        if (g.nodes[i].kind == N_CONST) at[i] = emit(g.nodes[i], REP_M, 0);
+    for (size_t i = 0; i < N; ++i) {
+        Node n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        const int ar = arity_of(n);
+        const int c = class_of(n);
+        uint8_t r = REP_M, f = 0;
+        if (ar && !off) {
+            // (no vote at all -- a value only the witness reads: an integer operation then keeps its canonical result, which saves
+            // its bundle the conversion and lets limb recurrences that end in witness elements run as scan bundles)
+            const bool want_c = pref[i] > 0.0f || (pref[i] == 0.0f && is_integer_class(c));
+            auto form_of = [&](uint32_t o, uint8_t if_const) -> uint8_t { return is_const(o) ? if_const : orep[o]; };
+            if (is_integer_class(c) || c == C_CMPZ) {
+                if (is_integer_class(c)) {
+                    f |= form_of(n.a, REP_C) == REP_C ? VF_A_CANON : 0;
+                    f |= (n.op == OP_BITX || form_of(n.b, REP_C) == REP_C) ? VF_B_CANON : 0;
+                    n.a = at[n.a];
+                    n.b = at[n.b];
+                } else if (n.op == OP_EQ || n.op == OP_NEQ) {  // equal forms on both sides (a constant follows the other side)
+                    const uint8_t side = is_const(n.a) ? form_of(n.b, REP_M) : orep[n.a];
+                    n.a = get(n.a, side);
+                    n.b = get(n.b, side);
+                    f |= side == REP_C ? VF_A_CANON : 0;  // (not a header bit for this class: which copy of a constant operand is read)
+                } else {  // Land / Lor: zero tests
+                    n.a = at[n.a];
+                    n.b = at[n.b];
+                }
+                r = want_c ? REP_C : REP_M;
+                f |= want_c ? VF_OUT_CANON : 0;
+            } else if (c == C_MUL) {
+                uint8_t ra = form_of(n.a, REP_M), rb = form_of(n.b, REP_M);
+                if (is_const(n.a) != is_const(n.b)) {  // x * constant: the constant in Montgomery form keeps x's form
+                    r = is_const(n.a) ? rb : ra;
+                    n.a = at[n.a];
+                    n.b = at[n.b];
+                } else {
+                    if (ra == REP_C && rb == REP_C && allow_cc && !is_const(n.a) && !is_const(n.b)) {
+                        f |= VF_MUL_CC;
+                        ++n_cc;
+                    } else if (ra == REP_C && rb == REP_C) {  // one factor into Montgomery form: the one that is already converted, else the second
+                        if (!is_const(n.a) && converted[n.a] != 0xffffffffu) ra = REP_M;
+                        else rb = REP_M;
+                    }
+                    n.a = get(n.a, ra);
+                    n.b = get(n.b, rb);
+                    r = (ra == REP_C || rb == REP_C) ? REP_C : REP_M;
+                }
+            } else if (c == C_DIV) {
+                n.a = get(n.a, REP_M);
+                n.b = get(n.b, REP_M);
+            } else if (c == C_LIN || c == C_TERN) {
+                const uint32_t x = n.kind == N_UNO ? n.a : n.kind == N_TRES ? n.b : n.a, y = n.kind == N_UNO ? n.a : n.kind == N_TRES ? n.c : n.b;
+                uint8_t side;
+                if (is_const(x) && is_const(y)) side = want_c ? REP_C : REP_M;
+                else if (is_const(x)) side = orep[y];
+                else if (is_const(y)) side = orep[x];
+                else if (orep[x] == orep[y]) side = orep[x];
+                else side = want_c ? REP_C : REP_M;
+                if (n.kind == N_UNO) {
+                    n.a = get(n.a, side);
+                } else if (n.kind == N_TRES) {
+                    n.a = at[n.a];
+                    n.b = get(n.b, side);
+                    n.c = get(n.c, side);
+                } else {
+                    n.a = get(n.a, side);
+                    n.b = get(n.b, side);
+                }
+                r = side;
+            }
+        } else if (ar) {
+            n.a = at[n.a];
+            if (ar >= 2) n.b = at[n.b];
+            if (ar >= 3) n.c = at[n.c];
+            if (is_integer_class(c)) f = (uint8_t)((is_const(g.nodes[i].a) ? VF_A_CANON : 0) | ((n.op == OP_BITX || is_const(g.nodes[i].b)) ? VF_B_CANON : 0));
+        }
+        orep[i] = r;
+        n_canonical += ar && r == REP_C;
+        at[i] = emit(n, r, f);
+    }
+    for (uint32_t& w : g.witness_signals) w = at[w];
+    g.nodes.swap(out);
+}
+
+// ---- scan chains (round 4) ------------------------------------------------------------------------------------------
+// Limb-wise big-integer circuits (RSA / long_div-class: BASELINE config 5) are serial recurrences over canonical integers,
+// one step per limb: the carry chain of a multi-limb sum
+//     t = x_c + carry_c;  limb_c = t mod 2^n (Band after the strength reduction);  carry_{c+1} = t \ 2^n (Shr)
+// and the remainder chain of a long division by one limb
+//     t = rem_c * 2^k + x_c;  q_c = t \ d;  rem_{c+1} = t mod d.
+// Unfused, a step is two or three bundles on the graph's critical chain (Add, then Band + Shr side by side; Mul, Add, then
+// Idiv + Mod), each with ~600 cycles of front end for a few dozen instructions of limb arithmetic: 1.74 M bundles for the
+// 10.5 M-node graph.  A step whose inner nodes nothing else reads becomes a PAIR of N_SCAN nodes -- the step's OUT value
+// (limb / quotient digit) and its ACC value (carry / remainder), both naming the step's operands (a = x, b = the accumulator
+// coming in, c = the divisor) -- and the scheduler places the consecutive steps of a chain in consecutive pairs of node
+// slots of ONE bundle (class C_SCAN, program_dev.h), which runs them with a loop inside the bundle.  Exact: the kernel's
+// step is the same field addition / product and the same integer operations (graph.rs:105, 110-121, 637-687) on the same
+// canonical integers; nothing that can fail is involved (Band with 2^n - 1 stays below 2^253, Shr / Idiv / Mod cannot fail).
+// Only values that representation inference keeps canonical are touched.  scan_imm[node]: CARRY the shift n, DIV the node
+// index of the constant 2^k (its Montgomery form is what the general path multiplies with).
+// scan_partner[node]: the other node of the step.
+void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner,
+                         uint64_t& n_steps) {
+    const size_t N = g.nodes.size();
+    static const uint32_t NONE = 0xffffffffu;
+    std::vector<uint32_t> uses(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) uses[ops[q]]++;
+    }
+    for (uint32_t w : g.witness_signals) uses[w] += 2;  // (a witness element is never an inner node)
+    // constants: 2^k -> k, 2^n - 1 -> n, small integers
+    auto const_value = [&](uint32_t idx) -> const Fr* { return g.nodes[idx].kind == N_CONST ? &g.const_values[g.nodes[idx].a] : nullptr; };
+    auto pow2_of = [&](uint32_t idx) -> int {
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        int k = -1, bits = 0;
+        for (int w = 0; w < 8; ++w)
+            if (v->v[w]) {
+                bits += __builtin_popcount(v->v[w]);
+                k = 32 * w + __builtin_ctz(v->v[w]);
+            }
+        return bits == 1 && k >= 1 && k <= 253 ? k : -1;
+    };
+    auto mask_of = [&](uint32_t idx) -> int {  // 2^n - 1 -> n
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        int n = 0;
+        bool ended = false;
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t x = v->v[w];
+            if (ended) {
+                if (x) return -1;
+            } else if (x == 0xffffffffu) {
+                n += 32;
+            } else {
+                if (x & (x + 1u)) return -1;
+                n += __builtin_popcount(x);
+                ended = true;
+            }
+        }
+        return n >= 1 && n <= 253 ? n : -1;
+    };
+    auto small_of = [&](uint32_t idx) -> int {  // a shift count
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        for (int w = 1; w < 8; ++w)
+            if (v->v[w]) return -1;
+        return v->v[0] >= 1 && v->v[0] <= 253 ? (int)v->v[0] : -1;
+    };
+    auto canon = [&](uint32_t o) { return g.nodes[o].kind == N_CONST || rep[o] == REP_C; };
+    // the two users of every candidate t: (Band, Shr) or (Idiv, Mod)
+    std::vector<uint32_t> user_out(N, NONE), user_acc(N, NONE);
+    for (size_t j = 0; j < N; ++j) {
+        Node& n = g.nodes[j];
+        if (n.kind != N_DUO) continue;
+        // (value numbering orders the operands of commutative operations by index: the mask may come first)
+        if (n.op == OP_BAND && g.nodes[n.a].kind == N_CONST && g.nodes[n.b].kind != N_CONST) {
+            std::swap(n.a, n.b);
+            vflags[j] = (uint8_t)((vflags[j] & ~(VF_A_CANON | VF_B_CANON)) | ((vflags[j] & VF_A_CANON) ? VF_B_CANON : 0) | ((vflags[j] & VF_B_CANON) ? VF_A_CANON : 0));
+        }
+        if (g.nodes[n.a].kind != N_DUO || g.nodes[n.a].op != OP_ADD) continue;
+        const uint8_t want = VF_A_CANON | VF_B_CANON | VF_OUT_CANON;
+        if ((vflags[j] & want) != want) continue;
+        if (n.op == OP_BAND || n.op == OP_IDIV) user_out[n.a] = user_out[n.a] == NONE ? (uint32_t)j : NONE - 1;
+        else if (n.op == OP_SHR || n.op == OP_MOD) user_acc[n.a] = user_acc[n.a] == NONE ? (uint32_t)j : NONE - 1;
+    }
+    struct Step { uint32_t t, out, acc, x, acc_in, d, imm; bool div; };
+    std::vector<Step> steps;
+    std::vector<uint32_t> step_of_acc(N, NONE);  // ACC node (Shr / Mod) -> step
+    for (size_t t = 0; t < N; ++t) {
+        const uint32_t o = user_out[t], a = user_acc[t];
+        if (o >= NONE - 1 || a >= NONE - 1 || uses[t] != 2 || rep[t] != REP_C) continue;
+        const Node& T_ = g.nodes[t];
+        const Node &O = g.nodes[o], &A = g.nodes[a];
+        if (!canon(T_.a) || !canon(T_.b)) continue;
+        if (O.op == OP_BAND && A.op == OP_SHR) {
+            const int n = small_of(A.b);
+            if (n < 0 || mask_of(O.b) != n) continue;
+            steps.push_back(Step{(uint32_t)t, o, a, T_.a, T_.b, 0, (uint32_t)n, false});
+        } else if (O.op == OP_IDIV && A.op == OP_MOD && O.b == A.b && canon(O.b)) {
+            // t = m + x with m = rem * 2^k read by nothing else
+            int side = -1;
+            for (int q = 0; q < 2 && side < 0; ++q) {
+                const uint32_t m = q ? T_.b : T_.a;
+                const Node& M = g.nodes[m];
+                if (M.kind != N_DUO || M.op != OP_MUL || uses[m] != 1 || rep[m] != REP_C) continue;
+                if ((pow2_of(M.b) >= 0 && canon(M.a) && g.nodes[M.a].kind != N_CONST) || (pow2_of(M.a) >= 0 && canon(M.b) && g.nodes[M.b].kind != N_CONST)) side = q;
+            }
+            if (side < 0) continue;
+            const uint32_t m = side ? T_.b : T_.a, x = side ? T_.a : T_.b;
+            const Node& M = g.nodes[m];
+            const bool base_b = pow2_of(M.b) >= 0 && g.nodes[M.a].kind != N_CONST;
+            steps.push_back(Step{(uint32_t)t, o, a, x, base_b ? M.a : M.b, O.b, base_b ? M.b : M.a, true});
+        }
+    }
+    if (getenv("CWC_DEBUG_SCAN")) {
+        size_t n_band = 0, n_shr = 0, pairs = 0, uses_ok = 0, rep_ok = 0, canon_ok = 0;
+        for (size_t t = 0; t < N; ++t) {
+            n_band += user_out[t] < NONE - 1;
+            n_shr += user_acc[t] < NONE - 1;
+            if (user_out[t] >= NONE - 1 || user_acc[t] >= NONE - 1) continue;
+            ++pairs;
+            uses_ok += uses[t] == 2;
+            rep_ok += rep[t] == REP_C;
+            canon_ok += canon(g.nodes[t].a) && canon(g.nodes[t].b);
+        }
+        fprintf(stderr, "scan detection: %zu Add nodes with an OUT user, %zu with an ACC user, %zu with both; of those uses == 2: %zu, canonical: %zu, canonical operands: %zu; steps %zu\n",
+                n_band, n_shr, pairs, uses_ok, rep_ok, canon_ok, steps.size());
+    }
+    if (steps.empty()) return;
+    for (size_t k = 0; k < steps.size(); ++k) step_of_acc[steps[k].acc] = (uint32_t)k;
+    // CARRY steps: the accumulator is the operand that is another step's carry (so that chains link up); either one at a chain's head
+    for (Step& st : steps) {
+        if (st.div) continue;
+        const uint32_t sx = step_of_acc[st.x], sa = step_of_acc[st.acc_in];
+        const bool x_links = sx != NONE && !steps[sx].div && steps[sx].imm == st.imm, a_links = sa != NONE && !steps[sa].div && steps[sa].imm == st.imm;
+        if (x_links && !a_links) std::swap(st.x, st.acc_in);
+    }
+    // rewrite: OUT and ACC become N_SCAN nodes on the step's operands, the inner nodes (t, m) lose their users
+    std::vector<uint8_t> dead(N, 0);
+    for (const Step& st : steps) {
+        const uint8_t kind = st.div ? SCAN_OP_DIV : 0;
+        g.nodes[st.out] = Node{N_SCAN, kind, st.x, st.acc_in, st.d};
+        g.nodes[st.acc] = Node{N_SCAN, (uint8_t)(kind | SCAN_OP_ACC), st.x, st.acc_in, st.d};
+        vflags[st.out] = vflags[st.acc] = 0;
+        dead[st.t] = 1;
+        if (st.div) dead[g.nodes[st.t].a == st.x ? g.nodes[st.t].b : g.nodes[st.t].a] = 1;
+    }
+    // Node order: a step's nodes sit where Band / Shr (Idiv / Mod) sat, behind t and therefore behind every operand.
+    scan_imm.assign(N, 0);
+    scan_partner.assign(N, NONE);
+    for (const Step& st : steps) {
+        scan_imm[st.out] = scan_imm[st.acc] = st.imm;
+        scan_partner[st.out] = st.acc;
+        scan_partner[st.acc] = st.out;
+    }
+    n_steps += steps.size();
+    // compact (the dead inner nodes would be scheduled)
+    std::vector<uint32_t> pos(N, NONE);
+    std::vector<Node> kept;
+    std::vector<uint8_t> krep, kfl;
+    std::vector<uint32_t> kimm, kpart;
+    kept.reserve(N);
+    krep.reserve(N);
+    kfl.reserve(N);
+    kimm.reserve(N);
+    kpart.reserve(N);
+    for (size_t i = 0; i < N; ++i) {
+        if (dead[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        uint32_t imm = scan_imm[i];
+        if (n.kind == N_SCAN && (n.op & SCAN_OP_DIV)) imm = pos[imm];  // (the constant 2^k: a node index)
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+        krep.push_back(rep[i]);
+        kfl.push_back(vflags[i]);
+        kimm.push_back(imm);
+        kpart.push_back(scan_partner[i]);  // (old index: renumbered below, the partner may sit behind this node)
+    }
+    for (uint32_t& x : kpart)
+        if (x != NONE) x = pos[x];
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
+    rep.swap(krep);
+    vflags.swap(kfl);
+    scan_imm.swap(kimm);
+    scan_partner.swap(kpart);
+}
+
+// ---- fused narrow chains (round 3) --------------------------------------------------------------------------------
+// A lone wavefront pays ~600 cycles for every bundle before any arithmetic (operand / record reads, staging loads, ring
+// write), and the graphs that bound small batches are ONE dependent chain for long stretches: a Poseidon partial round
+// of a lone Merkle chain is t -> t^2 -> t^4 -> (M t) t^4 -> + side sum, four bundles of one or two nodes.  A fused node
+// keeps such a sequence in the registers of the four lanes that share its product (class C_MULF): (s * s) * m + c, or
+// a * b +- c, is one node in one bundle.  Exact in the field (the same products and sums, graph.rs:105, 110-111); only
+// Mul / Add / Sub nodes whose values are in one form are touched, nothing that can fail.  The inner nodes stay wherever
+// something else -- a witness element, another node -- reads them (the product is then computed twice: once inside the
+// fused node on the critical chain, once off it in a lane that would idle), and die otherwise.
+// Only nodes within `slack` (scheduler cost units) of the graph's critical path are fused: off the critical path a fused
+// node saves nothing and takes one of the few node slots of a narrow bundle.
+void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, const uint32_t* class_cost, uint32_t slack_permille,
+                               bool two_stage_only, uint64_t& n_fused) {
+    const size_t N = g.nodes.size();
+    std::vector<uint64_t> rt(N, 0), ht(N, 0);  // earliest finish time / longest path to a sink (own cost included in both)
+    std::vector<uint32_t> n_users(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (n.kind == N_CONST) continue;
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        uint64_t t = 0;
+        for (int q = 0; q < ar; ++q) {
+            t = std::max(t, rt[ops[q]]);
+            n_users[ops[q]]++;
+        }
+        rt[i] = t + node_cost(class_cost, n);
+    }
+    uint64_t cp = 0;
+    for (size_t i = N; i-- > 0;) {
+        const Node& n = g.nodes[i];
+        if (n.kind == N_CONST) continue;
+        ht[i] += node_cost(class_cost, n);
+        cp = std::max(cp, rt[i] - node_cost(class_cost, n) + ht[i]);
+        const int ar = arity_of(n);
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < ar; ++q) ht[ops[q]] = std::max(ht[ops[q]], ht[i]);
+    }
+    const uint64_t slack = cp / 1000 * slack_permille;
+    auto is_mul = [&](uint32_t i) { return g.nodes[i].kind == N_DUO && g.nodes[i].op == OP_MUL; };
+    auto critical = [&](uint32_t i) { return rt[i] - node_cost(class_cost, g.nodes[i]) + ht[i] + slack >= cp; };
+    bool any = false;
+    for (size_t i = 0; i < N; ++i) {
+        Node& n = g.nodes[i];
+        if (n.kind != N_DUO || (n.op != OP_ADD && n.op != OP_SUB) || !critical((uint32_t)i)) continue;
+        // the product side: the later of the two operands if it is a multiplication
+        const bool a_mul = is_mul(n.a), b_mul = is_mul(n.b);
+        if (!a_mul && !b_mul) continue;
+        const bool take_a = a_mul && (!b_mul || rt[n.a] >= rt[n.b]);
+        const uint32_t m1 = take_a ? n.a : n.b, c = take_a ? n.b : n.a;
+        if (rt[m1] < rt[c]) continue;  // (the sum waits for its other operand: nothing to gain)
+        const uint32_t lin = n.op == OP_ADD ? FOP_ADD : take_a ? FOP_SUB : FOP_RSUB;
+        const Node& M1 = g.nodes[m1];
+        // (s * s) * m + c: the square on the product's later side
+        const uint32_t p = rt[M1.a] >= rt[M1.b] ? M1.a : M1.b, q = p == M1.a ? M1.b : M1.a;
+        const uint8_t r = rep[i];
+        // (the three-stage form wants its last operand before the bundle starts; where that operand is a side sum that is
+        // ready only by the time the products are -- Poseidon's partial rounds -- product + sum alone is the better node)
+        if (!two_stage_only && M1.a != M1.b && is_mul(p) && g.nodes[p].a == g.nodes[p].b && rt[p] >= rt[q] && rep[p] == rep[g.nodes[p].a] && rep[m1] == r) {
+            n = Node{N_FUSED, fused_code(true, FOP_MUL, lin), g.nodes[p].a, q, c};
+        } else if (rep[m1] == r) {
+            n = Node{N_FUSED, fused_code(false, lin, FOP_NONE), M1.a, M1.b, c};
+        } else {
+            continue;
+        }
+        any = true;
+        ++n_fused;
+    }
+    if (!any) return;
+    // drop what nothing reads any more (roots: witness elements and everything that is not a plain Add / Mul / fused node)
+    std::vector<uint8_t> live(N, 0);
+    for (uint32_t w : g.witness_signals) live[w] = 1;
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const bool pure = n.kind == N_FUSED || (n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_SUB || n.op == OP_MUL)) || n.kind == N_CONST;
+        if (!pure) live[i] = 1;
+    }
+    for (size_t i = N; i-- > 0;) {
+        if (!live[i]) continue;
+        const Node& n = g.nodes[i];
+        const int ar = arity_of(n);
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < ar; ++q) live[ops[q]] = 1;
+    }
+    std::vector<uint32_t> pos(N, 0xffffffffu);
+    std::vector<Node> kept;
+    std::vector<uint8_t> krep, kfl;
+    kept.reserve(N);
+    for (size_t i = 0; i < N; ++i) {
+        if (!live[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+        krep.push_back(rep[i]);
+        kfl.push_back(vflags[i]);
+    }
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
+    rep.swap(krep);
+    vflags.swap(kfl);
+}
+
+}  // namespace cwc

@@ -37,7 +37,7 @@ SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_A
 
 
 def blob_checksum(body):
-    """The trailer checksum of an exported image (runtime.cc blob_checksum): position-dependent sum over 64-bit words."""
+    """The trailer checksum of an exported image (bcast.cc blob_checksum): position-dependent sum over 64-bit words."""
     import numpy as np
     K1, K2, K3, M = 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, (1 << 64) - 1
     n = len(body)

@@ -289,7 +289,7 @@ def test_authv2_class_full_size_batch_1024(pkg):
 def test_workspace_chunking_gives_identical_bytes(pkg, monkeypatch):
     """A batch whose value workspace exceeds the per-descriptor window is spread over several workspace chunks,
     covered by one launch (the kernel picks the chunk per tile) or, beyond the chunk table / CWC_STREAMS, by several
-    launches (runtime.cc); the witnesses must not depend on either."""
+    launches (pipeline.cc); the witnesses must not depend on either."""
     rnd = random.Random(12)
     data = C.build_poseidon(2).to_bin()
     rows = cbind.ints_to_array([_rand_row(rnd, 3, 0) for _ in range(301)])

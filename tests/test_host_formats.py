@@ -556,7 +556,7 @@ def test_compiler_rewrites_are_exact_on_chain_heavy_graphs(pkg, key):
 
 
 def test_loader_and_compiler_under_sanitizers(tmp_path):
-    """graph.cc + compile.cc + optimize.cc (loader, load-time optimiser, exact rewrites, scheduler, encoder, blob) under ASan + UBSan on generated graphs,
+    """graph.cc + compile.cc + rewrite.cc + costmodel.cc + program_blob.cc + optimize.cc (loader, load-time optimiser, exact rewrites, scheduler, encoder, blob) under ASan + UBSan on generated graphs,
     a fuzzed DAG, the chain-heavy graphs and a few corrupted files (no GPU involved)."""
     import subprocess
     src = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc")
@@ -564,7 +564,8 @@ def test_loader_and_compiler_under_sanitizers(tmp_path):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-Wno-unknown-pragmas", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
                            os.path.join(ROOT, "tests", "native", "compile_sanitize.cc"),
-                           os.path.join(src, "graph.cc"), os.path.join(src, "compile.cc"), os.path.join(src, "optimize.cc")])
+                           os.path.join(src, "graph.cc"), os.path.join(src, "compile.cc"), os.path.join(src, "rewrite.cc"), os.path.join(src, "costmodel.cc"),
+                           os.path.join(src, "program_blob.cc"), os.path.join(src, "optimize.cc")])
     files = []
     cases = {"gadgets": C.build_gadgets(), "poseidon3": C.build_poseidon(3), "dag": C.build_random_dag(5, n_ops=300),
              "chains": C.build_chain_heavy(3), "bigint": C.build_bigint_class(k=3, rounds=2)}

@@ -1,4 +1,4 @@
-"""Checks the automatic program choice (cost model in runtime.cc) against neighbours: per batch size, the chosen
+"""Checks the automatic program choice (cost model in pipeline.cc) against neighbours: per batch size, the chosen
 tile width / divider and its throughput, authV2-class and sha256 graphs."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
