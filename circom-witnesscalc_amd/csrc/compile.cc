@@ -306,8 +306,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint8_t> node_rep, node_vflags;
     // (limb-arithmetic graphs -- the probe's scan-aware depth is well below the plain one -- at tile widths with the MODE 2 instances)
     const bool limb_graph = T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_SCAN") && st.depth_scan * 10 < st.depth * 8;
+    // bit graphs (sha256-like: one operation in thirty-two or more is a bit extract): canonical inputs, every product canonical
+    const bool bit_graph = T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_BIT_GRAPH") && !policy.all_montgomery && st.n_bitx_nodes * 32 >= st.n_op && st.n_op > 0;
     uint64_t n_mul_cc = 0;
-    infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery, limb_graph && !getenv("CWC_NO_MUL_CC"), n_mul_cc);
+    infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery, (limb_graph || bit_graph) && !getenv("CWC_NO_MUL_CC"), n_mul_cc,
+                          bit_graph);
     N = g.nodes.size();
     phase("representation inference");
     // ---- scan chains: the steps of serial limb recurrences as pairs of N_SCAN nodes (class C_SCAN) ----
@@ -381,6 +384,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         if (c == C_TERN) return q >= 1 && node_rep[i] == REP_C;
         if (c == C_SCAN) return true;  // x, the accumulator, the divisor: canonical integers
+        if (c == C_MUL) return (node_vflags[i] & VF_MUL_CC) != 0;  // canonical products (bit graphs: with a constant's canonical copy)
         return false;  // Mul / Div: Montgomery form
     };
     for (size_t i = 0; i < N; ++i) {
@@ -1107,6 +1111,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         if (has_crefs) out.crefs.resize((size_t)(cref_row + 1) * G, 0);
         // integer-class bundles: which operands arrive as canonical integers, and whether the result stays one
         uint32_t form_bits = 0;
+        if (!idle && cl == C_INPUT && (node_vflags[order[k0] & ~REQ_FLAG] & VF_OUT_CANON)) form_bits |= HDR_OUT_CANON;  // (bit graphs: every Input node)
         if (!idle && (is_integer_class(cl) || cl == C_CMPZ)) {
             const uint8_t f0 = node_vflags[order[k0] & ~REQ_FLAG];
             for (uint32_t k = k0; k < k1; ++k) {

@@ -96,7 +96,7 @@ void rewrite_pow2_divisions(Graph& g);
 void fuse_bit_extract(Graph& g);
 void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost);
 void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery,
-                           bool allow_cc, uint64_t& n_cc);
+                           bool allow_cc, uint64_t& n_cc, bool canonical_inputs);
 void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint64_t& n_steps);
 void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, const uint32_t* class_cost, uint32_t slack_permille, bool two_stage_only,
                         uint64_t& n_fused);

@@ -553,17 +553,35 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
             if constexpr (MODE == 2) {
                 if (h & HDR_MUL_CC) {  // canonical x canonical -> canonical: limb-sized factors (below 2^64 everywhere in the wave) multiply as integers
-                    if (!wave_any((a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
-                        const uint64_t p00 = (uint64_t)a_op.v[0] * b_op.v[0], p01 = (uint64_t)a_op.v[0] * b_op.v[1], p10 = (uint64_t)a_op.v[1] * b_op.v[0], p11 = (uint64_t)a_op.v[1] * b_op.v[1];
+                    auto limb_product = [&](const Fr& x, const Fr& y) -> Fr {  // x, y < 2^64
+                        const uint64_t p00 = (uint64_t)x.v[0] * y.v[0], p01 = (uint64_t)x.v[0] * y.v[1], p10 = (uint64_t)x.v[1] * y.v[0], p11 = (uint64_t)x.v[1] * y.v[1];
                         const uint64_t m1 = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
                         const uint64_t m2 = (m1 >> 32) + (p01 >> 32) + (p10 >> 32) + (uint32_t)p11;
-                        r = fr_zero();
-                        r.v[0] = (uint32_t)p00;
-                        r.v[1] = (uint32_t)m1;
-                        r.v[2] = (uint32_t)m2;
-                        r.v[3] = (uint32_t)((m2 >> 32) + (p11 >> 32));
-                    } else {  // any operands: a into Montgomery form, then Montgomery x canonical = the canonical product
-                        r = fr_mul_wave(fr_mul_wave(a_op, fr_r2(), pv), b_op, pv);
+                        Fr z = fr_zero();
+                        z.v[0] = (uint32_t)p00;
+                        z.v[1] = (uint32_t)m1;
+                        z.v[2] = (uint32_t)m2;
+                        z.v[3] = (uint32_t)((m2 >> 32) + (p11 >> 32));
+                        return z;
+                    };
+                    const uint32_t hi_a = a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7], hi_b = b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7];
+                    if (!wave_any((hi_a | hi_b) != 0u)) {
+                        r = limb_product(a_op, b_op);
+                    } else {
+                        // small NEGATIVE factors (r - y with y < 2^64: the -1 of a bit circuit's 1 - 2b, a difference of bits): (-x) * y = -(x * y)
+                        Fr na, nb;
+                        (void)u256_sub(na, fr_p(), a_op);
+                        (void)u256_sub(nb, fr_p(), b_op);
+                        const bool a_neg = hi_a != 0u, b_neg = hi_b != 0u;
+                        const Fr ma = u256_select(a_neg, na, a_op), mb = u256_select(b_neg, nb, b_op);
+                        if (!wave_any((ma.v[2] | ma.v[3] | ma.v[4] | ma.v[5] | ma.v[6] | ma.v[7] | mb.v[2] | mb.v[3] | mb.v[4] | mb.v[5] | mb.v[6] | mb.v[7]) != 0u)) {
+                            const Fr z = limb_product(ma, mb);
+                            Fr nz;
+                            (void)u256_sub(nz, fr_p(), z);
+                            r = u256_select((a_neg != b_neg) && !u256_is_zero(z), nz, z);
+                        } else {  // any operands: a into Montgomery form, then Montgomery x canonical = the canonical product
+                            r = fr_mul_wave(fr_mul_wave(a_op, fr_r2(), pv), b_op, pv);
+                        }
                     }
                     finish(r);
                     continue;
@@ -587,7 +605,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint32_t idx = crefs[(size_t)cref_row * G + j];
                 ++cref_row;
                 const uint4* q = inputs + ((size_t)set_c * p.n_inputs + idx) * 2;
-                r = fr_mul_wave(fr_from_u4(q[0], q[1]), fr_r2(), pv);  // (any value below 2^256 is reduced: Fr::new)
+                // (any value below 2^256 is reduced: Fr::new; x * R^2 / R = the Montgomery form, x * R / R = the canonical integer of bit graphs)
+                r = fr_mul_wave(fr_from_u4(q[0], q[1]), (h & HDR_OUT_CANON) ? fr_one() : fr_r2(), pv);
                 break;
             }
             case C_DIVREQ: {  // hand the operands to the divider wave; this bundle has no result of its own
@@ -811,17 +830,37 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             const uint64_t xl = ((uint64_t)x.v[1] << 32) | x.v[0];
                             const uint64_t a0 = ((uint64_t)acc0.v[1] << 32) | acc0.v[0];
                             uint64_t r64 = 0, qh = 0, ql = 0;
-                            for (uint32_t it = 0; it < iters; ++it) {
-                                const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
-                                const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
-                                // in * 2^k (1 <= k <= 64) + x
-                                const uint64_t lo = sh == 64u ? 0ull : in << sh, hi = sh == 64u ? in : (in >> 1) >> (63u - sh);
-                                const uint64_t tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
-                                uint64_t q_h, q_l, rr;
-                                u128_divrem_64_recip(th, tl, dv, s, dn, rv, wave_any(th >= dv), q_h, q_l, rr);
-                                qh = dz ? 0ull : q_h;
-                                ql = dz ? 0ull : q_l;
-                                r64 = dz ? 0ull : rr;
+                            if (sh == 64u) {
+                                // t = rem : x -- the low word is the lane's own x for all rounds: its normalised parts are made once
+                                const uint64_t xn = xl << s, xh = (xl >> 1) >> (63u - s);
+                                for (uint32_t it = 0; it < iters; ++it) {
+                                    const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
+                                    const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
+                                    uint64_t q_h = 0, q_l, rr;
+                                    if (wave_any(in >= dv)) {  // (a chain's first step with an accumulator that is not below its divisor)
+                                        u128_divrem_64_recip(in, xl, dv, s, dn, rv, true, q_h, q_l, rr);
+                                    } else {
+                                        uint64_t rn;
+                                        div2by1((in << s) | xh, xn, dn, rv, q_l, rn);
+                                        rr = rn >> s;
+                                    }
+                                    qh = dz ? 0ull : q_h;
+                                    ql = dz ? 0ull : q_l;
+                                    r64 = dz ? 0ull : rr;
+                                }
+                            } else {
+                                for (uint32_t it = 0; it < iters; ++it) {
+                                    const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
+                                    const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
+                                    // in * 2^k (1 <= k < 64) + x
+                                    const uint64_t lo = in << sh, hi = (in >> 1) >> (63u - sh);
+                                    const uint64_t tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
+                                    uint64_t q_h, q_l, rr;
+                                    u128_divrem_64_recip(th, tl, dv, s, dn, rv, wave_any(th >= dv), q_h, q_l, rr);
+                                    qh = dz ? 0ull : q_h;
+                                    ql = dz ? 0ull : q_l;
+                                    r64 = dz ? 0ull : rr;
+                                }
                             }
                             quo.v[0] = (uint32_t)ql; quo.v[1] = (uint32_t)(ql >> 32); quo.v[2] = (uint32_t)qh; quo.v[3] = (uint32_t)(qh >> 32);
                             rem.v[0] = (uint32_t)r64; rem.v[1] = (uint32_t)(r64 >> 32);

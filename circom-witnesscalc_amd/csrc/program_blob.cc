@@ -62,7 +62,7 @@ bool validate_program(const Program& p, std::string& err) {
         // the staging loads of the two bundles behind a wait are issued in front of it: they must not read anything
         if (NS > 1 && stream != 0 && executed && (b == p.stream_first[stream] + 1 || b == p.stream_first[stream] + 2) && cnt != 0) return bad("bundle " + std::to_string(b) + ": work right behind a wait");
         if ((h & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
-        if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ)) return bad("bundle " + std::to_string(b) + ": result form bit");
+        if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ || cls == C_INPUT)) return bad("bundle " + std::to_string(b) + ": result form bit");
         const uint32_t rep = cls == C_MULQ || cls == C_MULF ? COOP_LANES : 1u;
         if ((cnt == 0 && cls != C_LIN && cls != C_SYNC) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
         if (cls == C_MULF && T > COOP_FUSE_MAX_T) return bad("bundle " + std::to_string(b) + ": fused bundle at this tile width");

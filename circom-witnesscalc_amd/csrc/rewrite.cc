@@ -354,12 +354,16 @@ void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost)
 // converted by an inserted multiplication with a constant: x_M * (2^-256)_M = x_C, x_C * (2^256)_M = x_M; a value is
 // converted at most once per direction.  Constants serve either form (the table holds canonical copies where needed).
 // Graphs without integer chains come out all-Montgomery, as before.
+// canonical_inputs (bit graphs: circuits that compute on bits, sha256-like -- a share of their operations are bit extracts):
+// the Input bundles keep the canonical integer (x mod r) instead of its Montgomery form, so that everything downstream is
+// canonical, and a product with a constant is a canonical product too (the canonical copy of the constant).  Bits and small
+// signed combinations of bits multiply as integers in the kernel; other values take the general path.
 // allow_cc (limb-arithmetic graphs, tile widths with the MODE 2 interpreter instances): the product of two canonical values
 // stays a node of its own kind -- both factors canonical, result canonical (VF_MUL_CC) -- instead of converting one factor:
 // limb products are far below r, and the kernel multiplies limb-sized integers directly (general operands: two Montgomery
 // products).
 void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery,
-                                  bool allow_cc, uint64_t& n_cc) {
+                                  bool allow_cc, uint64_t& n_cc, bool canonical_inputs) {
     const size_t N = g.nodes.size();
     const bool off = all_montgomery || getenv("CWC_NO_REP_INFERENCE") != nullptr;
     // what the users of a value would rather read: > 0 canonical
@@ -447,6 +451,10 @@ void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint
                 uint8_t ra = form_of(n.a, REP_M), rb = form_of(n.b, REP_M);
                 if (is_const(n.a) != is_const(n.b)) {  // x * constant: the constant in Montgomery form keeps x's form
                     r = is_const(n.a) ? rb : ra;
+                    if (r == REP_C && allow_cc && canonical_inputs) {  // ... or, in bit graphs, a canonical product with the constant's canonical copy
+                        f |= VF_MUL_CC;
+                        ++n_cc;
+                    }
                     n.a = at[n.a];
                     n.b = at[n.b];
                 } else {
@@ -489,6 +497,10 @@ void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint
             if (ar >= 2) n.b = at[n.b];
             if (ar >= 3) n.c = at[n.c];
             if (is_integer_class(c)) f = (uint8_t)((is_const(g.nodes[i].a) ? VF_A_CANON : 0) | ((n.op == OP_BITX || is_const(g.nodes[i].b)) ? VF_B_CANON : 0));
+        }
+        if (n.kind == N_INPUT && canonical_inputs && !off) {
+            r = REP_C;
+            f = VF_OUT_CANON;
         }
         orep[i] = r;
         n_canonical += ar && r == REP_C;

@@ -151,7 +151,7 @@ def run(blob: Blob, inputs_row):
         assert (name == "SYNC") == bool(h & (HDR_POST | HDR_WAIT)) and not (name == "SYNC" and cnt)
         a_canon, b_canon, out_canon = bool(h & HDR_A_CANON), bool(h & HDR_B_CANON), bool(h & HDR_OUT_CANON)
         assert not (a_canon or b_canon) or name in ("BIT", "IDIVMOD", "CMPS")
-        assert not out_canon or name in ("BIT", "IDIVMOD", "CMPS", "CMPZ")
+        assert not out_canon or name in ("BIT", "IDIVMOD", "CMPS", "CMPZ", "INPUT")
         one_out = 1 if out_canon else R_MONT
         assert bool(h & HDR_WAIT) == (blob.n_streams > 1 and stream != 0 and b == blob.stream_first[stream])
         assert not (h & HDR_POST) or (stream == 0 and blob.n_streams > 1)
@@ -276,7 +276,7 @@ def run(blob: Blob, inputs_row):
             elif name == "DIVGET":
                 v = mont_div(*mailbox[j])
             elif name == "INPUT":
-                v = inputs_row[blob.crefs[cref_row * G + j]] % model.M * R_MONT % model.M
+                v = inputs_row[blob.crefs[cref_row * G + j]] % model.M * (1 if out_canon else R_MONT) % model.M  # Fr::new, kept canonical in bit graphs
             elif name == "TERN":
                 v = mem_at(blob.crefs[cref_row * G + j], b - 1, stream, b) if ops[0] == 0 else ops[1]
             else:
