@@ -294,6 +294,19 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         for (int c = 0; c < C_PROF; ++c) pf[c][0] = pf[c][1] = 0;
     }
 #define CWC_STAMP(var) unsigned long long var = 0; if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+    // The statements every class path of the loop repeats at the same place of its iteration -- written once, expanded textually
+    // (the paths keep their own copies in the ISA: a shared tail costs a lone wave a taken branch per bundle).
+    // CWC_SHADOW_ISSUE: what is issued in the shadow of an iteration's LDS reads -- the refill of the record ring (REC[b mod 4] held
+    // this bundle's record, read two iterations ago) and the two result stores of the previous bundle.
+#define CWC_SHADOW_ISSUE()                                                                                                                  \
+    stage_rec(b + 4);                                                                                                                       \
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);          \
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0)
+    // CWC_NEXT_HEADER: right behind the wait for the LDS reads -- the header of bundle b + 2 out of its landing register
+    // (CWC_HDR_LANDING below), the fetch of bundle b + 3's in the same statement.
+#define CWC_NEXT_HEADER(var)                                                                                                                 \
+    asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(var) : "s"(hdr), "s"(hdr_off_n2) : "memory"); \
+    hdr_off_n2 += 4u
 
     // Software pipeline, everything through LDS.  While bundle b computes: its operands sit in STAGE[b mod 2] / the
     // RING; the memory operands of bundle b+1 are landing in STAGE[(b+1) mod 2]; those of bundle b+2 are requested as
@@ -345,13 +358,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint2 aq = *reinterpret_cast<const uint2*>(ldsb + (la & 0xffffu) + coop_chunk);  // (for linear riders)
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
-                stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+                CWC_SHADOW_ISSUE();
                 asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(aq.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
                 uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
-                asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-                hdr_off_n2 += 4u;
+                CWC_NEXT_HEADER(h_n2);
                 CWC_STAMP(st2);
                 stage_operands(b + 2, rec_n2);
                 CWC_STAMP(st3);
@@ -401,13 +411,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 const uint2 x3q = *reinterpret_cast<const uint2*>(ldsb + (lx >> 16) + coop_chunk);          // third stage: an addition
                 const uint4 rec_full_n2 = *reinterpret_cast<const uint4*>(ldsb + LDS_REC_OFF + ((b + 2) % REC_AHEAD) * REC_BYTES + lane16);
                 const uint2 rec_n2 = make_uint2(rec_full_n2.x, rec_full_n2.y), rec_hi_n2 = make_uint2(rec_full_n2.z, rec_full_n2.w);
-                stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+                CWC_SHADOW_ISSUE();
                 asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(bq.x), "v"(x2_full.v[0]), "v"(x2_full.v[4]), "v"(x2q.x), "v"(x3q.x), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
                 uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
-                asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-                hdr_off_n2 += 4u;
+                CWC_NEXT_HEADER(h_n2);
                 stage_operands(b + 2, rec_n2);
                 uint32_t out[2];
                 fr_mul_coop4(a_op, bq.x, bq.y, nq0, nq1, out);
@@ -461,17 +468,14 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // first use of an LDS-read register waits for lgkmcnt(0), which counts scalar loads too)
         // results of bundle b-1 -> tile (unconditional: values without a slot and inactive node slots go to the tile's
         // trash slot; a fixed number of vector-memory operations per bundle is what makes the counted wait possible)
-        stage_rec(b + 4);  // (REC[b mod 4] held this bundle's record, read two iterations ago: its refill is issued in the shadow of the LDS reads)
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[0], r_prev.v[1], r_prev.v[2], r_prev.v[3]}, rsrc, (int)doff_prev, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0);
+        CWC_SHADOW_ISSUE();
         uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
         unsigned long long st2 = 0, st3 = 0;
         // the wait for the LDS reads and what must follow it: every read must have completed before the staging loads overwrite
         // STAGE[b mod 2].  A lambda because the linear class runs it behind its own branch (below), the rest in line.
         auto wait_and_stage = [&]() {
             asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a_op.v[0]), "v"(a_op.v[4]), "v"(b_op.v[0]), "v"(b_op.v[4]), "v"(rec_n2.x), "v"(rec_hi_n2.x) : "memory");
-            asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(h_n2) : "s"(hdr), "s"(hdr_off_n2) : "memory");
-            hdr_off_n2 += 4u;
+            CWC_NEXT_HEADER(h_n2);
             if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st2)::"memory");
             stage_operands(b + 2, rec_n2);
             if (PROF) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st3)::"memory");
