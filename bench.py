@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0 = only the timed metric (no sub-records)")
     ap.add_argument("--extra-batch", type=int, default=None, help=argparse.SUPPRESS)   # (round-1 flags, still accepted)
     ap.add_argument("--host-path", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-selfcheck", action="store_true", help="fail (exit 5) unless the committed PMC summary behind roofline.traffic is of this library's kernel sources")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank flow: gloo, program emulator, toy graph (no GPU, no timing claim)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -364,7 +365,10 @@ def main():
         avg_interp_s = float(np.mean(interp_ms)) * 1e-3
         alg_bytes = g.algorithmic_bytes_per_set * B  # per launch
         achieved = alg_bytes / avg_interp_s / 1e9
-        traffic, traffic_source = committed_traffic(kind, B, tm["tile_width"])
+        traffic, traffic_source = committed_traffic(kind, B, tm["tile_width"], pkg.kernel_source_hash())
+        if args.pmc_selfcheck and PMC_CHECK["same_kernels"] is not True:
+            log("bench.py --pmc-selfcheck: %s" % traffic_source)
+            sys.exit(5)
         eq_per_set = modmul_equivalents(wl.stats["hist"], g.n_witness)
         # the ceiling that binds: one-lane Montgomery products per second, chip-wide, with the multiplier the interpreter's
         # full-width bundles use (fr_mul_wave, 322 issue slots; its pinned accumulators allow two waves per SIMD) -- beside it
@@ -777,7 +781,7 @@ def config4_job(pkg, cdist, wl, dev, rank, world, distributed, per_gpu=8192):
     return rec
 
 
-def committed_traffic(graph_kind, batch, tile_width):
+def committed_traffic(graph_kind, batch, tile_width, kernel_hash=None):
     """HBM bytes per interpreter launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json, collected
     on this same command line by tools/collect_evidence.sh) -- a cross-reference, not measured in this run -- or None when
     no committed profile matches this configuration."""
@@ -792,7 +796,14 @@ def committed_traffic(graph_kind, batch, tile_width):
         if c.get("graph") == graph_kind and c.get("batch_per_gpu") == batch and c.get("tile_width") == tile_width:
             best = j["kernels"]["interp"]["hbm_bytes_per_launch_corrected"]
             src = "committed rocprofv3 --pmc passes of this command line (%s), FETCH_SIZE x2 gfx950 correction; not re-measured in this run" % os.path.relpath(f, ROOT)
+            profiled = j.get("kernel_source_hash")
+            same = None if not profiled or not kernel_hash else profiled == kernel_hash
+            src += "; profiled kernels = this library's" if same else "; the profile is of OTHER kernel sources than this library's" if same is False else "; kernel sources of the profile not recorded"
+            PMC_CHECK["same_kernels"] = same
     return best, src or "none: no committed PMC profile matches this graph / batch / tile width"
+
+
+PMC_CHECK = {"same_kernels": None}  # --pmc-selfcheck: the committed PMC summary must be of the kernels this library was built from
 
 
 def cpu_baseline(graph_data, rows, d_out, n, parse_reps=3, all_cores_sets=None):

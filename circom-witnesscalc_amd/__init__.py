@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "gwb_builder_new", "gwb_builder_free", "gwb_builder_input", "gwb_builder_constant", "gwb_builder_uno", "gwb_builder_duo", "gwb_builder_tres",
     "gwb_builder_witness", "gwb_builder_input_signal", "gwb_builder_node_count", "gwb_builder_finish",
     "gwb_ubench_modmul_block", "gwb_program_stats", "gwb_calc_witness_json_to_wtns", "gwb_model_class_cycles",
-    "gwb_kernel_source_hash",
+    "gwb_kernel_source_hash", "gwb_rccl_unique_id", "gwb_rccl_comm_init", "gwb_rccl_comm_ranks", "gwb_rccl_comm_destroy",
 ]
 
 

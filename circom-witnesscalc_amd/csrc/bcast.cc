@@ -175,6 +175,73 @@ int gwb_graph_import(const void* blob, size_t len, gwb_graph_t** out, gw_status_
     });
 }
 
+// RCCL's entry points are resolved in the running process (the host program has RCCL loaded, e.g. torch's copy; this library
+// does not link it), else from the system's librccl.
+static void* rccl_symbol(const char* name) {
+    void* f = dlsym(RTLD_DEFAULT, name);
+    if (!f) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) f = dlsym(h, name);
+    }
+    return f;
+}
+
+// A communicator for gwb_graph_broadcast made through the library itself: a host in a language without a RCCL binding (or
+// with one that cannot pass ncclUniqueId by value) draws the 128-byte id on one rank, carries the bytes to the others by
+// whatever channel its job has, and every rank joins.  (ncclUniqueId is a 128-byte struct passed BY VALUE to
+// ncclCommInitRank: done here in C, where the calling convention is the compiler's business.)
+struct GwbUniqueId {
+    char internal[GWB_RCCL_UNIQUE_ID_BYTES];
+};
+int gwb_rccl_unique_id(void* id128, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
+    if (!id128) return fail(status, "null argument");
+    typedef int (*fn_t)(GwbUniqueId*);
+    fn_t f = (fn_t)rccl_symbol("ncclGetUniqueId");
+    if (!f) return fail(status, "ncclGetUniqueId not found: RCCL is not loaded in this process");
+    GwbUniqueId id;
+    memset(&id, 0, sizeof id);
+    const int rc = f(&id);
+    if (rc != 0) return fail(status, "ncclGetUniqueId failed: RCCL error " + std::to_string(rc));
+    memcpy(id128, &id, sizeof id);
+    set_status(status, OK, "");
+    return 0;
+    });
+}
+int gwb_rccl_comm_init(const void* id128, int n_ranks, int rank, void** comm, gw_status_t* status) {
+    return guarded(status, [&]() -> int {
+    if (!id128 || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(status, "bad argument");
+    typedef int (*fn_t)(void**, int, GwbUniqueId, int);
+    typedef const char* (*errstr_fn)(int);
+    fn_t f = (fn_t)rccl_symbol("ncclCommInitRank");
+    if (!f) return fail(status, "ncclCommInitRank not found: RCCL is not loaded in this process");
+    std::string err = check_device();
+    if (!err.empty()) return fail(status, err);
+    GwbUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    *comm = nullptr;
+    const int rc = f(comm, n_ranks, id, rank);
+    if (rc != 0) {
+        errstr_fn errstr = (errstr_fn)rccl_symbol("ncclGetErrorString");
+        return fail(status, std::string("ncclCommInitRank failed: ") + (errstr ? errstr(rc) : "RCCL error"));
+    }
+    set_status(status, OK, "");
+    return 0;
+    });
+}
+int gwb_rccl_comm_ranks(void* comm) {
+    typedef int (*fn_t)(void*, int*);
+    fn_t f = comm ? (fn_t)rccl_symbol("ncclCommCount") : nullptr;
+    int n = 0;
+    return f && f(comm, &n) == 0 ? n : -1;
+}
+void gwb_rccl_comm_destroy(void* comm) {
+    typedef int (*fn_t)(void*);
+    fn_t f = comm ? (fn_t)rccl_symbol("ncclCommDestroy") : nullptr;
+    if (f) (void)f(comm);
+}
+
 // One collective in the whole path: the compiled program of rank `root` goes to every GPU of the communicator over RCCL
 // (xGMI inside a node).  RCCL's entry points are resolved in the running process (the host program that owns the
 // communicator has RCCL loaded; this library does not link it).
@@ -184,14 +251,9 @@ int gwb_graph_broadcast(gwb_graph_t* g, uint32_t tile_width, size_t batch_per_ra
     if (!out || !nccl_comm) return fail(status, "null argument");
     typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     typedef const char* (*errstr_fn)(int);
-    bcast_fn bcast = (bcast_fn)dlsym(RTLD_DEFAULT, "ncclBroadcast");
-    if (!bcast) {
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (h) bcast = (bcast_fn)dlsym(h, "ncclBroadcast");
-    }
+    bcast_fn bcast = (bcast_fn)rccl_symbol("ncclBroadcast");
     if (!bcast) return fail(status, "ncclBroadcast not found: RCCL is not loaded in this process");
-    errstr_fn errstr = (errstr_fn)dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+    errstr_fn errstr = (errstr_fn)rccl_symbol("ncclGetErrorString");
     std::string err = check_device();
     if (!err.empty()) return fail(status, err);
     hipStream_t stream = (hipStream_t)hip_stream;

@@ -55,8 +55,9 @@ def broadcast_graph(pkg, graph_data, tile_width=0, src=0, device=None, batch_per
 
 class RcclComm:
     """A RCCL communicator of this process group's ranks, made for the library's own collective (gwb_graph_broadcast takes an
-    ncclComm_t; torch does not hand out the one it uses).  rank `src` draws the unique id (ncclGetUniqueId), torch.distributed
-    carries its 128 bytes to the other ranks, every rank joins with ncclCommInitRank.  RCCL is the copy torch has already
+    ncclComm_t; torch does not hand out the one it uses).  rank `src` draws the unique id, torch.distributed carries its 128
+    bytes to the other ranks, every rank joins -- through the library's own gwb_rccl_unique_id / gwb_rccl_comm_init (the
+    128-byte id goes to ncclCommInitRank by value: done in C, not through ctypes).  RCCL is the copy torch has already
     loaded (librccl.so in torch/lib), resolved through the process's global symbols."""
 
     @staticmethod
@@ -76,7 +77,7 @@ class RcclComm:
                 continue
         return None
 
-    def __init__(self, device, src=0, library=None):
+    def __init__(self, device, src=0, library=None, pkg=None):
         import ctypes
         import torch
         import torch.distributed as dist
@@ -85,6 +86,35 @@ class RcclComm:
         if L is None:
             raise RuntimeError("RCCL not found (librccl.so)")
         self.L = L
+        self._native = None
+        if pkg is not None:  # the library's own helpers (the id by value in C)
+            N = pkg.lib()
+            N.gwb_rccl_unique_id.argtypes = [ctypes.c_void_p, ctypes.POINTER(pkg.GwStatus)]
+            N.gwb_rccl_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(pkg.GwStatus)]
+            N.gwb_rccl_comm_ranks.argtypes = [ctypes.c_void_p]
+            N.gwb_rccl_comm_destroy.argtypes = [ctypes.c_void_p]
+            N.gwb_rccl_comm_destroy.restype = None
+            rank, world = dist.get_rank(), dist.get_world_size()
+            raw = ctypes.create_string_buffer(128)
+
+            def check(rc, st, what):
+                msg = ctypes.string_at(st.error_msg).decode("utf-8", "replace") if st.error_msg else ""
+                N.gwb_free_status(ctypes.byref(st))
+                if rc != 0:
+                    raise RuntimeError("%s: %s" % (what, msg))
+            if rank == src:
+                st = pkg.GwStatus()
+                check(N.gwb_rccl_unique_id(raw, ctypes.byref(st)), st, "gwb_rccl_unique_id")
+            t = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone().to(device)
+            dist.broadcast(t, src=src)
+            raw = ctypes.create_string_buffer(t.cpu().numpy().tobytes(), 128)
+            torch.cuda.set_device(device)
+            self.comm = ctypes.c_void_p()
+            st = pkg.GwStatus()
+            check(N.gwb_rccl_comm_init(raw, world, rank, ctypes.byref(self.comm), ctypes.byref(st)), st, "gwb_rccl_comm_init")
+            self.n_ranks = N.gwb_rccl_comm_ranks(self.comm)
+            self._native = N
+            return
 
         class UniqueId(ctypes.Structure):
             _fields_ = [("internal", ctypes.c_ubyte * 128)]  # (c_char would cut the id at its first zero byte when read back)
@@ -112,7 +142,10 @@ class RcclComm:
 
     def close(self):
         if getattr(self, "comm", None) and self.comm.value:
-            self.L.ncclCommDestroy(self.comm)
+            if self._native is not None:
+                self._native.gwb_rccl_comm_destroy(self.comm)
+            else:
+                self.L.ncclCommDestroy(self.comm)
             self.comm = self._ct.c_void_p()
 
 
@@ -133,7 +166,7 @@ def broadcast_graph_rccl(pkg, graph_data, tile_width=0, src=0, device=None, batc
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             return broadcast_graph(pkg, graph_data, tile_width, src=src, device=device, batch_per_rank=batch_per_rank), 0
-        comm = RcclComm(device, src, library=lib_)
+        comm = RcclComm(device, src, library=lib_, pkg=pkg)
     try:
         g = pkg.Graph(graph_data) if rank == src else None
         out, st = ctypes.c_void_p(), pkg.GwStatus()

@@ -234,6 +234,15 @@ int gwb_graph_import(const void *blob, size_t blob_len, gwb_graph_t **out, gw_st
  * xGMI inside a node) on hip_stream; every other rank imports it.  *out = g on the root, a new replica elsewhere.  This
  * is the only collective of the path -- input sets are independent, shards need no exchange.  RCCL is resolved in the
  * running process (dlsym), the library does not link it. */
+/* A RCCL communicator for gwb_graph_broadcast made through the library (for hosts without a RCCL binding of their own):
+ * one rank draws the 128-byte id, the host carries the bytes to the other ranks by whatever channel its job has (a file,
+ * a socket, MPI, torch.distributed), every rank joins with the device it evaluates on current.  The handle is an
+ * ncclComm_t; gwb_rccl_comm_ranks = ncclCommCount (-1 on error). */
+#define GWB_RCCL_UNIQUE_ID_BYTES 128
+int gwb_rccl_unique_id(void *id128, gw_status_t *status);
+int gwb_rccl_comm_init(const void *id128, int n_ranks, int rank, void **comm, gw_status_t *status);
+int gwb_rccl_comm_ranks(void *comm);
+void gwb_rccl_comm_destroy(void *comm);
 int gwb_graph_broadcast(gwb_graph_t *g, uint32_t tile_width, size_t batch_per_rank, int root, int rank, void *nccl_comm,
                         void *hip_stream, gwb_graph_t **out, gw_status_t *status);
 

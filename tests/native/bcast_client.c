@@ -38,6 +38,20 @@ int main(int argc, char** argv) {
     ncclUniqueId id;
     void* comm = NULL;
     if (!get_id || !init_rank || get_id(&id) != 0 || init_rank(&comm, 1, id, 0) != 0) { fprintf(stderr, "RCCL communicator init failed\n"); return 4; }
+    /* the same through the library's own helpers (a host without a RCCL binding): id bytes, join, count, destroy */
+    {
+        gw_status_t st0;
+        unsigned char idb[GWB_RCCL_UNIQUE_ID_BYTES];
+        void* comm2 = NULL;
+        if (gwb_rccl_unique_id(idb, &st0) != 0) { fprintf(stderr, "gwb_rccl_unique_id: %s\n", st0.error_msg); return 12; }
+        if (gwb_rccl_comm_init(idb, 1, 0, &comm2, &st0) != 0) { fprintf(stderr, "gwb_rccl_comm_init: %s\n", st0.error_msg); return 13; }
+        if (gwb_rccl_comm_ranks(comm2) != 1) { fprintf(stderr, "gwb_rccl_comm_ranks\n"); return 14; }
+        if (gwb_rccl_comm_init(idb, 2, 5, &comm2, &st0) == 0) { fprintf(stderr, "a rank beyond the communicator accepted\n"); return 15; }
+        gwb_free_status(&st0);
+        if (destroy) destroy(comm);   /* the broadcast below runs on the library-made communicator */
+        comm = comm2;
+        destroy = NULL;
+    }
     size_t glen, jlen;
     void* gdata = read_file(argv[1], &glen);
     char* json = read_file(argv[2], &jlen);
@@ -64,5 +78,6 @@ int main(int argc, char** argv) {
     }
     gwb_graph_free(g);
     if (destroy) destroy(comm);
+    else gwb_rccl_comm_destroy(comm);
     return 0;
 }

@@ -10,6 +10,7 @@ mkdir -p $O
 # the library's device code must come from the kernel sources in the tree (a stale kernels.o once produced an hour of evidence)
 want=$(make -s -C circom-witnesscalc_amd/csrc print-ksrc-hash); have=$(python -c "import cwc_import; print(cwc_import.load().kernel_source_hash())" 2>/dev/null)
 if [ "$want" != "$have" ]; then echo "libcircom_witnesscalc_amd.so was built from other kernel sources ($have, tree: $want): run make first" | tee $O/STALE_LIBRARY_$R.txt; exit 1; fi
+echo "$have" > $O/ksrc_$R.txt   # (tools/profile_summary.py stamps the PMC summary with it: bench.py --pmc-selfcheck compares)
 BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0"
 python -m pytest tests -q -m gpu > $O/gputest_$R.log 2>&1; tail -1 $O/gputest_$R.log
 python bench.py > $O/bench_$R.json 2> $O/bench_$R.err

@@ -50,7 +50,13 @@ def main():
     pack = [d for d in disp if "pack_kernel" in d[0]]
     tile = int(interp[0][0].split("interp_kernel<")[1].split(",")[0])
     divider = int(interp[0][0].split("interp_kernel<")[1].split(">")[0].split(",")[2].strip())
+    ksrc = None  # the kernel sources the profiled library was built from (written on the GPU box by tools/collect_evidence.sh)
+    try:
+        ksrc = open(os.path.join(ROOT, "gpurun_out", "ksrc_%s.txt" % r)).read().strip() or None
+    except OSError:
+        pass
     summary = {"config": {"graph": a.graph, "batch_per_gpu": a.batch, "tile_width": tile, "interpreter_waves_per_divider_wave": divider},
+               "kernel_source_hash": ksrc,
                "source": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* passes of "
                          "`python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0`, one pass per command",
                "kernels": {"interp": {"name": interp[0][0].split("(")[0], "launches": len(interp),
