@@ -16,7 +16,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import model  # noqa: E402
-from tools.graphgen import circuits as C  # noqa: E402
+import cwc_import  # noqa: E402
+C = cwc_import.load().graphgen.circuits
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 M = model.M

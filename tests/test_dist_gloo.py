@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
     import cwc_import
     pkg = cwc_import.load()
     from circom_witnesscalc_amd import dist as cdist
-    from tools.graphgen import circuits as C
+    import cwc_import
+    C = cwc_import.load().graphgen.circuits
     import program_emulator as pe
     from oracle import model
     blob = b""
@@ -96,7 +97,8 @@ def _worker_config4(rank, world, port, q):
     import cwc_import
     pkg = cwc_import.load()
     from circom_witnesscalc_amd import dist as cdist
-    from tools.graphgen import circuits as C
+    import cwc_import
+    C = cwc_import.load().graphgen.circuits
     from tools.synth import synth_inputs
     import program_emulator as pe
     data = C.build_gadgets().to_bin()

@@ -5,7 +5,9 @@ import random
 
 import pytest
 
-from tools.graphgen import circuits as C
+import cwc_import
+
+C = cwc_import.load().graphgen.circuits
 
 
 def _mutations(data, rnd, n):
@@ -115,7 +117,9 @@ def test_corrupted_program_blobs_are_rejected(pkg):
 def test_oversized_input_map_is_refused(pkg):
     """An input-map entry far beyond the Input nodes (offset 0xFFFFFFFF, the advisor's case) used to wrap the 32-bit
     input count, after which the kernel would have read beyond the caller's rows; such a graph is refused at load."""
-    from tools.graphgen.builder import Builder, serialize_graph
+    import cwc_import
+    from tools.graphgen.pywriter import serialize_graph
+    Builder = cwc_import.load().graphgen.builder.Builder
     b = Builder()
     a = b.input("a", 1)[0]
     b.signal(b.mul(a, a))

@@ -12,8 +12,10 @@ import numpy as np
 import pytest
 
 from oracle import cbind, model
-from tools.graphgen import circuits as C
-from tools.graphgen.builder import Builder
+import cwc_import
+C = cwc_import.load().graphgen.circuits
+import cwc_import
+Builder = cwc_import.load().graphgen.builder.Builder
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 
 from oracle import model
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 import program_emulator as pe
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -160,7 +161,7 @@ def test_bin_reader_accepts_unpacked_witness_and_long_constants(pkg):
 
 
 def test_graph_validation_errors(pkg):
-    from tools.graphgen.builder import serialize_graph
+    from tools.graphgen.pywriter import serialize_graph
     bad = [
         ([("Input", 0), ("Duo", "Add", 0, 1)], [0], "not before it"),          # forward reference
         ([("Input", 0), ("Duo", "Pow", 0, 0)], [0], "Pow"),                     # graph.rs:141-142
@@ -193,7 +194,8 @@ def test_inputs_from_json_matches_reference_semantics(pkg):
             g.inputs_from_json(txt)
     # reference lib.rs:259-271 vector: keys unknown to this graph -> reference panics, here an error; parse itself is
     # covered through the graph of matching shape
-    from tools.graphgen.builder import Builder
+    import cwc_import
+    Builder = cwc_import.load().graphgen.builder.Builder
     bb = Builder()
     k1 = bb.input("key1", 3); k2 = bb.input("key2"); k3 = bb.input("key3")
     for h in k1 + k2 + k3:
@@ -341,7 +343,8 @@ def test_value_numbering_lists_and_overflow(pkg):
     nodes whose larger operand a value is), and a value combined with more than 24 earlier ones moves into a hash table.
     A late value multiplied with / added to 60 inputs, every pair twice and in both operand orders, summed in long chains
     that the reduction opens: duplicates merge, and the emulator gives the reference's witnesses for every tile width."""
-    from tools.graphgen.builder import Builder
+    import cwc_import
+    Builder = cwc_import.load().graphgen.builder.Builder
     rnd = random.Random(5)
     b = Builder()
     xs = b.input("in", 60)
@@ -474,7 +477,8 @@ def test_batched_json_front_end_and_wtns_writer(pkg, tmp_path):
 
 def test_power_of_two_division_rewrite_is_exact(pkg):
     """Idiv/Mod by a constant 2^k are compiled as Shr/Band (compile.cc rewrite_pow2_divisions): same values."""
-    from tools.graphgen.builder import Builder
+    import cwc_import
+    Builder = cwc_import.load().graphgen.builder.Builder
     b = Builder()
     (x,) = b.input("x")
     ks = [0, 1, 31, 32, 33, 64, 128, 200, 253]
@@ -679,7 +683,8 @@ def test_probabilistic_passes_of_the_reference(pkg, monkeypatch):
     shape -- (a + b) * c and a * c + b * c, sums in another association, x - x, equal-valued operands of a non-algebraic
     operation -- become one node / a constant; witnesses stay those of the reference on fuzzed graphs, panicking rows
     included (operations that can fail are random functions in the evaluation: never folded, never dropped)."""
-    from tools.graphgen.builder import Builder
+    import cwc_import
+    Builder = cwc_import.load().graphgen.builder.Builder
     b = Builder()
     a, bb, c = b.input("a")[0], b.input("b")[0], b.input("c")[0]
     e1 = b.mul(b.add(a, bb), c)
@@ -729,7 +734,8 @@ def fold_heavy_builder(variant, rnd):
     """A graph built to fold: every operator on CONSTANT operands over a grid of edge values (variant 0 keeps the ones the
     reference panics on), same-operand forms, field identities, duplicated subexpressions, dead code (also fallible dead
     code).  Shared by the emulator test below and the GPU on / off test of the load-time optimiser."""
-    from tools.graphgen.builder import Builder
+    import cwc_import
+    Builder = cwc_import.load().graphgen.builder.Builder
     M = model.M
     edge = [0, 1, 2, 5, 253, 254, 255, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, M & ((1 << 253) - 1), M ^ (M & ((1 << 253) - 1))]
     duo = ["Mul", "Div", "Add", "Sub", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land", "Lor", "Shl", "Shr", "Bor", "Band", "Bxor"]

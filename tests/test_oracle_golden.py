@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from oracle import cbind, model
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KAT = json.load(open(os.path.join(GOLD, "kat_ops.json")))
@@ -85,7 +86,7 @@ def test_storage_roundtrip_vector():
     write -> read, and the trailing u64 points at a metadata record that decodes to the same witness list / input map.
     (Operand indices are not checked at this level -- the reference's reader does not check them either.)"""
     import struct
-    from tools.graphgen.builder import serialize_graph
+    from tools.graphgen.pywriter import serialize_graph
     nodes = [("Input", 0), ("Const", 1), ("Uno", "Id", 4), ("Duo", "Mul", 5, 6), ("Tres", "TernCond", 7, 8, 9)]
     wit = [4, 1]
     ins = {"sig1": (1, 3), "sig2": (5, 1)}
@@ -243,7 +244,8 @@ def test_oracles_against_plain_integer_semantics_and_published_poseidon():
             if not panics:
                 assert cbind.array_to_ints(row)[1 + k] == v, (op, a, b)
     assert n_panic >= 5
-    from tools.graphgen import circuits as C
+    import cwc_import
+    C = cwc_import.load().graphgen.circuits
     for ins, want in anchors.POSEIDON_PUBLISHED.items():
         data = C.build_poseidon_circomlib(len(ins)).to_bin()
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)

@@ -6,7 +6,8 @@ import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
 from oracle import cbind
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 rounds = int(os.environ.get("BIGINT_ROUNDS", "400")); k = int(os.environ.get("BIGINT_K", "32")); B = int(os.environ.get("PROBE_B", "32"))
 t = time.time(); b = C.build_bigint_class(k=k, rounds=rounds); data = b.to_bin(); print("generated %d bytes in %.1fs" % (len(data), time.time() - t), flush=True)
 t = time.time(); g = pkg.Graph(data); print("loaded: n_nodes=%d n_op=%d W=%d depth=%d in %.1fs" % (g.n_nodes, g.n_op, g.n_witness, g.depth, time.time() - t), flush=True)

@@ -23,7 +23,8 @@ subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "diag"])
 os.environ["CWC_LIB_PATH"] = os.path.join(_PKG, "libcircom_witnesscalc_amd_diag.so")
 import cwc_import
 pkg = cwc_import.load()
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 
 STAMPS = {"MULF": 2}   # time stamps of ~40 cycles inside a bundle's measured span (every other class path: 5)
 STAMP_CYCLES = 40

@@ -10,7 +10,8 @@ subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "diag"])
 os.environ["CWC_LIB_PATH"] = os.path.join(_PKG, "libcircom_witnesscalc_amd_diag.so")
 import cwc_import
 pkg = cwc_import.load()
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 kind = os.environ.get("PROBE_GRAPH", "authv2")
 b = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else C.build_bigint_class(k=32, rounds=int(os.environ.get("BIGINT_ROUNDS", "400")))
 g = pkg.Graph(b.to_bin())

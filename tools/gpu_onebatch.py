@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 g = pkg.Graph(C.build_authv2_class().to_bin())
 B = int(os.environ.get("PROBE_B", "1024")); T = int(os.environ.get("PROBE_T", "2"))
 rng = np.random.default_rng(1)

@@ -6,7 +6,8 @@ import numpy as np
 import cwc_import
 pkg = cwc_import.load()
 from oracle import cbind, model
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 
 def parity(name, builder, rows, tws=(1, 4, 64)):
     data = builder.to_bin()

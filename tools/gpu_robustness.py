@@ -13,7 +13,8 @@ import torch  # noqa: E402
 import cwc_import  # noqa: E402
 pkg = cwc_import.load()
 from oracle import cbind  # noqa: E402
-from tools.graphgen import circuits as C  # noqa: E402
+import cwc_import  # noqa: E402
+C = cwc_import.load().graphgen.circuits
 from tools.synth import synth_inputs  # noqa: E402
 
 D, G, T3, S2, S4 = 0x100, 0x200, 0x400, 0x800, 0x1000

@@ -1,7 +1,8 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cwc_import; pkg = cwc_import.load()
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 data = C.build_authv2_class().to_bin()
 js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'circuit9_authV2_inputs.json')).read()
 for i in range(int(os.environ.get('SHOTS', '14'))):

@@ -10,7 +10,8 @@ import numpy as np
 import cwc_import
 pkg = cwc_import.load()
 from oracle import cbind
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 
 M = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 EDGE = [0, 1, 2, 3, 63, 64, 65, 127, 128, 253, 254, 255, 256, M - 1, M - 2, M // 2, M // 2 + 1, 1 << 253, (1 << 64) - 1, 1 << 64,

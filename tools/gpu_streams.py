@@ -7,7 +7,8 @@ import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
 from oracle import cbind
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 from tools.synth import synth_inputs
 D, S2, S4 = 0x100, 0x800, 0x1000
 data = C.build_authv2_class().to_bin()

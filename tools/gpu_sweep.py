@@ -6,7 +6,8 @@ import numpy as np, torch
 import cwc_import
 pkg = cwc_import.load()
 from oracle import cbind
-from tools.graphgen import circuits as C
+import cwc_import
+C = cwc_import.load().graphgen.circuits
 sys.path.insert(0, ROOT)
 from tools.synth import synth_inputs as _synth_inputs
 
