@@ -1064,7 +1064,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (uint32_t w : g.witness_signals)
             if (g.nodes[w].kind != N_CONST && witness_rank[w] == 0xffffffffu) witness_rank[w] = n_slots++;
     }
-    const uint32_t zero_off = (uint32_t)((uint64_t)zero_const * slot_bytes);
+    // (CWC_NOWHERE=0: the zero constant's slot and the trash slot as before round 4, for A/B runs)
+    const bool nowhere = !(getenv("CWC_NOWHERE") && atoi(getenv("CWC_NOWHERE")) == 0);
+    const uint32_t zero_off = nowhere ? OFF_NOWHERE : (uint32_t)((uint64_t)zero_const * slot_bytes);
     auto mem_off = [&](uint32_t producer) -> uint64_t {
         if (g.nodes[producer].kind == N_CONST) return (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes;
         return ((uint64_t)NC + ref[producer]) * slot_bytes;
@@ -1316,12 +1318,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         for (uint32_t o : dying) free_slots.push_back(ref[o]);
     }
     n_slots = std::max(n_slots, 1u);
-    if (ws_tile_bytes(NC, n_slots, T) > 0xffffffffull) {
+    if (ws_tile_bytes(NC, n_slots, T) >= (uint64_t)OFF_NOWHERE) {
         err = "graph too large: one tile of the value workspace exceeds the 4 GiB buffer range";
         return false;
     }
     // second pass: destination byte offsets (trash slot = n_slots) + ctrl, and inactive padding records
-    const uint32_t trash_off = (uint32_t)(((uint64_t)NC + n_slots) * slot_bytes);
+    const uint32_t trash_off = nowhere ? OFF_NOWHERE : (uint32_t)(((uint64_t)NC + n_slots) * slot_bytes);
+    out.trash_off = trash_off;
     for (uint32_t b = 0; b < NB; ++b) {
         const uint32_t rep = bundle_coop[b] == 1 || bundle_coop[b] == 2 ? COOP_LANES : 1u;
         const uint32_t cnt = (bundle_start[b + 1] - bundle_start[b]) * rep;  // record positions in use

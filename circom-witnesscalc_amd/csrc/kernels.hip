@@ -36,7 +36,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // The program arrays are separate `const __restrict__` kernel arguments (not a by-value struct) so that hipcc can
 // prove them read-only: the wave-uniform header stream then becomes scalar loads (s_load).
 struct InterpDims {
-    uint32_t n_bundles, n_slots, n_inputs, batch, n_const, n_div_requests;
+    uint32_t n_bundles, n_slots, n_inputs, batch, n_const, n_div_requests, trash_off;
     const uint32_t* div_lanes;  // active lanes of each division request (divider programs)
     // streams: interpreter wave w of a workgroup evaluates bundles [stream_first[s], stream_first[s] + stream_count[s]),
     // s = w % n_streams, of tile w / n_streams (program.hpp); with divider waves, divider d serves interpreter wave d
@@ -285,7 +285,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     uint32_t nq0 = cq == 0 ? CWC_P0 : cq == 1 ? CWC_P2 : cq == 2 ? CWC_P4 : CWC_P6;
     uint32_t nq1 = cq == 0 ? CWC_P1 : cq == 1 ? CWC_P3 : cq == 2 ? CWC_P5 : CWC_P7;
     asm volatile("" : "+v"(nq0), "+v"(nq1));
-    const uint32_t trash_doff = (p.n_const + p.n_slots) * 2u * HI | t16;
+    const uint32_t trash_doff = p.trash_off | t16;  // (OFF_NOWHERE: dropped by the buffer range check)
     constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
     unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
     unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67]) / C_SCAN (prof[68], prof[71])
@@ -1053,7 +1053,7 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     const uint32_t tiles_per_wg = nw / ns;
     dim3 grid((tiles + tiles_per_wg - 1) / tiles_per_wg), block((W ? (W + 1) * pack : pack) * 64);
     const uint4* in = (const uint4*)inputs;
-    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, p.trash_off, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dims.stream_first[s] = p.stream_first[s];
         dims.stream_count[s] = p.stream_count[s];

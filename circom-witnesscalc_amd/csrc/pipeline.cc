@@ -48,6 +48,7 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.n_inputs = p.n_inputs;
     dp.dev.n_witness = p.n_witness;
     dp.dev.n_const = p.n_const;
+    dp.dev.trash_off = p.trash_off;
     dp.dev.has_fused = 0;  // (from the bundle headers themselves: an imported program's statistics are not what the kernel runs)
     for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : ((h & HDR_CLASS_MASK) == C_SCAN || ((h & HDR_CLASS_MASK) == C_MUL && (h & HDR_MUL_CC))) ? 2u : 0u;
     dp.dev.n_streams = p.n_streams;

@@ -39,6 +39,7 @@ struct Program {
     uint32_t divider = 0;                // W > 0: compiled for a divider wave shared by W interpreter waves (1 or 4)
     uint32_t n_div_requests = 0;         // C_DIVREQ bundles (what the divider wave serves, in order)
     uint32_t n_bundles = 0, n_slots = 0, n_const = 0, n_inputs = 0, n_witness = 0;
+    uint32_t trash_off = 0;              // tile-relative destination of results without a slot (program_dev.h OFF_NOWHERE, or the trash slot)
     std::vector<uint32_t> hdr;           // [n_bundles]      see program_dev.h (format v4)
     std::vector<uint32_t> recs;          // [n_bundles*G*4]  {a_off, b_off, dst | ctrl, a_lds | b_lds << 16}
     std::vector<uint32_t> crefs;         // [n_cref_rows*G]  third operand byte offset (C_TERN) / input index (C_INPUT): one row per such bundle, in bundle order

@@ -23,7 +23,10 @@ bool validate_program(const Program& p, std::string& err) {
         p.consts.size() != (size_t)p.n_const * 8 || p.witness_refs.size() != p.n_witness || p.div_lanes.size() != p.n_div_requests)
         return bad("array sizes");
     const uint32_t slot_bytes = 32u * T, HI = 16u * T;
-    const uint64_t trash_off = ((uint64_t)p.n_const + p.n_slots) * slot_bytes;
+    const uint64_t trash_slot = ((uint64_t)p.n_const + p.n_slots) * slot_bytes;
+    if (p.trash_off != OFF_NOWHERE && p.trash_off != trash_slot) return bad("trash offset");
+    if (tile_bytes >= (uint64_t)OFF_NOWHERE) return bad("tile size");
+    const uint64_t trash_off = p.trash_off;
     // streams: consecutive bundle ranges, each starting at a multiple of the pipeline depths; one stream unless the
     // divider mode is none or one divider wave per interpreter
     const uint32_t NS = p.n_streams;
@@ -85,7 +88,7 @@ bool validate_program(const Program& p, std::string& err) {
             const uint32_t* r = &p.recs[((size_t)b * G + q) * 4];
             // staging loads: 16 bytes per lane at off + 16 t and at off + HI + 16 t
             for (int k = 0; k < 2; ++k)
-                if ((r[k] % slot_bytes) != 0 || (uint64_t)r[k] + slot_bytes > tile_bytes) return bad("bundle " + std::to_string(b) + ": operand offset");
+                if (r[k] != OFF_NOWHERE && ((r[k] % slot_bytes) != 0 || (uint64_t)r[k] + slot_bytes > tile_bytes)) return bad("bundle " + std::to_string(b) + ": operand offset");
             if (cls == C_MULF) {  // stage codes: op2 in the main records (even positions), op3 (additions only) in the extra records
                 const uint32_t code = r[2] & CTRL_SUB_MASK;
                 if ((q & 1u) ? (code == FOP_MUL || code > FOP_RSUB || (r[2] & ~CTRL_MASK) != trash_off) : code > FOP_RSUB) return bad("bundle " + std::to_string(b) + ": fused stage code");
@@ -97,7 +100,7 @@ bool validate_program(const Program& p, std::string& err) {
                     return bad("bundle " + std::to_string(b) + ": scan record");
             }
             const uint32_t dst = r[2] & ~CTRL_MASK;
-            if ((dst % slot_bytes) != 0 || dst < (uint64_t)p.n_const * slot_bytes || dst > trash_off) return bad("bundle " + std::to_string(b) + ": destination");
+            if (dst != trash_off && ((dst % slot_bytes) != 0 || dst < (uint64_t)p.n_const * slot_bytes || dst >= trash_slot)) return bad("bundle " + std::to_string(b) + ": destination");
             const uint32_t la = r[3] & 0xffffu, lb = r[3] >> 16;
             const bool bitx = cls == C_BIT && (r[2] & CTRL_SUB_MASK) == SUB_BITX;
             if ((la % 16) != 0 || la + 16u * (T - 1) + LDS_HALF_BYTES + 16u > LDS_BYTES) return bad("bundle " + std::to_string(b) + ": LDS address");
@@ -133,7 +136,7 @@ static const uint32_t kBlobMagic = 0x47505743u;  // "CWPG"
 struct BlobHeader {
     uint32_t magic, version, T, G, n_bundles, n_slots, n_const, n_inputs, n_witness, divider, n_div_requests, n_streams;
     uint32_t stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS], stream_cref_first[MAX_STREAMS];
-    uint32_t n_cref_rows, reserved;
+    uint32_t n_cref_rows, trash_off;
     double stream_cycles[MAX_STREAMS], stream_cycles_mul_div[MAX_STREAMS], stream_chain_cycles[MAX_STREAMS];
     ProgramStats stats;
 };
@@ -147,12 +150,13 @@ void program_blob_write(const Program& p, uint8_t* dst) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 16;  // (16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
+    h.version = 17;  // (17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
     h.n_streams = p.n_streams;
     h.n_cref_rows = p.n_cref_rows;
+    h.trash_off = p.trash_off;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         h.stream_first[s] = p.stream_first[s]; h.stream_count[s] = p.stream_count[s]; h.stream_div_requests[s] = p.stream_div_requests[s]; h.stream_cref_first[s] = p.stream_cref_first[s];
         h.stream_cycles[s] = p.stream_cycles[s]; h.stream_cycles_mul_div[s] = p.stream_cycles_mul_div[s]; h.stream_chain_cycles[s] = p.stream_chain_cycles[s];
@@ -177,13 +181,14 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 16 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 17 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;
     p.divider = h.divider; p.n_div_requests = h.n_div_requests;
     p.n_streams = h.n_streams;
     p.n_cref_rows = h.n_cref_rows;
+    p.trash_off = h.trash_off;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         p.stream_first[s] = h.stream_first[s]; p.stream_count[s] = h.stream_count[s]; p.stream_div_requests[s] = h.stream_div_requests[s]; p.stream_cref_first[s] = h.stream_cref_first[s];
         p.stream_cycles[s] = h.stream_cycles[s]; p.stream_cycles_mul_div[s] = h.stream_cycles_mul_div[s]; p.stream_chain_cycles[s] = h.stream_chain_cycles[s];

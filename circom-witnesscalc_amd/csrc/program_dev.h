@@ -96,6 +96,11 @@ CWC_HDC uint32_t coop_nodes(uint32_t T) { return T <= COOP_MAX_T ? 64u / (COOP_L
 // crefs[row][node slot]: TernCond third operand (tile-relative byte offset, always MEM, loaded in place);
 //                        INPUT bundles: index into the set's input row.  One row per C_TERN / C_INPUT bundle in bundle
 //                        order; a wave counts the rows it has used (its stream starts at stream_cref_first).
+// A tile-relative offset beyond every tile (round 4): a staging load from there lands zeros in LDS through the buffer range
+// check and moves nothing through the memory system, a store there is dropped.  What the operands of ring-forwarded and
+// idle node slots "load" and where results without a slot "go" -- before, a zero constant's slot and the tile's trash slot:
+// real requests, 6 KiB per bundle and wave, most of an interpreter launch's L2 traffic.
+static const uint32_t OFF_NOWHERE = 0xffff0000u;
 static const uint32_t HDR_CLASS_MASK = 0xfu;
 static const int HDR_COUNT_SHIFT = 4;
 static const uint32_t HDR_LIN_SUB = 1u << 11, HDR_LIN_ADD = 1u << 12, HDR_BITX_ALL = 1u << 13;
@@ -156,6 +161,7 @@ struct ProgramDev {
     const uint32_t* witness_refs;  // [n_witness]
     const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
+    uint32_t trash_off;            // where results without a slot go: OFF_NOWHERE, or (programs compiled with CWC_NOWHERE=0) the tile's trash slot
     uint32_t has_fused;            // 1: the program has C_MULF bundles, 2: C_SCAN bundles (the interpreter instance with their path is launched)
     uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4], stream_cref_first[4];  // (program.hpp; MAX_STREAMS entries)
 };

@@ -33,6 +33,7 @@ COOP_LANES, COOP_MAX_T = 4, 4
 # scan bundles (class SCAN): pairs of record positions (2p: the step's OUT record, 2p + 1: its ACC record); header bit 11
 # kind (0 carry chain, 1 long division by one limb), bits 19-26 the shift, bits 27-31 iterations - 1; sub-op bit 0 role, bit 1 START
 HDR_MUL_CC = 1 << 13
+OFF_NOWHERE = 0xFFFF0000
 SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_ACC, SCAN_START = 2, 1 << 11, 19, 27, 1, 2
 
 
@@ -57,7 +58,7 @@ class Blob:
         (self.magic, self.version, self.T, self.G, self.n_bundles, self.n_slots, self.n_const, self.n_inputs,
          self.n_witness, self.divider, self.n_div_requests, self.n_streams) = h[:12]
         self.stream_first, self.stream_count, self.stream_div_requests, self.stream_cref_first = h[12:16], h[16:20], h[20:24], h[24:28]
-        self.n_cref_rows = h[28]
+        self.n_cref_rows, self.trash_off = h[28], h[29]
         self.stream_cycles = h[30:34]
         assert self.n_streams in (1, 2, 3, 4) and all(f % 4 == 0 for f in self.stream_first[:self.n_streams])
         assert sum(self.stream_div_requests[:self.n_streams]) == self.n_div_requests
@@ -97,8 +98,11 @@ def run(blob: Blob, inputs_row):
     T, G = blob.T, blob.G
     slot_bytes = 32 * T
     NC = blob.n_const
-    trash = (NC + blob.n_slots) * slot_bytes
-    zero_off = (NC - 1) * slot_bytes
+    # results without a slot and the operands of ring-forwarded / idle node slots: OFF_NOWHERE (dropped / zeros through the buffer
+    # range check), or -- programs compiled with CWC_NOWHERE=0 -- the tile's trash slot and the zero constant's slot
+    trash = blob.trash_off
+    assert trash in (OFF_NOWHERE, (NC + blob.n_slots) * slot_bytes)
+    zero_off = OFF_NOWHERE if trash == OFF_NOWHERE else (NC - 1) * slot_bytes
     history = {}  # value slot -> list of (stream, bundle that stored, value)
     status = 0
     # Streams (wavefronts of the tile with their own bundle ranges) run at their own pace; what orders them is stream
@@ -116,6 +120,8 @@ def run(blob: Blob, inputs_row):
     def mem_at(off, as_of_bundle, stream, issued_at):
         """content of the tile at byte offset off, after the stores of the stream's bundles <= as_of_bundle; the load
         is issued at the top of bundle `issued_at`"""
+        if off == OFF_NOWHERE:  # beyond the tile: the buffer range check lands zeros in the stage cell (idle node slots, the 0 of Neg = 0 - a)
+            return 0
         assert off % slot_bytes == 0
         s_ = off // slot_bytes
         if s_ < NC:
@@ -336,7 +342,7 @@ def run(blob: Blob, inputs_row):
         dsts = [d for d, _ in results if d != trash]
         assert len(set(dsts)) == len(dsts), "two nodes of one bundle share a destination slot"
         for d, v in results:
-            assert d % slot_bytes == 0 and NC * slot_bytes <= d <= trash
+            assert d == trash or (d % slot_bytes == 0 and NC * slot_bytes <= d < (NC + blob.n_slots) * slot_bytes)
             if d != trash:
                 hist = history.setdefault(d // slot_bytes - NC, [])
                 assert not hist or hist[0][0] == stream, "a slot is written by one stream only"
