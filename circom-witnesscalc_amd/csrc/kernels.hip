@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "fr_gfx950.hpp"
+#include "scan_gfx950.hpp"
 #include "program_dev.h"
 
 namespace cwc {
@@ -77,50 +78,6 @@ __device__ __forceinline__ void dma16(uint32_t lds_addr, uint32_t voff, const i3
 __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;
     return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-
-// ---- scan bundles (class C_SCAN, program_dev.h): helpers -------------------------------------------------------------
-// Lane l takes lane l - D's value across the whole wave (DPP wave_shr:1, a gfx9 control; the first D lanes take zero).
-template <int D>
-__device__ __forceinline__ uint32_t wave_shr_lanes(uint32_t v) {
-#pragma unroll
-    for (int i = 0; i < D; ++i) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-    return v;
-}
-template <int QP>
-__device__ __forceinline__ Fr fr_quad_perm(const Fr& a) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], QP, 0xf, 0xf, false);
-    return r;
-}
-// word k of 2^n - 1 (wave-uniform n)
-__device__ __forceinline__ uint32_t mask_word(uint32_t n, uint32_t k) { return n >= 32u * (k + 1u) ? 0xffffffffu : n > 32u * k ? (1u << (n - 32u * k)) - 1u : 0u; }
-// The carry chain's limb-sized rounds: x < 2^128 and every accumulator < 2^128 (so t = x + acc < 2^129), 1 <= n <= 128 with
-// n = 32 WS + bs.  acc' = t >> n, limb = t & (2^n - 1); the accumulator moves D lanes up the wave between rounds.
-template <int WS, int D>
-__device__ __forceinline__ void scan_carry_rounds(uint32_t iters, uint32_t bs, const uint32_t (&m)[4], bool start, const uint32_t (&x)[4], const uint32_t (&a0)[4],
-                                                  uint32_t (&limb)[4], uint32_t (&carry)[4]) {
-    uint32_t c[4] = {0, 0, 0, 0};
-    for (uint32_t it = 0; it < iters; ++it) {
-        uint32_t in[4], t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t sft = wave_shr_lanes<D>(c[k]);
-            in[k] = start ? a0[k] : sft;
-        }
-        uint32_t cy = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = adc32(x[k], in[k], cy);
-        t[4] = cy;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            limb[k] = t[k] & m[k];
-            c[k] = __builtin_amdgcn_alignbit(t[k + WS + 1], t[k + WS], bs);  // (t >> n, word k)
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) carry[k] = c[k];
 }
 
 // W = interpreter waves that share one divider wave (0: no divider waves).  PACK = such units per workgroup: PACK
@@ -785,7 +742,22 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     if (!(h & HDR_SCAN_DIV)) {
                         // ---- carry chain: t = x + acc; limb = t & (2^n - 1); acc' = t >> n
                         const bool small = !wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7]) != 0u) && sh >= 1u && sh <= 128u;
-                        if (small) {
+                        // 64-bit limbs: every segment of the bundle at once (scan_carry_parallel) when x (+ the accumulator coming in) < 2^192
+                        const bool seg = start || !active;
+                        uint32_t xp[8];
+                        {
+                            uint32_t cy = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) xp[k] = adc32(active ? x.v[k] : 0u, start && active ? acc0.v[k] : 0u, cy);
+                            xp[7] |= cy;
+                        }
+                        if (sh == 64u && iters > 2u && !wave_any((xp[6] | xp[7]) != 0u)) {
+                            const uint32_t xw[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
+                            uint32_t limb[2], carry[6];
+                            scan_carry_parallel<T>(seg, lane, xw, limb, carry);
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) r.v[k] = role_acc ? carry[k] : (k < 2 ? limb[k] : 0u);
+                        } else if (small) {
                             const uint32_t m[4] = {mask_word(sh, 0), mask_word(sh, 1), mask_word(sh, 2), mask_word(sh, 3)};
                             const uint32_t xs[4] = {x.v[0], x.v[1], x.v[2], x.v[3]}, as[4] = {acc0.v[0], acc0.v[1], acc0.v[2], acc0.v[3]};
                             uint32_t limb[4], carry[4];
@@ -834,7 +806,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             const uint64_t xl = ((uint64_t)x.v[1] << 32) | x.v[0];
                             const uint64_t a0 = ((uint64_t)acc0.v[1] << 32) | acc0.v[0];
                             uint64_t r64 = 0, qh = 0, ql = 0;
-                            if (sh == 64u) {
+                            // one divisor per segment, every incoming remainder below it: all segments at once (scan_div_parallel)
+                            const bool seg = start || !active;
+                            const uint64_t d_prev = ((uint64_t)wave_shr_lanes<D>((uint32_t)(dv >> 32)) << 32) | wave_shr_lanes<D>((uint32_t)dv);
+                            if (sh == 64u && iters > 2u && !wave_any(active && (dz || (start ? a0 >= dv : dv != d_prev)))) {
+                                scan_div_parallel<T>(seg, lane, iters, active ? dv : 1ull, active ? xl : 0ull, active ? a0 : 0ull, ql, r64);
+                            } else if (sh == 64u) {
                                 // t = rem : x -- the low word is the lane's own x for all rounds: its normalised parts are made once
                                 const uint64_t xn = xl << s, xh = (xl >> 1) >> (63u - s);
                                 for (uint32_t it = 0; it < iters; ++it) {

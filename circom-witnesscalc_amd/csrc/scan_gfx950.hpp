@@ -1,0 +1,152 @@
+// Scan bundles (class C_SCAN, program_dev.h): wave-level helpers of the interpreter's scan path -- the accumulator's move up the
+// wave, the limb-sized serial rounds, and the parallel forms of the two recurrences for 64-bit limbs.  Included by kernels.hip
+// and by tools/ubench/scan_par_test.hip (the parallel forms against the serial recurrences on one wave).
+#pragma once
+#include "fr_gfx950.hpp"
+
+namespace cwc {
+
+// ---- scan bundles (class C_SCAN, program_dev.h): helpers -------------------------------------------------------------
+// Lane l takes lane l - D's value across the whole wave (DPP wave_shr:1, a gfx9 control; the first D lanes take zero).
+// Call it as a statement of its own, never inside the unevaluated arm of `c ? a : wave_shr_lanes(v)`: there the move runs with
+// the other lanes switched off, and a DPP move reads zero from a lane that is switched off (tools/ubench/scan_par_test.hip).
+template <int D>
+__device__ __forceinline__ uint32_t wave_shr_lanes(uint32_t v) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    return v;
+}
+template <int QP>
+__device__ __forceinline__ Fr fr_quad_perm(const Fr& a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], QP, 0xf, 0xf, false);
+    return r;
+}
+// word k of 2^n - 1 (wave-uniform n)
+__device__ __forceinline__ uint32_t mask_word(uint32_t n, uint32_t k) { return n >= 32u * (k + 1u) ? 0xffffffffu : n > 32u * k ? (1u << (n - 32u * k)) - 1u : 0u; }
+// The carry chain's limb-sized rounds: x < 2^128 and every accumulator < 2^128 (so t = x + acc < 2^129), 1 <= n <= 128 with
+// n = 32 WS + bs.  acc' = t >> n, limb = t & (2^n - 1); the accumulator moves D lanes up the wave between rounds.
+template <int WS, int D>
+__device__ __forceinline__ void scan_carry_rounds(uint32_t iters, uint32_t bs, const uint32_t (&m)[4], bool start, const uint32_t (&x)[4], const uint32_t (&a0)[4],
+                                                  uint32_t (&limb)[4], uint32_t (&carry)[4]) {
+    uint32_t c[4] = {0, 0, 0, 0};
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t in[4], t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t sft = wave_shr_lanes<D>(c[k]);
+            in[k] = start ? a0[k] : sft;
+        }
+        uint32_t cy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = adc32(x[k], in[k], cy);
+        t[4] = cy;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            limb[k] = t[k] & m[k];
+            c[k] = __builtin_amdgcn_alignbit(t[k + WS + 1], t[k + WS], bs);  // (t >> n, word k)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) carry[k] = c[k];
+}
+
+// Parallel forms of the two recurrences for 64-bit limbs (n = k = 64), a bundle's chain segments all at once instead of round by
+// round.  `st`: the lane's pair starts a segment (START, or an idle pair); values are the same in both lanes of a pair.
+// Carry chain.  X = sum x_p B^p (B = 2^64, a segment's incoming accumulator added to its first x), every x_p < 2^192 as three
+// words x0 + x1 B + x2 B^2: the words that meet at position p are s_p = x0_p + x1_(p-1) + x2_(p-2) < 3 B.  Two local rounds bring the
+// carries down to one bit per position (s = lo + B ov; lo + ov_(p-1) = lo' + B w; z = lo' + w_(p-1) <= B), the last one is a
+// carry-lookahead over the wave: per pair a gate bit (0 at a segment's start) and a generate / propagate bit, one 64-bit integer
+// addition on the scalar unit ripples the carries through them.  limb_p = (z_p + c_p) mod B; the carry leaving position p is
+// x1_p + x2_p B + x2_(p-1) + ov_p + w_p + c_(p+1) -- the words of x_p and x_(p-1) above position p plus what the positions up to p
+// push out.  (tests/test_host_formats.py holds the same algorithm on plain integers against the serial recurrence.)
+template <int T>
+__device__ __forceinline__ void scan_carry_parallel(bool st, uint32_t lane, const uint32_t (&xp)[6], uint32_t (&limb)[2], uint32_t (&carry)[6]) {
+    constexpr int D = 2 * T;
+    auto u64 = [](uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; };
+    auto shr64 = [&](uint64_t v) {  // the previous pair's value, nothing at a segment's start
+        const uint32_t lo = wave_shr_lanes<D>((uint32_t)v), hi = wave_shr_lanes<D>((uint32_t)(v >> 32));
+        return st ? 0ull : u64(lo, hi);
+    };
+    const uint64_t x0 = u64(xp[0], xp[1]), x1 = u64(xp[2], xp[3]), x2 = u64(xp[4], xp[5]);
+    const uint64_t y1 = shr64(x1), y2a = shr64(x2), y2 = shr64(y2a);
+    uint64_t lo = x0 + y1;
+    uint32_t ov = lo < x0 ? 1u : 0u;
+    const uint64_t lo_b = lo + y2;
+    ov += lo_b < lo ? 1u : 0u;
+    const uint32_t ov_sh = wave_shr_lanes<D>(ov), ovp = st ? 0u : ov_sh;
+    const uint64_t lo2 = lo_b + ovp;
+    const uint32_t w = lo2 < lo_b ? 1u : 0u;
+    const uint32_t w_sh = wave_shr_lanes<D>(w), wp = st ? 0u : w_sh;
+    const uint64_t z = lo2 + wp;
+    const bool gen = z < lo2, prop = z == ~0ull;
+    // lookahead: lanes of set t = lane mod T; OUT lanes carry the gate, ACC lanes generate / propagate
+    constexpr uint64_t OUT_LANES = T == 1 ? 0x5555555555555555ull : 0x3333333333333333ull;
+    const uint64_t b_gate = __ballot(!st) & OUT_LANES, b_pg = __ballot(gen || prop) & ~OUT_LANES, b_g = __ballot(gen) & ~OUT_LANES;
+    uint64_t cbits = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint64_t lt = T == 1 ? ~0ull : (t == 0 ? 0x5555555555555555ull : 0xAAAAAAAAAAAAAAAAull);
+        const uint64_t a = ((b_gate | b_pg) & lt) | ~lt, bb = b_g & lt;
+        cbits |= ((a + bb) ^ a ^ bb) & lt;
+    }
+    const uint32_t cin = (uint32_t)(cbits >> (lane | (uint32_t)T)) & 1u;  // the carry into the pair's ACC lane of this set
+    const uint64_t dgt = z + cin;
+    const uint32_t cout = (gen || (prop && cin)) ? 1u : 0u;
+    limb[0] = (uint32_t)dgt;
+    limb[1] = (uint32_t)(dgt >> 32);
+    // carry = x1 + x2 B + x2_(p-1) + ov + w + cout  (< 2^129 + ...: three words and a bit)
+    const uint32_t small = ov + w + cout;
+    uint64_t c0 = x1 + y2a;
+    uint64_t k1 = c0 < x1 ? 1ull : 0ull;
+    const uint64_t c0b = c0 + small;
+    k1 += c0b < c0 ? 1ull : 0ull;
+    const uint64_t c1 = x2 + k1;
+    carry[0] = (uint32_t)c0b;
+    carry[1] = (uint32_t)(c0b >> 32);
+    carry[2] = (uint32_t)c1;
+    carry[3] = (uint32_t)(c1 >> 32);
+    carry[4] = c1 < x2 ? 1u : 0u;
+    carry[5] = 0u;
+}
+// Long division by one limb d (the same for all steps of a segment, every incoming remainder below it).  A step is the map
+// r -> (r B + x) mod d = (r m + v) mod d with m = B mod d, v = x mod d; maps compose ((m1, v1) then (m2, v2) = (m1 m2, v1 m2 + v2)),
+// so an inclusive segmented prefix over the pairs (log2 rounds; a segment's first step takes its incoming remainder in: m = 0,
+// v = (acc B + x) mod d) leaves every step's outgoing remainder, and the quotient digit is one more two-by-one division of
+// (incoming remainder : x).  Products modulo d: a b < d^2 has its high word below d, the precondition of div2by1.
+template <int T>
+__device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32_t rounds_cover, uint64_t dv, uint64_t x, uint64_t a0, uint64_t& quo, uint64_t& rem) {
+    constexpr int D = 2 * T;
+    const uint32_t s = clz64_nonzero(dv);
+    const uint64_t dn = dv << s, rv = recip64(dn);
+    auto divrem = [&](uint64_t hi, uint64_t lo, uint64_t& q) -> uint64_t {  // hi < dv
+        uint64_t rn;
+        div2by1((hi << s) | ((lo >> 1) >> (63u - s)), lo << s, dn, rv, q, rn);
+        return rn >> s;
+    };
+    uint64_t qd;
+    uint64_t m = st ? 0ull : divrem(0ull, 0ull - dv, qd);  // B mod d = (B - d) mod d
+    uint64_t v = divrem(st ? a0 : 0ull, x, qd);
+    bool f = st;
+    for (uint32_t dl = 1; dl < rounds_cover; dl <<= 1) {
+        const int src = (int)((lane - dl * (uint32_t)D) << 2);
+        const uint64_t pm = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)m);
+        const uint64_t pv_ = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)v);
+        const bool pf = __builtin_amdgcn_ds_bpermute(src, f ? 1 : 0) != 0;
+        // v' = (pv m + v) mod d, m' = (pm m) mod d
+        const uint64_t t1 = divrem(mulhi64(pv_, m), pv_ * m, qd);
+        uint64_t nv = t1 + v;
+        nv -= (nv < t1 || nv >= dv) ? dv : 0ull;
+        const uint64_t nm = divrem(mulhi64(pm, m), pm * m, qd);
+        v = f ? v : nv;
+        m = f ? m : nm;
+        f = f || pf;
+    }
+    const uint32_t r0 = wave_shr_lanes<D>((uint32_t)v), r1 = wave_shr_lanes<D>((uint32_t)(v >> 32));
+    const uint64_t rin = st ? a0 : (((uint64_t)r1 << 32) | r0);
+    (void)divrem(rin, x, quo);
+    rem = v;
+}
+
+}  // namespace cwc

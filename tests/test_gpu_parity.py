@@ -584,6 +584,41 @@ def test_scan_bundles_on_the_gpu(pkg):
     _check(pkg, data, scan_rows(rnd, g.n_inputs, 40), tiles=(1, 2, 4))
 
 
+def test_parallel_scan_forms(pkg, tmp_path):
+    """Round 4: chains of 64-bit limbs run all segments of a scan bundle at once (csrc/scan_gfx950.hpp: carry-lookahead over the
+    wave; long division as a segmented prefix of affine maps modulo the divisor).  (1) One wave, the helpers alone: 8 000 random
+    bundles -- segment starts anywhere, x up to 192 bits, all-ones runs (carries that ripple through the whole wave), divisors
+    1, 2, 2^63, 2^64 - 1 -- against the serial recurrences on the host (tools/ubench/scan_par_test.hip, compiled here).
+    (2) Through the C-ABI against the oracle: limb chains longer than a bundle with the edge values in every position, tile
+    widths 1 and 2; accumulators / divisors that rule the parallel form out (acc >= d, d == 0, a divisor that changes inside a
+    chain, x beyond 192 bits) take the serial rounds in the same bundles."""
+    exe = tmp_path / "scan_par_test"
+    src = os.path.join(ROOT, "tools", "ubench", "scan_par_test.hip")
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "circom-witnesscalc_amd", "csrc"), src, "-o", str(exe)],
+                   check=True, timeout=600)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=300).stdout
+    assert "scan_par_test: ok" in out and "8000" not in out and out.count(" 0 carry mismatches, 0 division mismatches") == 2, out
+    rnd = random.Random(64)
+    B = 1 << 64
+    edge = [B - 1, B - 1, B - 1, 0, 1, B - 2, 1 << 63, (1 << 63) + 1]
+    for steps, chains in ((70, 1), (33, 2), (5, 3)):
+        data = C.build_limb_chains(64, 64, steps, chains, False, False).to_bin()
+        g = pkg.Graph(data)
+        n = g.n_inputs - 1
+        rows = [[1] + [B - 1] * n, [1] + [B - 1] * (n - chains) + [1] * chains, [1] + [0] * n]
+        for _ in range(20):
+            rows.append([1] + [rnd.choice(edge) if rnd.random() < 0.7 else rnd.randrange(B) for _ in range(n)])
+        for _ in range(8):   # wide x / accumulators: 128 .. 192 bits and beyond (the serial 256-bit rounds)
+            rows.append([1] + [rnd.randrange(1 << rnd.choice([64, 128, 191, 192, 200, 253])) for _ in range(n)])
+        _check(pkg, data, rows, tiles=(1, 2))
+    # the bigint-class graph on limbs that are all ones / all zero / edge values (columns of 2^133, carries through every position)
+    data = C.build_bigint_class(k=16, rounds=6).to_bin()
+    g = pkg.Graph(data)
+    n = g.n_inputs - 1
+    rows = [[1] + [B - 1] * n, [1] + [0] * n, [1] + [B - 1] * (n - 1) + [0], [1] + [1] * n] + [[1] + [rnd.choice(edge) for _ in range(n)] for _ in range(12)]
+    _check(pkg, data, rows, tiles=(1, 2))
+
+
 @pytest.mark.timeout(900)
 def test_config5_named_size_ten_million_nodes_all_sets(pkg):
     """BASELINE config 5 at its NAMED size: the 10.5 M-node bigint / long_div-class graph (32 limbs x 4000 rounds), the

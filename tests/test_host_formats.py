@@ -302,6 +302,98 @@ def scan_rows(rnd, n_inputs, n_rows):
     return rows
 
 
+def test_parallel_scan_algorithms_on_plain_integers():
+    """The parallel forms of the scan recurrences (csrc/scan_gfx950.hpp scan_carry_parallel / scan_div_parallel) restated on
+    plain integers, pair by pair, against the serial recurrences: the three-word column sums, the two local carry rounds, the
+    lookahead as ONE integer addition over gate and generate / propagate bits (two bits per pair), the carry leaving a
+    position; the segmented prefix of the maps r -> (r m + v) mod d and the quotient digits.  Random segment starts, all-ones
+    runs, x up to 192 bits, divisors 1, 2, 2^63, 2^64 - 1."""
+    B = 1 << 64
+
+    def serial_carry(xs, starts, a0s):
+        limb, carry, c = [], [], 0
+        for p, x in enumerate(xs):
+            t = x + (a0s[p] if starts[p] else c)
+            limb.append(t % B)
+            c = t // B
+            carry.append(c)
+        return limb, carry
+
+    def par_carry(xs, starts, a0s):
+        L = len(xs)
+        xp = [xs[p] + (a0s[p] if starts[p] else 0) for p in range(L)]
+        x0, x1, x2 = [v % B for v in xp], [(v >> 64) % B for v in xp], [v >> 128 for v in xp]
+        prev = lambda a: [0 if starts[p] else v for p, v in enumerate([0] + a[:-1])]   # the previous pair's value, nothing at a segment's start
+        y1, y2a = prev(x1), prev(x2)
+        y2 = prev(y2a)
+        s = [x0[p] + y1[p] + y2[p] for p in range(L)]
+        lo, ov = [v % B for v in s], [v // B for v in s]
+        u = [a + c for a, c in zip(lo, prev(ov))]
+        lo2, w = [v % B for v in u], [v // B for v in u]
+        z = [a + c for a, c in zip(lo2, prev(w))]
+        gen, zz = [v >= B for v in z], [v % B for v in z]
+        prop = [v == B - 1 for v in zz]
+        a = b = 0
+        for p in range(L):
+            a |= (0 if starts[p] else 1) << (2 * p) | (1 if gen[p] or prop[p] else 0) << (2 * p + 1)
+            b |= (1 if gen[p] else 0) << (2 * p + 1)
+        cbits = (a + b) ^ a ^ b
+        cin = [(cbits >> (2 * p + 1)) & 1 for p in range(L)]
+        limb = [(zz[p] + cin[p]) % B for p in range(L)]
+        cout = [1 if gen[p] or (prop[p] and cin[p]) else 0 for p in range(L)]
+        return limb, [x1[p] + x2[p] * B + y2a[p] + ov[p] + w[p] + cout[p] for p in range(L)]
+
+    def serial_div(xs, starts, a0s, ds):
+        q, r, rem = [], [], 0
+        for p, x in enumerate(xs):
+            t = (a0s[p] if starts[p] else rem) * B + x
+            q.append(t // ds[p])
+            rem = t % ds[p]
+            r.append(rem)
+        return q, r
+
+    def par_div(xs, starts, a0s, ds):
+        L = len(xs)
+        m = [0 if starts[p] else B % ds[p] for p in range(L)]
+        v = [((a0s[p] if starts[p] else 0) * B + xs[p]) % ds[p] for p in range(L)]
+        f = list(starts)
+        delta = 1
+        while delta < L:
+            m2, v2, f2 = m[:], v[:], f[:]
+            for p in range(delta, L):
+                if not f[p]:
+                    v2[p] = (v[p - delta] * m[p] + v[p]) % ds[p]
+                    m2[p] = (m[p - delta] * m[p]) % ds[p]
+                    f2[p] = f[p - delta]
+            m, v, f = m2, v2, f2
+            delta *= 2
+        rin = [a0s[p] if starts[p] else v[p - 1] for p in range(L)]
+        return [(rin[p] * B + xs[p]) // ds[p] for p in range(L)], v
+
+    rnd = random.Random(4)
+
+    def pick(bits):
+        k = rnd.random()
+        return (1 << bits) - 1 if k < 0.2 else 0 if k < 0.3 else ((1 << bits) - 1) ^ rnd.getrandbits(3) if k < 0.4 else rnd.getrandbits(bits)
+
+    for trial in range(1500):
+        L = rnd.choice([16, 32])
+        starts = [p == 0 or rnd.random() < 0.1 for p in range(L)]
+        bits = rnd.choice([64, 128, 133, 190])
+        xs = [B - 1] * L if rnd.random() < 0.3 else [pick(rnd.choice([64, bits])) for _ in range(L)]
+        a0s = [pick(rnd.choice([1, 64, 70, 190])) if starts[p] else None for p in range(L)]
+        if all(xs[p] + (a0s[p] or 0) < (1 << 192) for p in range(L)):
+            assert serial_carry(xs, starts, a0s) == par_carry(xs, starts, a0s)
+        ds, d = [], 1
+        for p in range(L):
+            if starts[p]:
+                d = rnd.choice([1, 2, 3, B - 1, B - 2, 1 << 63, (1 << 63) + 1, rnd.getrandbits(64) | 1, rnd.getrandbits(20) + 1])
+            ds.append(d)
+        xd = [pick(64) for _ in range(L)]
+        a0d = [rnd.randrange(ds[p]) if starts[p] else None for p in range(L)]
+        assert serial_div(xd, starts, a0d, ds) == par_div(xd, starts, a0d, ds)
+
+
 def test_scan_chains_are_exact(pkg):
     """Round 4: the steps of serial limb recurrences -- carry chains `t = x + c; limb = t % 2^n; c' = t \\ 2^n`, remainder
     chains `t = r * 2^k + x; q = t \\ d; r' = t % d` -- become pairs of N_SCAN nodes that the scheduler places in consecutive
