@@ -38,7 +38,7 @@ class ProgramStats(ctypes.Structure):
     _fields_ = [("tile_width", ctypes.c_uint32), ("divider", ctypes.c_uint32), ("streams", ctypes.c_uint32), ("n_classes", ctypes.c_uint32),
                 ("n_bundles", ctypes.c_uint64), ("n_fused_nodes", ctypes.c_uint64), ("class_bundles", ctypes.c_uint64 * 16),
                 ("class_nodes", ctypes.c_uint64 * 16), ("model_wave_cycles", ctypes.c_double), ("lanes_active_mean", ctypes.c_double),
-                ("values_per_bundle_mean", ctypes.c_double), ("chain_floor_cycles", ctypes.c_double), ("n_scan_steps", ctypes.c_uint64)]
+                ("values_per_bundle_mean", ctypes.c_double), ("chain_floor_cycles", ctypes.c_double), ("n_scan_steps", ctypes.c_uint64), ("n_conv_products", ctypes.c_uint64)]
 
 
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "SCAN"]
@@ -435,7 +435,7 @@ class Graph:
             raise WitnessCalcError("gwb_program_stats: no such program")
         n = ps.n_classes
         return {"tile_width": ps.tile_width, "divider": ps.divider, "streams": ps.streams, "n_bundles": ps.n_bundles,
-                "n_fused_nodes": ps.n_fused_nodes, "n_scan_steps": ps.n_scan_steps, "chain_floor_cycles": ps.chain_floor_cycles, "model_wave_cycles": ps.model_wave_cycles, "lanes_active_mean": ps.lanes_active_mean, "values_per_bundle_mean": ps.values_per_bundle_mean,
+                "n_fused_nodes": ps.n_fused_nodes, "n_scan_steps": ps.n_scan_steps, "n_conv_products": ps.n_conv_products, "chain_floor_cycles": ps.chain_floor_cycles, "model_wave_cycles": ps.model_wave_cycles, "lanes_active_mean": ps.lanes_active_mean, "values_per_bundle_mean": ps.values_per_bundle_mean,
                 "class_bundles": {CLASS_NAMES[c]: int(ps.class_bundles[c]) for c in range(n) if ps.class_bundles[c]},
                 "class_nodes": {CLASS_NAMES[c]: int(ps.class_nodes[c]) for c in range(n) if ps.class_nodes[c]}}
 

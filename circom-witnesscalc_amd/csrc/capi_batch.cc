@@ -686,6 +686,7 @@ int gwb_program_stats(gwb_graph_t* g, uint32_t program_key, gwb_program_stats_t*
         out->n_fused_nodes = p->stats.n_fused_nodes;
         out->chain_floor_cycles = (double)p->stats.chain_floor_cycles;
         out->n_scan_steps = p->stats.n_scan_steps;
+        out->n_conv_products = p->stats.n_conv_products;
         return 0;
     } catch (...) {
         return 1;

@@ -77,7 +77,7 @@ std::string program_cache_file(const void* graph_data, size_t len) {
     // and the kernels that give a program its meaning are compiled separately from this file --, the program format, the
     // cost model's cycle table: a program is chosen under one table)
     static const std::string build = []() {
-        const std::string id = std::string(CWC_TREE_HASH " format 17 table ") + std::to_string((unsigned long long)model_table_id());
+        const std::string id = std::string(CWC_TREE_HASH " format 18 table ") + std::to_string((unsigned long long)model_table_id());
         return sha256_hex((const uint8_t*)id.data(), id.size()).substr(0, 16);
     }();
     return dir + "/" + sha256_hex((const uint8_t*)graph_data, len) + "-" + build + ".cwcprog";

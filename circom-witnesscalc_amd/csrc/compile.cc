@@ -317,6 +317,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint32_t> scan_imm, scan_partner;
     if (T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_SCAN")) {
         detect_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
+        // schoolbook limb products: the column sums of a k x k block as one bundle (2k - 1 columns, one node slot each)
+        if (n_mul_cc && !getenv("CWC_NO_CONV")) detect_convolutions(g, node_rep, node_vflags, scan_imm, scan_partner, G, st.n_conv_products);
         N = g.nodes.size();
         phase("scan chains");
     }
@@ -343,7 +345,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 case C_IDIVMOD: return 1500;
                 case C_TERN: return 100;
                 case C_MULF: return 704.0 * (1 + (fused_op2(n.op) == FOP_MUL ? 1 : 0)) + 290.0 * ((fused_op2(n.op) > FOP_MUL ? 1 : 0) + (fused_op3(n.op) ? 1 : 0));
-                case C_SCAN: return (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry;
+                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry;
                 default: return 0;
             }
         };
@@ -506,7 +508,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         const bool ride_along = !getenv("CWC_NO_RIDE_ALONG");
         // Scan chains: a step is scheduled as a unit (its OUT node stands for both), consecutive steps of a chain go into
         // consecutive pairs of ONE bundle.  A bundle's steps share kind and shift: one ready heap per (kind, shift).
-        const bool has_scans = st.n_scan_steps != 0;
+        const bool has_scans = st.n_scan_steps != 0 || st.n_conv_products != 0;
+        static const uint32_t kConvKey = 512;        // the heap of convolution groups (a group is named by its column-0 node)
+        std::unordered_map<uint32_t, std::vector<uint32_t>> conv_members;  // column-0 node -> the group's nodes in column order
         std::vector<uint32_t> scan_keys;             // distinct (kind << 8 | shift)
         std::vector<uint32_t> scan_next;             // ACC node -> OUT node of the step that continues its chain
         auto scan_shift_of = [&](uint32_t i) -> uint32_t {
@@ -526,6 +530,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             scan_next.assign(N, 0xffffffffu);
             for (size_t i = 0; i < N; ++i) {
                 const Node& n = g.nodes[i];
+                if (n.kind == N_CONV) {
+                    if (scan_key_index(kConvKey) < 0) scan_keys.push_back(kConvKey);
+                    std::vector<uint32_t>& m = conv_members[scan_partner[i]];
+                    if (m.empty()) m.assign(2 * (scan_imm[i] >> 8) - 1, 0xffffffffu);
+                    m[scan_imm[i] & 0xffu] = (uint32_t)i;
+                    continue;
+                }
                 if (n.kind != N_SCAN || (n.op & SCAN_OP_ACC)) continue;
                 const uint32_t key = scan_key_of((uint32_t)i);
                 if (scan_key_index(key) < 0) scan_keys.push_back(key);
@@ -579,8 +590,20 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             std::vector<std::vector<Key>> heap(NH);
             std::vector<uint8_t> placed;  // scan nodes that sit in a bundle already (a step's successor inside its own bundle is released with it)
             if (has_scans) placed.assign(N, 0);
+            std::unordered_map<uint32_t, uint32_t> conv_ready;  // group -> how many of its nodes have their operands
             auto push = [&](uint32_t i) {
                 int hc = class_of(g.nodes[i]);
+                if (hc == C_SCAN && g.nodes[i].kind == N_CONV) {  // a group goes into ONE bundle, once the last of its factors is there
+                    const uint32_t head = scan_partner[i];
+                    const std::vector<uint32_t>& m = conv_members.find(head)->second;
+                    if (++conv_ready[head] < m.size()) return;
+                    uint64_t hgt = 0;
+                    for (uint32_t u : m) hgt = std::max(hgt, height[u]);
+                    auto& hs = heap[(int)C_SCAN + (int)C_COUNT * (17 + scan_key_index(kConvKey))];
+                    hs.push_back(Key(hgt + (prologue[head] ? kPrologueBoost : 0ull), tie_reverse ? head : ~head));
+                    std::push_heap(hs.begin(), hs.end());
+                    return;
+                }
                 if (hc == C_SCAN) {  // the step's OUT node stands for the pair
                     if ((g.nodes[i].op & SCAN_OP_ACC) || placed[i]) return;
                     auto& hs = heap[(int)C_SCAN + (int)C_COUNT * (17 + scan_key_index(scan_key_of(i)))];
@@ -692,7 +715,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 // A scan bundle costs its front end however few steps it runs, and a wave's time is the sum of its bundles: while the
                 // chain of the most urgent ready step goes on with steps whose other operands are not computed yet, anything else
                 // that is ready runs first (it has to run anyway), so that chains go into few, full bundles.
-                if (best % (int)C_COUNT == (int)C_SCAN && best >= (int)C_COUNT * 17 && !getenv("CWC_SCAN_EAGER")) {
+                const int conv_heap = scan_key_index(kConvKey) < 0 ? -1 : (int)C_SCAN + (int)C_COUNT * (17 + scan_key_index(kConvKey));
+                if (best % (int)C_COUNT == (int)C_SCAN && best >= (int)C_COUNT * 17 && best != conv_heap && !getenv("CWC_SCAN_EAGER")) {
                     const uint32_t head = tie_reverse ? heap[best].front().second : ~heap[best].front().second;
                     size_t len_ready = 1, len_all = 1;
                     bool contiguous = true;
@@ -714,6 +738,15 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 if (!heap[C_INPUT].empty()) best = C_INPUT;
                 picked.clear();
                 auto& h = heap[best];
+                if (best == conv_heap) {  // the columns of one limb product, position c = column c
+                    std::pop_heap(h.begin(), h.end());
+                    const uint32_t head = tie_reverse ? h.back().second : ~h.back().second;
+                    h.pop_back();
+                    picked = conv_members.find(head)->second;
+                    emit_bundle(picked, false, false);
+                    clock += 14 + 70;
+                    continue;
+                }
                 if (best % (int)C_COUNT == (int)C_SCAN && best >= (int)C_COUNT * 17) {
                     // the most urgent ready step and, pair after pair, the steps that continue its chain -- as far as every other
                     // operand of theirs was produced by an earlier bundle --, then the next ready chain of the same kind
@@ -872,7 +905,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         const uint32_t ra = find((uint32_t)i), rb = find(ops[q]);
                         if (ra != rb) parent[ra] = rb;
                     }
-                if (n.kind == N_SCAN) {  // the two nodes of a step sit in one bundle: one part (their operands may all be prologue values)
+                if (n.kind == N_SCAN || n.kind == N_CONV) {  // the two nodes of a step / the columns of a product sit in one bundle: one part (their operands may all be prologue values)
                     const uint32_t ra = find((uint32_t)i), rb = find(scan_partner[i]);
                     if (ra != rb) parent[ra] = rb;
                 }
@@ -1231,6 +1264,16 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     }
                     break;
                 }
+                case N_CONV:
+                    if (js != (scan_imm[i] & 0xffu)) {
+                        err = "internal error: convolution columns out of place";
+                        return false;
+                    }
+                    enc_operand(n.a, 0);
+                    enc_operand(n.b, 1);
+                    scan_bits = HDR_SCAN_CONV;
+                    scan_longest = scan_imm[i] >> 8;  // (k rounds)
+                    break;
                 case N_TRES:
                     enc_operand(n.a, 0);
                     enc_operand(n.b, 1);
@@ -1261,7 +1304,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         if (cl == C_SCAN) {
             lin_bits = scan_bits | ((scan_longest - 1u) << HDR_SCAN_ITER_SHIFT);
-            form_saved = kCycles[C_SCAN] - ((scan_bits & HDR_SCAN_DIV) ? kCyclesScanFrontDiv + (double)scan_longest * kCyclesScanStepDiv : kCyclesScanFront + (double)scan_longest * kCyclesScanStepCarry);
+            form_saved = kCycles[C_SCAN] - ((scan_bits & HDR_SCAN_CONV) ? kCyclesConvFront + (double)scan_longest * kCyclesConvStep : (scan_bits & HDR_SCAN_DIV) ? kCyclesScanFrontDiv + (double)scan_longest * kCyclesScanStepDiv : kCyclesScanFront + (double)scan_longest * kCyclesScanStepCarry);
         }
         if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {

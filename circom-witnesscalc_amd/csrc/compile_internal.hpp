@@ -28,6 +28,7 @@ inline int class_of(const Node& n) {
     switch (n.kind) {
         case N_FUSED: return C_MULF;
         case N_SCAN: return C_SCAN;
+        case N_CONV: return C_SCAN;
         case N_INPUT: return C_INPUT;
         case N_UNO: return C_LIN;
         case N_TRES: return C_TERN;
@@ -49,6 +50,7 @@ inline int class_of(const Node& n) {
 inline int arity_of(const Node& n) {
     if (n.kind == N_FUSED) return fused_sq(n.op) ? 1 + (fused_op2(n.op) ? 1 : 0) + (fused_op3(n.op) ? 1 : 0) : 3;
     if (n.kind == N_SCAN) return (n.op & SCAN_OP_DIV) ? 3 : 2;  // x, the accumulator coming in, the divisor
+    if (n.kind == N_CONV) return 2;                              // x_c, y_c
     return n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0;
 }
 
@@ -82,7 +84,7 @@ static inline uint64_t fused_cost50(uint8_t op) {
 // a step of a scan bundle: its share of the bundle's front end and one round of the loop (cycles / 50; kCyclesScan* below)
 static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 10u : 4u; }
 static inline uint64_t node_cost(const uint32_t* table, const Node& n) {
-    return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : cost_of(table, class_of(n));
+    return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : n.kind == N_CONV ? 70u : cost_of(table, class_of(n));  // (a convolution bundle: ~3.5 k cycles)
 }
 
 // ---- node forms (rewrite.cc infer_representations) ----
@@ -98,6 +100,9 @@ void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost)
 void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery,
                            bool allow_cc, uint64_t& n_cc, bool canonical_inputs);
 void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint64_t& n_steps);
+// scan_imm[column node] = column | k << 8, scan_partner[column node] = the node of column 0 (the group's name)
+void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint32_t max_columns,
+                         uint64_t& n_products);
 void fuse_narrow_chains(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, const uint32_t* class_cost, uint32_t slack_permille, bool two_stage_only,
                         uint64_t& n_fused);
 
@@ -115,6 +120,7 @@ static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 470
 static const double kCyclesMulCC = 760;  // a bundle of canonical limb products (HDR_MUL_CC)
 // (carry bundles of 32 rounds 6.3 k cycles, division bundles 17 k: 33 and 85 instructions per round on a lone wave, the
 // division bundle's reciprocal once per bundle)
+static const double kCyclesConvFront = 900, kCyclesConvStep = 85;  // a convolution bundle: k rounds of one 64 x 64 multiply-accumulate per lane
 static const double kCyclesScanFront = 1000, kCyclesScanFrontDiv = 2200, kCyclesScanStepCarry = 170, kCyclesScanStepDiv = 460;
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves

@@ -25,7 +25,12 @@ enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES
                           // detect_scans, class C_SCAN).  op = ScanOp bits: kind (carry chain / long division by one limb) and
                           // role (the step's OUT value: limb / quotient digit; its ACC value: carry / remainder).  Both nodes
                           // of a step name the same operands: a = x, b = the accumulator coming in, c = the divisor (DIV).
-                          N_SCAN = 6 };
+                          N_SCAN = 6,
+                          // compiler-internal, never in a file: one column sum_{i + j = c} x_i y_j of a schoolbook limb product
+                          // (rewrite.cc detect_convolutions; a bundle of class C_SCAN with HDR_SCAN_CONV holds the 2k - 1 columns
+                          // of one product).  a = x_c, b = y_c (c < k; the columns above name x_(k-1), y_(k-1)): every factor
+                          // is the operand of exactly one column node, the bundle reads them all.
+                          N_CONV = 7 };
 enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2 };
 
 // graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into

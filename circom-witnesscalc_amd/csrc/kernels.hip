@@ -733,6 +733,35 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             case C_SCAN: {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
                 r = fr_zero();
                 if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
+                    if (h & HDR_SCAN_CONV) {  // the columns of a k x k limb product (program_dev.h): out_c = sum_{i + j = c} x_i y_j; graph.rs:105, 110
+                        const uint32_t k = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
+                        const bool holds_y = active && lane < k * (uint32_t)T;  // (the columns k and above name a factor only to name one)
+                        if (!wave_any(active && (a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
+                            uint32_t col[5];
+                            conv_limb_columns<T>(k, lane, ((uint64_t)a_op.v[1] << 32) | a_op.v[0], holds_y ? (((uint64_t)b_op.v[1] << 32) | b_op.v[0]) : 0ull, col);
+#pragma unroll
+                            for (int w = 0; w < 5; ++w) r.v[w] = col[w];
+                        } else {  // factors of any size: the same rounds with field products (x_i into Montgomery form, times the canonical y) and field sums
+                            Fr yy = u256_select(holds_y, b_op, fr_zero());
+                            for (uint32_t i = 0; i < k; ++i) {
+                                Fr xi;
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) {
+                                    if constexpr (T == 1) {
+                                        xi.v[w] = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)i);
+                                    } else {
+                                        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)(2 * i)), o = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)(2 * i + 1));
+                                        xi.v[w] = (lane & 1u) ? o : e;
+                                    }
+                                }
+                                r = fr_add_wave(r, fr_mul_wave(fr_mul_wave(xi, fr_r2(), pv), yy, pv), pv);
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) yy.v[w] = wave_shr_lanes<T>(yy.v[w]);
+                            }
+                        }
+                        finish(r);
+                        continue;
+                    }
                     // lanes of a pair: the OUT record's lanes, then the ACC record's (T each); both compute the whole step
                     constexpr int QP_OUT = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x44 /* [0,1,0,1] */, QP_ACC = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xEE /* [2,3,2,3] */;
                     constexpr int D = 2 * T;  // lanes from a pair to the next

@@ -31,6 +31,7 @@ struct ProgramStats {
     uint64_t n_fused_nodes = 0;         // fused narrow chains made by the compiler (class C_MULF)
     uint64_t n_scan_steps = 0;          // steps of serial limb recurrences run inside scan bundles (class C_SCAN)
     uint64_t chain_floor_cycles = 0;    // the compiled graph's longest dependent chain at the best measured per-operation latency on a lone wave (no bundle overhead)
+    uint64_t n_conv_products = 0;       // limb products computed inside convolution bundles (rewrite.cc detect_convolutions)
     uint64_t depth_scan = 0;            // estimate of the dependency depth with such steps at a tenth of a level (what bounds the bundle count of a program with scan bundles)
 };
 

@@ -55,7 +55,9 @@ bool validate_program(const Program& p, std::string& err) {
         if (cls >= C_COUNT || (cls != C_SCAN && (h >> 19) != 0)) return bad("bundle " + std::to_string(b) + ": header");
         if (cls == C_SCAN) {  // pairs of record positions, an iteration count that covers the longest chain segment, a shift below 254
             const uint32_t iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u, sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu;
-            if (T > SCAN_MAX_T || (cnt & 1u) || cnt == 0 || iters > cnt / 2 || sh >= 254u || (h & 0x7f000u)) return bad("bundle " + std::to_string(b) + ": scan bundle");
+            if (h & HDR_SCAN_CONV) {  // the 2k - 1 columns of a k x k limb product
+                if (T > SCAN_MAX_T || cnt != 2 * iters - 1 || iters < 2 || sh != 0 || (h & 0x7e800u)) return bad("bundle " + std::to_string(b) + ": convolution bundle");
+            } else if (T > SCAN_MAX_T || (cnt & 1u) || cnt == 0 || iters > cnt / 2 || sh >= 254u || (h & 0x7f000u)) return bad("bundle " + std::to_string(b) + ": scan bundle");
         }
         // posts and waits are C_SYNC bundles without nodes: stream 0 posts once, every other stream waits in its first bundle
         // (nothing else is compiled)
@@ -94,7 +96,9 @@ bool validate_program(const Program& p, std::string& err) {
                 if ((q & 1u) ? (code == FOP_MUL || code > FOP_RSUB || (r[2] & ~CTRL_MASK) != trash_off) : code > FOP_RSUB) return bad("bundle " + std::to_string(b) + ": fused stage code");
                 if ((code == FOP_MUL && !(h & HDR_F_S2MUL)) || (code > FOP_MUL && !(h & ((q & 1u) ? HDR_F_S3LIN : HDR_F_S2LIN)))) return bad("bundle " + std::to_string(b) + ": fused stage bits");
             }
-            if (cls == C_SCAN && q < cnt) {  // position 2p: the step's OUT record, 2p + 1: its ACC record, same START bit; the first pair starts a chain
+            if (cls == C_SCAN && (h & HDR_SCAN_CONV)) {
+                if (q < cnt && ((r[2] & CTRL_SUB_MASK) || !(r[2] & CTRL_ACTIVE))) return bad("bundle " + std::to_string(b) + ": convolution record");
+            } else if (cls == C_SCAN && q < cnt) {  // position 2p: the step's OUT record, 2p + 1: its ACC record, same START bit; the first pair starts a chain
                 const uint32_t sub = r[2] & CTRL_SUB_MASK, sub0 = p.recs[((size_t)b * G + (q & ~1u)) * 4 + 2] & CTRL_SUB_MASK;
                 if ((sub & SCAN_ROLE_ACC) != (q & 1u) || (sub & ~(SCAN_ROLE_ACC | SCAN_START)) || ((sub ^ sub0) & SCAN_START) || (q < 2 && !(sub & SCAN_START)) || !(r[2] & CTRL_ACTIVE))
                     return bad("bundle " + std::to_string(b) + ": scan record");
@@ -150,7 +154,7 @@ void program_blob_write(const Program& p, uint8_t* dst) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 17;  // (17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
+    h.version = 18;  // (18: convolution bundles (C_SCAN with HDR_SCAN_CONV), one more statistics word.  17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -181,7 +185,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 17 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 18 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

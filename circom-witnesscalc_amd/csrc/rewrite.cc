@@ -510,6 +510,47 @@ void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint
     g.nodes.swap(out);
 }
 
+// Drops the nodes marked dead and renumbers everything that names a node: operands, the witness list, a DIV step's constant
+// 2^k (scan_imm), the partner / group node (scan_partner).
+static void compact_dead(Graph& g, const std::vector<uint8_t>& dead, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm,
+                         std::vector<uint32_t>& scan_partner) {
+    static const uint32_t NONE = 0xffffffffu;
+    const size_t N = g.nodes.size();
+    std::vector<uint32_t> pos(N, NONE);
+    std::vector<Node> kept;
+    std::vector<uint8_t> krep, kfl;
+    std::vector<uint32_t> kimm, kpart;
+    kept.reserve(N);
+    krep.reserve(N);
+    kfl.reserve(N);
+    kimm.reserve(N);
+    kpart.reserve(N);
+    for (size_t i = 0; i < N; ++i) {
+        if (dead[i]) continue;
+        Node n = g.nodes[i];
+        const int ar = arity_of(n);
+        if (ar >= 1) n.a = pos[n.a];
+        if (ar >= 2) n.b = pos[n.b];
+        if (ar >= 3) n.c = pos[n.c];
+        uint32_t imm = scan_imm[i];
+        if (n.kind == N_SCAN && (n.op & SCAN_OP_DIV)) imm = pos[imm];  // (the constant 2^k: a node index)
+        pos[i] = (uint32_t)kept.size();
+        kept.push_back(n);
+        krep.push_back(rep[i]);
+        kfl.push_back(vflags[i]);
+        kimm.push_back(imm);
+        kpart.push_back(scan_partner[i]);  // (old index: renumbered below, the partner may sit behind this node)
+    }
+    for (uint32_t& x : kpart)
+        if (x != NONE) x = pos[x];
+    for (uint32_t& w : g.witness_signals) w = pos[w];
+    g.nodes.swap(kept);
+    rep.swap(krep);
+    vflags.swap(kfl);
+    scan_imm.swap(kimm);
+    scan_partner.swap(kpart);
+}
+
 // ---- scan chains (round 4) ------------------------------------------------------------------------------------------
 // Limb-wise big-integer circuits (RSA / long_div-class: BASELINE config 5) are serial recurrences over canonical integers,
 // one step per limb: the carry chain of a multi-limb sum
@@ -665,40 +706,169 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
         scan_partner[st.acc] = st.out;
     }
     n_steps += steps.size();
-    // compact (the dead inner nodes would be scheduled)
-    std::vector<uint32_t> pos(N, NONE);
-    std::vector<Node> kept;
-    std::vector<uint8_t> krep, kfl;
-    std::vector<uint32_t> kimm, kpart;
-    kept.reserve(N);
-    krep.reserve(N);
-    kfl.reserve(N);
-    kimm.reserve(N);
-    kpart.reserve(N);
+    compact_dead(g, dead, rep, vflags, scan_imm, scan_partner);  // (the dead inner nodes would be scheduled)
+}
+
+// ---- limb products as convolutions (round 4) -----------------------------------------------------------------------------
+// A schoolbook product of two k-limb integers is k^2 limb products and, per column c, the sum of the products with
+// i + j = c: in the 10.5 M-node bigint-class graph 16 full bundles of canonical products and a tree of ~19 Add bundles per
+// round, a third of its time once the scan chains run in parallel.  Where the products of a complete k x k block are each
+// read once, by the Add tree of their column, and nothing else reads the trees' inner nodes, the 2k - 1 column sums become
+// N_CONV nodes (graph.hpp) that ONE bundle computes: lane c keeps y_c, x_i is broadcast round after round, the y's move up
+// the wave, every lane accumulates x_i y_(c-i) -- k multiply-accumulates per lane instead of k^2 products through memory.
+// Exact: the same products and sums in the field on canonical integers (graph.rs:105, 110), in another order.
+// Recognition: the leaves of every maximal single-use Add tree over canonical products; the products as edges between their
+// factors must form a complete bipartite graph X x Y with |X| = |Y| = k, X and Y disjoint, and the trees must be exactly its
+// anti-diagonals: with x_0 y_0 the lone product of a one-leaf tree, j(y) = leaves(tree of x_0 y) - 1 and i(x) likewise, every
+// leaf x y of a tree then has the same i(x) + j(y), and the 2k - 1 trees have distinct columns.
+void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner,
+                         uint32_t max_columns, uint64_t& n_products) {
+    const size_t N = g.nodes.size();
+    static const uint32_t NONE = 0xffffffffu;
+    if (scan_imm.size() != N) scan_imm.assign(N, 0);
+    if (scan_partner.size() != N) scan_partner.assign(N, NONE);
+    std::vector<uint32_t> uses(N, 0), user(N, NONE);
     for (size_t i = 0; i < N; ++i) {
-        if (dead[i]) continue;
-        Node n = g.nodes[i];
-        const int ar = arity_of(n);
-        if (ar >= 1) n.a = pos[n.a];
-        if (ar >= 2) n.b = pos[n.b];
-        if (ar >= 3) n.c = pos[n.c];
-        uint32_t imm = scan_imm[i];
-        if (n.kind == N_SCAN && (n.op & SCAN_OP_DIV)) imm = pos[imm];  // (the constant 2^k: a node index)
-        pos[i] = (uint32_t)kept.size();
-        kept.push_back(n);
-        krep.push_back(rep[i]);
-        kfl.push_back(vflags[i]);
-        kimm.push_back(imm);
-        kpart.push_back(scan_partner[i]);  // (old index: renumbered below, the partner may sit behind this node)
+        const Node& n = g.nodes[i];
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) {
+            uses[ops[q]]++;
+            user[ops[q]] = (uint32_t)i;
+        }
     }
-    for (uint32_t& x : kpart)
-        if (x != NONE) x = pos[x];
-    for (uint32_t& w : g.witness_signals) w = pos[w];
-    g.nodes.swap(kept);
-    rep.swap(krep);
-    vflags.swap(kfl);
-    scan_imm.swap(kimm);
-    scan_partner.swap(kpart);
+    for (uint32_t w : g.witness_signals) uses[w] += 2;  // (a witness element is never an inner node)
+    auto is_product = [&](uint32_t i) {
+        const Node& n = g.nodes[i];
+        return n.kind == N_DUO && n.op == OP_MUL && (vflags[i] & VF_MUL_CC) && rep[i] == REP_C && g.nodes[n.a].kind != N_CONST && g.nodes[n.b].kind != N_CONST && n.a != n.b;
+    };
+    auto is_sum = [&](uint32_t i) {
+        const Node& n = g.nodes[i];
+        return n.kind == N_DUO && n.op == OP_ADD && rep[i] == REP_C;  // (a sum of two canonical values: infer_representations gives a linear node's operands its own form)
+    };
+    // the tree above every product / sum: a node is inner while it is read once, by a sum
+    auto inner = [&](uint32_t i) { return uses[i] == 1 && user[i] != NONE && is_sum(user[i]); };
+    auto find_root = [&](uint32_t i) -> uint32_t {  // (the height reduction keeps sum trees shallow; a tree deeper than this is left alone)
+        for (int depth = 0; inner(i); ++depth) {
+            if (depth > 96) return NONE;
+            i = user[i];
+        }
+        return i;
+    };
+    std::vector<uint32_t> root_of(N, NONE);  // product -> the root of its tree (itself: a lone product)
+    std::vector<uint32_t> leaves(N, 0);      // root -> number of products below it; NONE: the tree has another kind of leaf
+    for (size_t i = 0; i < N; ++i) {
+        const uint32_t u = (uint32_t)i;
+        if (is_product(u)) {
+            root_of[u] = find_root(u);
+            if (root_of[u] != NONE && leaves[root_of[u]] != NONE) leaves[root_of[u]]++;
+        } else if (is_sum(u)) {
+            const Node& n = g.nodes[u];
+            bool clean = n.a != n.b;
+            for (uint32_t o : {n.a, n.b}) clean = clean && (is_product(o) || is_sum(o)) && inner(o);
+            if (!clean) {
+                const uint32_t r = find_root(u);
+                if (r != NONE) leaves[r] = NONE;
+            }
+        }
+    }
+    // factor -> its products
+    std::unordered_map<uint32_t, std::vector<uint32_t>> adj;
+    for (size_t i = 0; i < N; ++i)
+        if (is_product((uint32_t)i) && root_of[i] != NONE && leaves[root_of[i]] != NONE) {
+            adj[g.nodes[i].a].push_back((uint32_t)i);
+            adj[g.nodes[i].b].push_back((uint32_t)i);
+        }
+    auto other = [&](uint32_t prod, uint32_t f) { return g.nodes[prod].a == f ? g.nodes[prod].b : g.nodes[prod].a; };
+    std::vector<uint8_t> dead(N, 0), taken(N, 0);
+    bool any = false;
+    const bool debug = getenv("CWC_DEBUG_CONV") != nullptr;
+    if (debug) {
+        size_t np = 0, nroot = 0, nclean = 0, nseed = 0, ncc = 0, nmul = 0;
+        for (size_t i = 0; i < N; ++i) {
+            nmul += g.nodes[i].kind == N_DUO && g.nodes[i].op == OP_MUL;
+            ncc += g.nodes[i].kind == N_DUO && g.nodes[i].op == OP_MUL && (vflags[i] & VF_MUL_CC);
+            if (!is_product((uint32_t)i)) continue;
+            ++np;
+            nroot += root_of[i] != NONE;
+            nclean += root_of[i] != NONE && leaves[root_of[i]] != NONE;
+            nseed += root_of[i] == i && leaves[i] == 1;
+        }
+        fprintf(stderr, "convolution detection: %zu Mul nodes, %zu canonical, %zu candidate products, %zu with a root, %zu in clean trees, %zu lone\n", nmul, ncc, np, nroot, nclean, nseed);
+    }
+    for (size_t s0 = 0; s0 < N; ++s0) {
+        // seed: a lone product that is its own root (column 0)
+        const uint32_t seed = (uint32_t)s0;
+        if (root_of[seed] != seed || leaves[seed] != 1 || taken[seed]) continue;
+        for (int flip = 0; flip < 2; ++flip) {
+            const uint32_t x0 = flip ? g.nodes[seed].b : g.nodes[seed].a, y0 = other(seed, x0);
+            const std::vector<uint32_t>&px = adj[x0], &py = adj[y0];  // x_0 y for every y; x y_0 for every x
+            const size_t k = px.size();
+            if (debug) fprintf(stderr, "  seed %u: x0 in %zu products, y0 in %zu\n", seed, px.size(), py.size());
+            if (k < 2 || k > 32 || py.size() != k || 2 * k - 1 > max_columns) continue;
+            // indices from the sizes of the trees
+            std::vector<uint32_t> X(k, NONE), Y(k, NONE);
+            std::unordered_map<uint32_t, uint32_t> ix, jy;
+            bool ok = true;
+            for (uint32_t p : px) {
+                const uint32_t y = other(p, x0), r = root_of[p];
+                const uint32_t j = leaves[r] == NONE ? NONE : leaves[r] - 1;
+                if (j >= k || Y[j] != NONE || taken[p]) { ok = false; break; }
+                Y[j] = y;
+                jy[y] = j;
+            }
+            for (uint32_t p : py) {
+                if (!ok) break;
+                const uint32_t x = other(p, y0), r = root_of[p];
+                const uint32_t i = leaves[r] == NONE ? NONE : leaves[r] - 1;
+                if (i >= k || X[i] != NONE || taken[p]) { ok = false; break; }
+                X[i] = x;
+                ix[x] = i;
+            }
+            if (!ok || X[0] != x0 || Y[0] != y0) continue;
+            for (uint32_t x : X) ok = ok && !jy.count(x);  // disjoint
+            // every x has exactly the products x y_j, each in the tree of column i + j, each tree exactly one anti-diagonal
+            std::vector<uint32_t> col_root(2 * k - 1, NONE);
+            std::vector<uint32_t> prods;
+            for (size_t i = 0; i < k && ok; ++i) {
+                const std::vector<uint32_t>& pa = adj[X[i]];
+                if (pa.size() != k) { ok = false; break; }
+                std::vector<uint8_t> seen(k, 0);
+                for (uint32_t p : pa) {
+                    auto it = jy.find(other(p, X[i]));
+                    if (it == jy.end() || seen[it->second] || taken[p]) { ok = false; break; }
+                    seen[it->second] = 1;
+                    const uint32_t c = (uint32_t)i + it->second, r = root_of[p];
+                    const uint32_t want = (uint32_t)std::min<size_t>(c, 2 * k - 2 - c) + 1;
+                    if (leaves[r] != want || (col_root[c] != NONE && col_root[c] != r)) { ok = false; break; }
+                    col_root[c] = r;
+                    prods.push_back(p);
+                }
+            }
+            for (size_t j = 0; j < k && ok; ++j) ok = adj[Y[j]].size() == k;
+            for (size_t c = 0; c < 2 * k - 1 && ok; ++c)
+                for (size_t c2 = 0; c2 < c && ok; ++c2) ok = col_root[c] != col_root[c2];
+            if (!ok) continue;
+            // rewrite: the roots become the column nodes, everything below them dies
+            for (uint32_t p : prods) {
+                taken[p] = 1;
+                for (uint32_t i = p; i != root_of[p]; i = user[i]) dead[i] = 1;
+            }
+            for (size_t c = 0; c < 2 * k - 1; ++c) {
+                const uint32_t r = col_root[c];
+                dead[r] = 0;
+                taken[r] = 1;
+                g.nodes[r] = Node{N_CONV, 0, c < k ? X[c] : X[k - 1], c < k ? Y[c] : Y[k - 1], 0};
+                rep[r] = REP_C;
+                vflags[r] = 0;
+                scan_imm[r] = (uint32_t)c | ((uint32_t)k << 8);
+                scan_partner[r] = col_root[0];
+            }
+            n_products += k * k;
+            any = true;
+            break;
+        }
+    }
+    if (any) compact_dead(g, dead, rep, vflags, scan_imm, scan_partner);
 }
 
 // ---- fused narrow chains (round 3) --------------------------------------------------------------------------------

@@ -149,4 +149,44 @@ __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32
     rem = v;
 }
 
+// Convolution bundles (HDR_SCAN_CONV): the columns of a k x k limb product, x, y < 2^64.  Lane c of set t (lane = c T + t) holds
+// x_c and y_c (y = 0 in the lanes of the columns k and above).  Round i: x_i is read out of its lane, every lane adds
+// x_i * (the y it holds) to its 192-bit sum, the y's move one column up the wave: lane c meets y_(c-i) in round i, zero when
+// c - i is outside [0, k).
+template <int T>
+__device__ __forceinline__ void conv_limb_columns(uint32_t k, uint32_t lane, uint64_t x, uint64_t y, uint32_t (&out)[5]) {
+    uint64_t a0 = 0, a1 = 0;
+    uint32_t a2 = 0;
+    uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+    for (uint32_t i = 0; i < k; ++i) {
+        uint32_t b0, b1;
+        if constexpr (T == 1) {
+            b0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)i);
+            b1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, (int)i);
+        } else {
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)(2 * i)), e1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, (int)(2 * i));
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)(2 * i + 1)), o1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, (int)(2 * i + 1));
+            b0 = (lane & 1u) ? o0 : e0;
+            b1 = (lane & 1u) ? o1 : e1;
+        }
+        const uint64_t xi = ((uint64_t)b1 << 32) | b0, yy = ((uint64_t)y1 << 32) | y0;
+        const uint64_t lo = xi * yy, hi = mulhi64(xi, yy);
+        a0 += lo;
+        const uint64_t c0 = a0 < lo ? 1ull : 0ull;
+        a1 += hi;
+        uint32_t c1 = a1 < hi ? 1u : 0u;
+        a1 += c0;
+        c1 += a1 < c0 ? 1u : 0u;
+        a2 += c1;
+        y0 = wave_shr_lanes<T>(y0);
+        y1 = wave_shr_lanes<T>(y1);
+    }
+    out[0] = (uint32_t)a0;
+    out[1] = (uint32_t)(a0 >> 32);
+    out[2] = (uint32_t)a1;
+    out[3] = (uint32_t)(a1 >> 32);
+    out[4] = a2;
+}
+
 }  // namespace cwc

@@ -217,6 +217,7 @@ typedef struct {
   double chain_floor_cycles;    /* the compiled graph's longest dependent chain priced at the best measured latency of each operation on a
                                  * lone wavefront, arithmetic only (no bundle front end): the floor of this execution model for one tile */
   uint64_t n_scan_steps;        /* steps of serial limb recurrences that run inside scan bundles */
+  uint64_t n_conv_products;     /* limb products computed inside convolution bundles (the columns of a k x k schoolbook product in one bundle) */
 } gwb_program_stats_t;
 int gwb_program_stats(gwb_graph_t *g, uint32_t program_key, gwb_program_stats_t *out);
 

@@ -21,7 +21,7 @@ SUB_NAMES = {"LIN": ["Add", "Sub"], "CMPZ": ["Eq", "Neq", "Land", "Lor"], "CMPS"
              "MULQ": ["Add", "Sub", "Mul"]}
 R_MONT = (1 << 256) % model.M
 R_INV = pow(R_MONT, -1, model.M)
-HDR_FMT = "<12I12I6I12d51Q"
+HDR_FMT = "<12I12I6I12d52Q"
 HDR_POST, HDR_WAIT = 1 << 15, 1 << 16
 HDR_SIZE = struct.calcsize(HDR_FMT)
 CLASS_NAMES = ["INPUT", "MUL", "LIN", "DIV", "CMPZ", "CMPS", "BIT", "IDIVMOD", "TERN", "DIVREQ", "DIVGET", "MULQ", "SYNC", "MULF", "SCAN"]
@@ -34,7 +34,7 @@ COOP_LANES, COOP_MAX_T = 4, 4
 # kind (0 carry chain, 1 long division by one limb), bits 19-26 the shift, bits 27-31 iterations - 1; sub-op bit 0 role, bit 1 START
 HDR_MUL_CC = 1 << 13
 OFF_NOWHERE = 0xFFFF0000
-SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_ACC, SCAN_START = 2, 1 << 11, 19, 27, 1, 2
+SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_CONV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_ACC, SCAN_START = 2, 1 << 11, 1 << 12, 19, 27, 1, 2
 
 
 def blob_checksum(body):
@@ -66,7 +66,7 @@ class Blob:
         st = h[42:]
         c0, c1, c2 = 6, 6 + N_CLASSES, 6 + 2 * N_CLASSES
         self.stats = dict(n_nodes=st[0], n_op=st[1], n_input_nodes=st[2], n_const=st[3], n_witness=st[4], depth=st[5],
-                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12], chain_floor_cycles=st[c2 + 13], depth_scan=st[c2 + 14])
+                          class_nodes=st[c0:c1], class_bundles=st[c1:c2], n_op_compiled=st[c2], n_bitx_bundles=st[c2 + 1], n_bitx_nodes=st[c2 + 2], algorithmic_bytes_per_set=st[c2 + 3], n_coop_rider_bundles=st[c2 + 4], n_conversions=st[c2 + 5], n_canonical=st[c2 + 6], form_cycles_saved=st[c2 + 7], n_folded=st[c2 + 8], n_numbered=st[c2 + 9], n_shaken=st[c2 + 10], n_fused_nodes=st[c2 + 11], n_scan_steps=st[c2 + 12], chain_floor_cycles=st[c2 + 13], n_conv_products=st[c2 + 14], depth_scan=st[c2 + 15])
         assert self.magic == 0x47505743 and self.G == 64 // self.T
         pos = HDR_SIZE
 
@@ -190,11 +190,27 @@ def run(blob: Blob, inputs_row):
             # The steps of serial limb recurrences in consecutive pairs of positions, chain segments one behind the other: a
             # step takes the accumulator of the pair in front of it unless its START bit says "my own operand".  All values
             # are canonical integers; the arithmetic is the unfused nodes' (x + acc, Band / Shr; acc * 2^k + x, Idiv / Mod).
-            assert T <= SCAN_MAX_T and cnt % 2 == 0 and blob.stats["class_bundles"][CLASS_NAMES.index("MULF")] == 0 and (h & 0x7F000) == 0
             is_div, sh, iters = bool(h & HDR_SCAN_DIV), (h >> HDR_SCAN_SHIFT_SHIFT) & 0xFF, (h >> HDR_SCAN_ITER_SHIFT) + 1
-            assert sh < 254
+            is_conv = bool(h & HDR_SCAN_CONV)
+            assert T <= SCAN_MAX_T and blob.stats["class_bundles"][CLASS_NAMES.index("MULF")] == 0
+            if is_conv:
+                # The 2k - 1 columns of a k x k limb product: position c names x_c and y_c (c < k), its result is the sum of
+                # x_i y_j with i + j = c, in the field on canonical integers (the unfused Mul / Add nodes' arithmetic).
+                k = iters
+                assert cnt == 2 * k - 1 and k >= 2 and sh == 0 and not is_div and (h & 0x7E800) == 0
+                xs, ys, dsts = [], [], []
+                for c in range(cnt):
+                    r_ = blob.recs[(b * G + c) * 4:(b * G + c) * 4 + 4]
+                    assert (r_[2] & CTRL_MASK) == CTRL_ACTIVE
+                    xs.append(fetch(r_[0], r_[3] & 0xFFFF, 0, c))
+                    ys.append(fetch(r_[1], r_[3] >> 16, 1, c))
+                    dsts.append(r_[2] & ~CTRL_MASK)
+                assert all(v < model.M for v in xs + ys)
+                for c in range(cnt):
+                    results.append((dsts[c], sum(xs[i] * ys[c - i] for i in range(k) if 0 <= c - i < k) % model.M))
+            assert is_conv or (cnt % 2 == 0 and (h & 0x7F000) == 0 and sh < 254)
             acc, seg, longest = None, 0, 0
-            for pr in range(cnt // 2):
+            for pr in range(0 if is_conv else cnt // 2):
                 ro = blob.recs[(b * G + 2 * pr) * 4:(b * G + 2 * pr) * 4 + 4]
                 ra = blob.recs[(b * G + 2 * pr + 1) * 4:(b * G + 2 * pr + 1) * 4 + 4]
                 co, ca = ro[2] & CTRL_MASK, ra[2] & CTRL_MASK
@@ -218,7 +234,7 @@ def run(blob: Blob, inputs_row):
                     out, acc = t & ((1 << sh) - 1), t >> sh
                 results.append((ro[2] & ~CTRL_MASK, out))
                 results.append((ra[2] & ~CTRL_MASK, acc))
-            assert iters == longest, "the iteration count is the longest chain segment"
+            assert is_conv or iters == longest, "the iteration count is the longest chain segment"
             for pos in range(cnt, G):
                 a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
                 assert not (dctl & CTRL_ACTIVE) and (dctl & ~CTRL_MASK) == trash and a_off == zero_off and b_off == zero_off

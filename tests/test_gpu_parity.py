@@ -619,6 +619,25 @@ def test_parallel_scan_forms(pkg, tmp_path):
     _check(pkg, data, rows, tiles=(1, 2))
 
 
+def test_convolution_bundles_on_the_gpu(pkg):
+    """Round 4: the column sums of a k x k schoolbook limb product as ONE bundle (rewrite.cc detect_convolutions, class SCAN with
+    HDR_SCAN_CONV: lane c accumulates x_i y_(c-i) while the y's move up the wave).  Bigint-class graphs with k = 2 .. 32 limbs of
+    32 / 64 bits (the 64 x 64 multiply-accumulate rounds), of 100 bits (factors beyond a limb: the field-arithmetic rounds) and
+    of 130 bits (products that wrap around r), tile widths 1 and 2 where 2k - 1 columns fit; all-ones limbs (column sums of
+    2^133), zeros, uniform field elements as inputs; against the oracle."""
+    rnd = random.Random(33)
+    from test_host_formats import scan_rows
+    B = 1 << 64
+    for k, rounds, nb, tiles in ((32, 2, 64, (1,)), (16, 3, 64, (1, 2)), (8, 3, 100, (1, 2)), (5, 2, 130, (1, 2)), (3, 2, 32, (1, 2, 4)), (2, 3, 64, (1, 2))):
+        data = C.build_bigint_class(k=k, rounds=rounds, n_bits=nb).to_bin()
+        g = pkg.Graph(data)
+        n = g.n_inputs - 1
+        rows = [[1] + [M - 1] * n, [1] + [0] * n, [1] + [B - 1] * n, [1] + [(1 << nb) - 1] * n] + scan_rows(rnd, g.n_inputs, 36)
+        g = _check(pkg, data, rows, tiles=tiles)
+        st = g.program_stats(tiles[0])
+        assert st["n_conv_products"] == k * k * rounds, (k, st["n_conv_products"])
+
+
 @pytest.mark.timeout(900)
 def test_config5_named_size_ten_million_nodes_all_sets(pkg):
     """BASELINE config 5 at its NAMED size: the 10.5 M-node bigint / long_div-class graph (32 limbs x 4000 rounds), the
@@ -648,7 +667,8 @@ def test_config5_named_size_ten_million_nodes_all_sets(pkg):
     assert np.array_equal(st != 0, wst != 0)
     assert np.array_equal(got[wst == 0], want[wst == 0])
     tm = g.last_timing()
-    assert tm["n_bundles"] > 100000 and g.depth > 1000000
+    assert tm["n_bundles"] > 40000 and g.depth > 1000000
+    assert g.program_stats(key)["n_conv_products"] == 32 * 32 * 4000 and g.program_stats(key)["n_scan_steps"] > 4000 * 120
 
 
 # BabyJubjub in twisted Edwards form a x^2 + y^2 = 1 + d x^2 y^2 (a = 168700, d = 168696), independent of the generator's

@@ -302,6 +302,54 @@ def scan_rows(rnd, n_inputs, n_rows):
     return rows
 
 
+def test_convolution_columns_are_exact(pkg):
+    """Round 4: the column sums of a k x k schoolbook limb product -- k^2 canonical products each read once by the Add tree of
+    its column -- become 2k - 1 N_CONV nodes that ONE bundle computes (rewrite.cc detect_convolutions; class SCAN with
+    HDR_SCAN_CONV).  The emulator runs the compiled programs of bigint-class graphs on the stored words: k = 2 .. 32 limbs, limb
+    widths 32 / 64 / 100 / 130 bits, tile widths 1 and 2 (32 limbs fit tile width 1 only: 63 columns), inputs of every size;
+    the programs hold no multiplication bundle any more, and a block whose products something else reads stays as it is."""
+    rnd = random.Random(3)
+    for k, rounds, nb in ((8, 3, 64), (4, 2, 64), (16, 2, 64), (32, 1, 64), (8, 2, 100), (5, 2, 130), (3, 2, 32), (2, 3, 64)):
+        b = C.build_bigint_class(k=k, rounds=rounds, n_bits=nb)
+        data = b.to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        g = pkg.Graph(data)
+        for key in (1, 2):
+            blob = pe.Blob(g.export_blob(key))
+            fits = 2 * k - 1 <= 64 // key
+            assert blob.stats["n_conv_products"] == (k * k * rounds if fits else 0), (k, key)
+            assert (blob.stats["class_bundles"][1] == 0) == fits, "the limb products left the multiplication bundles"
+            for row in scan_rows(rnd, blob.n_inputs, 2 if k > 8 else 3):
+                got, st = pe.run(blob, row)
+                assert st == 0 and got == model.evaluate(nodes, row, wit), (k, key)
+        assert pe.Blob(g.export_blob(4)).stats["n_conv_products"] == 0
+    # a product that a witness element names is no inner node: the block keeps its unfused nodes
+    b = cwc_import.load().graphgen.builder.Builder()
+    xs, ys = b.input("x", 3), b.input("y", 3)
+    m = b.const((1 << 64) - 1)
+    xs, ys = [b.op("Band", v, m) for v in xs], [b.op("Band", v, m) for v in ys]
+    cols = [None] * 5
+    for i in range(3):
+        for j in range(3):
+            pr = b.mul(xs[i], ys[j])
+            if i == 1 and j == 1:
+                b.signal(pr)
+            cols[i + j] = pr if cols[i + j] is None else b.add(cols[i + j], pr)
+    carry = b.const(0)
+    base = b.const(1 << 64)
+    for c in range(5):
+        t = b.add(cols[c], carry)
+        b.signal(b.op("Mod", t, base))
+        carry = b.signal(b.op("Idiv", t, base))
+    data = b.to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    blob = pe.Blob(pkg.Graph(data).export_blob(1))
+    assert blob.stats["n_conv_products"] == 0
+    for row in scan_rows(rnd, blob.n_inputs, 3):
+        got, st = pe.run(blob, row)
+        assert st == 0 and got == model.evaluate(nodes, row, wit)
+
+
 def test_parallel_scan_algorithms_on_plain_integers():
     """The parallel forms of the scan recurrences (csrc/scan_gfx950.hpp scan_carry_parallel / scan_div_parallel) restated on
     plain integers, pair by pair, against the serial recurrences: the three-word column sums, the two local carry rounds, the
