@@ -345,7 +345,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 case C_IDIVMOD: return 1500;
                 case C_TERN: return 100;
                 case C_MULF: return 704.0 * (1 + (fused_op2(n.op) == FOP_MUL ? 1 : 0)) + 290.0 * ((fused_op2(n.op) > FOP_MUL ? 1 : 0) + (fused_op3(n.op) ? 1 : 0));
-                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry;
+                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry;  // (the serial rounds; chains of 64-bit limbs beat this "floor" with the parallel forms)
                 default: return 0;
             }
         };
@@ -1304,7 +1304,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         }
         if (cl == C_SCAN) {
             lin_bits = scan_bits | ((scan_longest - 1u) << HDR_SCAN_ITER_SHIFT);
-            form_saved = kCycles[C_SCAN] - ((scan_bits & HDR_SCAN_CONV) ? kCyclesConvFront + (double)scan_longest * kCyclesConvStep : (scan_bits & HDR_SCAN_DIV) ? kCyclesScanFrontDiv + (double)scan_longest * kCyclesScanStepDiv : kCyclesScanFront + (double)scan_longest * kCyclesScanStepCarry);
+            const bool limbs64 = ((scan_bits >> HDR_SCAN_SHIFT_SHIFT) & 0xffu) == 64u && scan_longest > 2;  // (priced as the parallel forms: what limb-sized operands take)
+            uint32_t log_rounds = 0;
+            while ((1u << log_rounds) < scan_longest) ++log_rounds;
+            const double scan_cycles = (scan_bits & HDR_SCAN_CONV) ? kCyclesConvFront + (double)scan_longest * kCyclesConvStep
+                                       : (scan_bits & HDR_SCAN_DIV) ? kCyclesScanFrontDiv + (limbs64 ? kCyclesScanParDivFlat + log_rounds * kCyclesScanParDivRound : (double)scan_longest * kCyclesScanStepDiv)
+                                                                    : kCyclesScanFront + (limbs64 ? kCyclesScanParCarry : (double)scan_longest * kCyclesScanStepCarry);
+            form_saved = kCycles[C_SCAN] - scan_cycles;
         }
         if (cl == C_LIN || cl == C_MUL || cl == C_MULQ)
             for (uint32_t k = k0; k < k1; ++k) {

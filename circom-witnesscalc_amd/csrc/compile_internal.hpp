@@ -120,7 +120,9 @@ static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 470
 static const double kCyclesMulCC = 760;  // a bundle of canonical limb products (HDR_MUL_CC)
 // (carry bundles of 32 rounds 6.3 k cycles, division bundles 17 k: 33 and 85 instructions per round on a lone wave, the
 // division bundle's reciprocal once per bundle)
-static const double kCyclesConvFront = 900, kCyclesConvStep = 85;  // a convolution bundle: k rounds of one 64 x 64 multiply-accumulate per lane
+static const double kCyclesConvFront = 900, kCyclesConvStep = 175;  // a convolution bundle: k rounds of one 64 x 64 multiply-accumulate per lane (four quarter-rate v_mad_u64_u32, 27 instructions)
+// chains of 64-bit limbs run all segments of a bundle at once (scan_gfx950.hpp): a flat carry-lookahead; log2 rounds of two products modulo d
+static const double kCyclesScanParCarry = 700, kCyclesScanParDivRound = 900, kCyclesScanParDivFlat = 900;
 static const double kCyclesScanFront = 1000, kCyclesScanFrontDiv = 2200, kCyclesScanStepCarry = 170, kCyclesScanStepDiv = 460;
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves

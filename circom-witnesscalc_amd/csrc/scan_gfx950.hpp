@@ -115,9 +115,21 @@ __device__ __forceinline__ void scan_carry_parallel(bool st, uint32_t lane, cons
 // so an inclusive segmented prefix over the pairs (log2 rounds; a segment's first step takes its incoming remainder in: m = 0,
 // v = (acc B + x) mod d) leaves every step's outgoing remainder, and the quotient digit is one more two-by-one division of
 // (incoming remainder : x).  Products modulo d: a b < d^2 has its high word below d, the precondition of div2by1.
+// The two lanes of a pair hold the same values, so they share the work: a round's two products (v' needs pv m, m' needs pm m)
+// are ONE product per lane -- the OUT lane's for v, the ACC lane's for m -- exchanged inside the quad afterwards.
 template <int T>
 __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32_t rounds_cover, uint64_t dv, uint64_t x, uint64_t a0, uint64_t& quo, uint64_t& rem) {
     constexpr int D = 2 * T;
+    constexpr int QP_OUT = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x44 /* [0,1,0,1] */, QP_ACC = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xEE /* [2,3,2,3] */;
+    const bool acc_lane = ((lane / (uint32_t)T) & 1u) != 0;
+    auto from_out = [&](uint64_t v) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, QP_OUT, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), QP_OUT, 0xf, 0xf, false);
+        return ((uint64_t)hi << 32) | lo;
+    };
+    auto from_acc = [&](uint64_t v) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, QP_ACC, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), QP_ACC, 0xf, 0xf, false);
+        return ((uint64_t)hi << 32) | lo;
+    };
     const uint32_t s = clz64_nonzero(dv);
     const uint64_t dn = dv << s, rv = recip64(dn);
     auto divrem = [&](uint64_t hi, uint64_t lo, uint64_t& q) -> uint64_t {  // hi < dv
@@ -126,19 +138,21 @@ __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32
         return rn >> s;
     };
     uint64_t qd;
-    uint64_t m = st ? 0ull : divrem(0ull, 0ull - dv, qd);  // B mod d = (B - d) mod d
-    uint64_t v = divrem(st ? a0 : 0ull, x, qd);
+    // OUT lane: v = ((incoming remainder at a segment's start) B + x) mod d; ACC lane: m = B mod d = (B - d) mod d
+    const uint64_t t0 = divrem(acc_lane ? 0ull : (st ? a0 : 0ull), acc_lane ? 0ull - dv : x, qd);
+    const uint64_t t0v = from_out(t0), t0m = from_acc(t0);
+    uint64_t v = t0v, m = st ? 0ull : t0m;
     bool f = st;
     for (uint32_t dl = 1; dl < rounds_cover; dl <<= 1) {
         const int src = (int)((lane - dl * (uint32_t)D) << 2);
-        const uint64_t pm = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)m);
-        const uint64_t pv_ = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)v);
+        const uint64_t mine = acc_lane ? m : v;  // (the partner pair's lane of the same role holds the same v and m)
+        const uint64_t theirs = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(mine >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)mine);
         const bool pf = __builtin_amdgcn_ds_bpermute(src, f ? 1 : 0) != 0;
         // v' = (pv m + v) mod d, m' = (pm m) mod d
-        const uint64_t t1 = divrem(mulhi64(pv_, m), pv_ * m, qd);
+        const uint64_t t = divrem(mulhi64(theirs, m), theirs * m, qd);
+        const uint64_t t1 = from_out(t), nm = from_acc(t);
         uint64_t nv = t1 + v;
         nv -= (nv < t1 || nv >= dv) ? dv : 0ull;
-        const uint64_t nm = divrem(mulhi64(pm, m), pm * m, qd);
         v = f ? v : nv;
         m = f ? m : nm;
         f = f || pf;
@@ -170,8 +184,12 @@ __device__ __forceinline__ void conv_limb_columns(uint32_t k, uint32_t lane, uin
             b0 = (lane & 1u) ? o0 : e0;
             b1 = (lane & 1u) ? o1 : e1;
         }
-        const uint64_t xi = ((uint64_t)b1 << 32) | b0, yy = ((uint64_t)y1 << 32) | y0;
-        const uint64_t lo = xi * yy, hi = mulhi64(xi, yy);
+        // x_i * y as four 32 x 32 + 64 multiply-adds (v_mad_u64_u32, x_i's words in scalar registers)
+        const uint64_t p00 = (uint64_t)b0 * y0;
+        const uint64_t p01 = (uint64_t)b0 * y1 + (p00 >> 32);
+        const uint64_t p10 = (uint64_t)b1 * y0 + (uint32_t)p01;
+        const uint64_t hi = (uint64_t)b1 * y1 + ((p01 >> 32) + (p10 >> 32));
+        const uint64_t lo = (uint64_t)(uint32_t)p00 | (p10 << 32);
         a0 += lo;
         const uint64_t c0 = a0 < lo ? 1ull : 0ull;
         a1 += hi;

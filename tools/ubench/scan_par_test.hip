@@ -29,6 +29,18 @@ __global__ void run(const Case* c, Out* o, int n) {
     }
 }
 
+struct ConvCase { uint64_t x[64], y[64]; uint32_t k; };
+struct ConvOut { uint32_t col[64][5]; };
+template <int T>
+__global__ void run_conv(const ConvCase* c, ConvOut* o, int n) {
+    const uint32_t lane = threadIdx.x;
+    for (int i = 0; i < n; ++i) {
+        uint32_t col[5];
+        conv_limb_columns<T>(c[i].k, lane, c[i].x[lane], lane < c[i].k * T ? c[i].y[lane] : 0ull, col);
+        for (int w = 0; w < 5; ++w) o[i].col[lane][w] = col[w];
+    }
+}
+
 static uint64_t rnd64() { return ((uint64_t)rand() << 42) ^ ((uint64_t)rand() << 21) ^ (uint64_t)rand(); }
 static uint64_t pick64() {
     switch (rand() % 8) {
@@ -118,10 +130,58 @@ static int test(int n) {
     return bad_c + bad_d;
 }
 
+// the columns of k x k limb products (conv_limb_columns) against 128-bit host arithmetic
+template <int T>
+static int test_conv(int n) {
+    const int maxk = T == 1 ? 32 : 16;
+    std::vector<ConvCase> cs(n);
+    for (int i = 0; i < n; ++i) {
+        cs[i].k = 2 + rand() % (maxk - 1);
+        const int mode = rand() % 3;
+        for (int l = 0; l < 64; ++l) {
+            cs[i].x[l] = mode == 0 ? ~0ull : pick64();
+            cs[i].y[l] = mode == 0 ? ~0ull : pick64();  // (lanes of the columns k and above hold anything: the kernel side masks y)
+        }
+    }
+    ConvCase* dc; ConvOut* dout;
+    (void)hipMalloc(&dc, n * sizeof(ConvCase)); (void)hipMalloc(&dout, n * sizeof(ConvOut));
+    (void)hipMemcpy(dc, cs.data(), n * sizeof(ConvCase), hipMemcpyHostToDevice);
+    run_conv<T><<<1, 64>>>(dc, dout, n);
+    std::vector<ConvOut> os(n);
+    (void)hipMemcpy(os.data(), dout, n * sizeof(ConvOut), hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const int k = (int)cs[i].k;
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < 2 * k - 1; ++c) {
+                uint64_t w[3] = {0, 0, 0};  // 192-bit sum
+                for (int a = 0; a < k; ++a) {
+                    const int b = c - a;
+                    if (b < 0 || b >= k) continue;
+                    const u128 p = (u128)cs[i].x[a * T + t] * cs[i].y[b * T + t];
+                    u128 s = (u128)w[0] + (uint64_t)p;
+                    w[0] = (uint64_t)s;
+                    s = (u128)w[1] + (uint64_t)(p >> 64) + (uint64_t)(s >> 64);
+                    w[1] = (uint64_t)s;
+                    w[2] += (uint64_t)(s >> 64);
+                }
+                const uint32_t* g = os[i].col[c * T + t];
+                const bool ok = (((uint64_t)g[1] << 32) | g[0]) == w[0] && (((uint64_t)g[3] << 32) | g[2]) == w[1] && g[4] == (uint32_t)w[2];
+                if (!ok && bad++ < 5) printf("T=%d conv case %d k %d column %d: got %x %08x%08x %08x%08x want %llx %016llx %016llx\n", T, i, k, c, g[4], g[3], g[2], g[1], g[0],
+                                             (unsigned long long)w[2], (unsigned long long)w[1], (unsigned long long)w[0]);
+            }
+    }
+    printf("T=%d: %d limb products, %d column mismatches\n", T, n, bad);
+    (void)hipFree(dc); (void)hipFree(dout);
+    return bad;
+}
+
 int main() {
     srand(7);
     int bad = test<1>(4000);
     bad += test<2>(4000);
+    bad += test_conv<1>(1500);
+    bad += test_conv<2>(1500);
     printf(bad ? "FAILED\n" : "scan_par_test: ok\n");
     return bad != 0;
 }
