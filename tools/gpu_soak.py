@@ -30,8 +30,9 @@ def run(n_seeds, base, verbose=True):
     for s in range(n_seeds):
         kind = rnd.choice(KINDS)
         if kind == "limb":  # serial limb recurrences: what the compiler runs as scan bundles (tile widths 1 and 2), every shift / base width
-            if rnd.random() < 0.15:
-                b = C.build_bigint_class(k=rnd.randrange(2, 12), rounds=rnd.randrange(1, 5))
+            if rnd.random() < 0.25:  # (schoolbook limb products: convolution bundles where 2k - 1 columns fit the tile width's node slots)
+                b = C.build_bigint_class(k=rnd.choice([2, 3, 5, 8, 11, 16, 17, 24, 32, rnd.randrange(2, 33)]), rounds=rnd.randrange(1, 4),
+                                         n_bits=rnd.choice([64, 64, 64, 16, 32, 63, 65, 100, 126]))
             else:
                 b = C.build_limb_chains(rnd.choice([1, 31, 32, 33, 63, 64, 65, 100, 121, 127, 128, 129, 200, 253, rnd.randrange(1, 254)]),
                                         rnd.choice([1, 17, 32, 63, 64, 65, 121, 128, 253, rnd.randrange(1, 254)]), rnd.randrange(1, 80), rnd.randrange(1, 4),
