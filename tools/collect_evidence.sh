@@ -29,6 +29,7 @@ python tools/gpu_sweep.py > $O/sweep_$R.log 2>&1
 python tools/gpu_autopick.py > $O/autopick_$R.log 2>&1
 python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
 (cd tools/ubench && ./coop_mul) > $O/coop_mul_$R.log 2>&1
+(cd tools/ubench && timeout 120 ./scan_par_test) > $O/scan_par_$R.log 2>&1
 (cd tools/ubench && for v in r02 cxx sh32 blk; do echo "== inv_bench_$v"; timeout 120 ./inv_bench_$v; done) > $O/inv_bench_$R.log 2>&1
 python tools/gpu_e2e.py > $O/e2e_$R.log 2>&1
 CWC_FUSE=1001 SOAK_SEEDS=2000 SOAK_BASE=20261004 python tools/gpu_soak.py > $O/soak_fused_$R.log 2>&1

@@ -15,6 +15,7 @@ cp $O/autopick_$R.log $P/${R}_autopick.txt
 cp $O/robustness_$R.log $P/${R}_robustness.txt
 cp $O/coop_mul_$R.log $P/${R}_ubench_coop_mul.txt
 cp $O/inv_bench_$R.log $P/${R}_inv_bench.txt
+cp $O/scan_par_$R.log $P/${R}_scan_par_test.txt
 cp $O/e2e_$R.log $P/${R}_e2e_ab.txt
 cp $O/hostpath_$R.log $P/${R}_host_path.txt
 cp $O/single_shot_$R.log $P/${R}_single_shot.txt
