@@ -305,9 +305,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // ---- one form per value: Montgomery or canonical (inserts the conversions; see infer_representations) ----
     std::vector<uint8_t> node_rep, node_vflags;
     // (limb-arithmetic graphs -- the probe's scan-aware depth is well below the plain one -- at tile widths with the MODE 2 instances)
-    const bool limb_graph = T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_SCAN") && st.depth_scan * 10 < st.depth * 8;
+    // (The interpreter instances with scan / convolution / canonical-product paths exist for programs without divider waves, the
+    // ones with fused narrow bundles for none or one divider per interpreter: kernels.hip launch_interp.  A graph with limb
+    // chains AND field divisions is compiled both ways -- divisions in line beside scan bundles, or divider waves beside the
+    // unfused steps -- and the cost model picks, pipeline.cc candidate_keys.)
+    const bool mode2_ok = T <= SCAN_MAX_T && G >= 2 && divider == 0;
+    const bool limb_graph = mode2_ok && !getenv("CWC_NO_SCAN") && st.depth_scan * 10 < st.depth * 8;
     // bit graphs (sha256-like: one operation in thirty-two or more is a bit extract): canonical inputs, every product canonical
-    const bool bit_graph = T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_BIT_GRAPH") && !policy.all_montgomery && st.n_bitx_nodes * 32 >= st.n_op && st.n_op > 0;
+    const bool bit_graph = mode2_ok && !getenv("CWC_NO_BIT_GRAPH") && !policy.all_montgomery && st.n_bitx_nodes * 32 >= st.n_op && st.n_op > 0;
     uint64_t n_mul_cc = 0;
     infer_representations(g, node_rep, node_vflags, st.n_conversions, st.n_canonical, policy.all_montgomery, (limb_graph || bit_graph) && !getenv("CWC_NO_MUL_CC"), n_mul_cc,
                           bit_graph);
@@ -315,14 +320,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     phase("representation inference");
     // ---- scan chains: the steps of serial limb recurrences as pairs of N_SCAN nodes (class C_SCAN) ----
     std::vector<uint32_t> scan_imm, scan_partner;
-    if (T <= SCAN_MAX_T && G >= 2 && !getenv("CWC_NO_SCAN")) {
+    if (mode2_ok && !getenv("CWC_NO_SCAN")) {
         detect_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
         // schoolbook limb products: the column sums of a k x k block as one bundle (2k - 1 columns, one node slot each)
         if (n_mul_cc && !getenv("CWC_NO_CONV")) detect_convolutions(g, node_rep, node_vflags, scan_imm, scan_partner, G, st.n_conv_products);
         N = g.nodes.size();
         phase("scan chains");
     }
-    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1 && st.n_scan_steps == 0 && n_mul_cc == 0) {  // (a program has fused bundles or scan bundles: one interpreter instance each)
+    if (policy.fuse && policy.fill && T <= COOP_FUSE_MAX_T && G > 1 && divider <= 1 && st.n_scan_steps == 0 && n_mul_cc == 0) {  // (a program has fused bundles or scan bundles: one interpreter instance each)
         fuse_narrow_chains(g, node_rep, node_vflags, class_cost, (policy.fuse & 0xffffu) - 1, (policy.fuse & 0x10000u) != 0, st.n_fused_nodes);
         N = g.nodes.size();
         phase("fused narrow chains");
