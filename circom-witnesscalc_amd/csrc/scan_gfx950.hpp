@@ -169,42 +169,54 @@ __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32
 // c - i is outside [0, k).
 template <int T>
 __device__ __forceinline__ void conv_limb_columns(uint32_t k, uint32_t lane, uint64_t x, uint64_t y, uint32_t (&out)[5]) {
-    uint64_t a0 = 0, a1 = 0;
-    uint32_t a2 = 0;
+    // three 64-bit sums of 32 x 32 products by weight (1: x0 y0; 2^32: x0 y1 + x1 y0; 2^64: x1 y1), each with a counter of its
+    // overflows: a round is four v_mad_u64_u32 whose carry-outs (the instruction's scalar destination, which the compiler has no
+    // builtin for) go straight into the counters -- 8 instructions instead of 4 multiply-adds + 15 of carry handling
+    uint64_t s_lo = 0, s_mid = 0, s_hi = 0;
+    uint32_t c_lo = 0, c_mid = 0, c_hi = 0;
     uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
     const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+    auto mac = [](uint64_t& sum, uint32_t& overflows, uint32_t xs, uint32_t yv) {  // sum += xs * yv (xs in a scalar register), overflows += carry
+        uint64_t cy, unused;
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(sum), "=s"(cy) : "s"(xs), "v"(yv));
+        asm volatile("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(overflows), "=s"(unused) : "s"(cy));
+    };
     for (uint32_t i = 0; i < k; ++i) {
         uint32_t b0, b1;
         if constexpr (T == 1) {
             b0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)i);
             b1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, (int)i);
-        } else {
+            mac(s_lo, c_lo, b0, y0);
+            mac(s_mid, c_mid, b0, y1);
+            mac(s_mid, c_mid, b1, y0);
+            mac(s_hi, c_hi, b1, y1);
+        } else {  // (two sets side by side: each lane takes its own set's x_i, a vector operand)
             const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)(2 * i)), e1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, (int)(2 * i));
             const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)(2 * i + 1)), o1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, (int)(2 * i + 1));
             b0 = (lane & 1u) ? o0 : e0;
             b1 = (lane & 1u) ? o1 : e1;
+            auto macv = [](uint64_t& sum, uint32_t& overflows, uint32_t xv, uint32_t yv) {
+                uint64_t cy, unused;
+                asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(sum), "=s"(cy) : "v"(xv), "v"(yv));
+                asm volatile("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(overflows), "=s"(unused) : "s"(cy));
+            };
+            macv(s_lo, c_lo, b0, y0);
+            macv(s_mid, c_mid, b0, y1);
+            macv(s_mid, c_mid, b1, y0);
+            macv(s_hi, c_hi, b1, y1);
         }
-        // x_i * y as four 32 x 32 + 64 multiply-adds (v_mad_u64_u32, x_i's words in scalar registers)
-        const uint64_t p00 = (uint64_t)b0 * y0;
-        const uint64_t p01 = (uint64_t)b0 * y1 + (p00 >> 32);
-        const uint64_t p10 = (uint64_t)b1 * y0 + (uint32_t)p01;
-        const uint64_t hi = (uint64_t)b1 * y1 + ((p01 >> 32) + (p10 >> 32));
-        const uint64_t lo = (uint64_t)(uint32_t)p00 | (p10 << 32);
-        a0 += lo;
-        const uint64_t c0 = a0 < lo ? 1ull : 0ull;
-        a1 += hi;
-        uint32_t c1 = a1 < hi ? 1u : 0u;
-        a1 += c0;
-        c1 += a1 < c0 ? 1u : 0u;
-        a2 += c1;
         y0 = wave_shr_lanes<T>(y0);
         y1 = wave_shr_lanes<T>(y1);
     }
-    out[0] = (uint32_t)a0;
-    out[1] = (uint32_t)(a0 >> 32);
-    out[2] = (uint32_t)a1;
-    out[3] = (uint32_t)(a1 >> 32);
-    out[4] = a2;
+    // total = s_lo + c_lo 2^64 + s_mid 2^32 + c_mid 2^96 + s_hi 2^64 + c_hi 2^128  (< 2^134)
+    out[0] = (uint32_t)s_lo;
+    const uint64_t t1 = (s_lo >> 32) + (uint32_t)s_mid;
+    out[1] = (uint32_t)t1;
+    const uint64_t t2 = (t1 >> 32) + c_lo + (s_mid >> 32) + (uint32_t)s_hi;
+    out[2] = (uint32_t)t2;
+    const uint64_t t3 = (t2 >> 32) + c_mid + (s_hi >> 32);
+    out[3] = (uint32_t)t3;
+    out[4] = (uint32_t)(t3 >> 32) + c_hi;
 }
 
 }  // namespace cwc
