@@ -74,12 +74,25 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
             base.all_montgomery = true;
         }
     }
+    // Convolution bundles hold ONE limb product each: a long product (k = 32: 63 lanes busy for 32 rounds) always pays, many
+    // small products that the unfused program runs side by side in a few full bundles may not -- the unfused program competes
+    if (out.stats.n_conv_products != 0 && g.nodes.size() <= 2000000 && !getenv("CWC_CONV_ALWAYS")) {
+        CoopPolicy plain = base;
+        plain.no_conv = true;
+        Program alt;
+        std::string err2;
+        if (compile_variant(g, T, divider, fusion, plain, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
+            out = std::move(alt);
+            base.no_conv = true;
+        }
+    }
     if (base.fill == 0 || forced || g.nodes.size() > 2000000) return true;  // (huge graphs: one schedule, compile time counts)
     const CoopPolicy more[] = {{0, 0}, {std::max(12u, G * 3 / 8), 0}, {G / 2, 2}, {G * 5 / 8, 2}};
     CoopPolicy kept = base;
     for (CoopPolicy pol : more) {
         pol.all_montgomery = base.all_montgomery;
         pol.witness_slots = base.witness_slots;
+        pol.no_conv = base.no_conv;
         Program alt;
         std::string err2;
         if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
@@ -323,7 +336,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     if (mode2_ok && !getenv("CWC_NO_SCAN")) {
         detect_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
         // schoolbook limb products: the column sums of a k x k block as one bundle (2k - 1 columns, one node slot each)
-        if (n_mul_cc && !getenv("CWC_NO_CONV")) detect_convolutions(g, node_rep, node_vflags, scan_imm, scan_partner, G, st.n_conv_products);
+        if (n_mul_cc && !policy.no_conv && !getenv("CWC_NO_CONV")) detect_convolutions(g, node_rep, node_vflags, scan_imm, scan_partner, G, st.n_conv_products);
         N = g.nodes.size();
         phase("scan chains");
     }

@@ -120,7 +120,7 @@ static const double kCyclesDefault[C_COUNT] = {4000, 2015, 706, 55000, 1000, 470
 static const double kCyclesMulCC = 760;  // a bundle of canonical limb products (HDR_MUL_CC)
 // (carry bundles of 32 rounds 6.3 k cycles, division bundles 17 k: 33 and 85 instructions per round on a lone wave, the
 // division bundle's reciprocal once per bundle)
-static const double kCyclesConvFront = 900, kCyclesConvStep = 175;  // a convolution bundle: k rounds of one 64 x 64 multiply-accumulate per lane (four quarter-rate v_mad_u64_u32, 27 instructions)
+static const double kCyclesConvFront = 900, kCyclesConvStep = 125;  // a convolution bundle: k rounds of one 64 x 64 multiply-accumulate per lane (four quarter-rate v_mad_u64_u32 among 14 instructions)
 // chains of 64-bit limbs run all segments of a bundle at once (scan_gfx950.hpp): a flat carry-lookahead; log2 rounds of two products modulo d
 static const double kCyclesScanParCarry = 700, kCyclesScanParDivRound = 900, kCyclesScanParDivFlat = 900;
 static const double kCyclesScanFront = 1000, kCyclesScanFrontDiv = 2200, kCyclesScanStepCarry = 170, kCyclesScanStepDiv = 460;
@@ -194,6 +194,7 @@ struct CoopPolicy {
     uint32_t slack_levels;  // ~0u: everything ready counts as urgent
     bool all_montgomery = false;  // no representation inference: every value in Montgomery form
     bool witness_slots = false;   // the slots of witness elements in witness order (see the slot allocation)
+    bool no_conv = false;         // schoolbook limb products stay unfused (detect_convolutions off): a competitor where many small blocks run side by side
     uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused; + 0x10000: product + sum nodes only
 };
 }  // namespace cwc

@@ -779,6 +779,25 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
             adj[g.nodes[i].b].push_back((uint32_t)i);
         }
     auto other = [&](uint32_t prod, uint32_t f) { return g.nodes[prod].a == f ? g.nodes[prod].b : g.nodes[prod].a; };
+    // Only limbs that are known to fit 64 bits: the bundle's multiply-accumulate rounds are for such factors, and its rounds for
+    // any factor (field products) cost more than the unfused block's bundles (k x two Montgomery products against k^2 / 64
+    // bundles of them).  Known: a Band with a constant, the limb a carry chain's step leaves (t mod 2^n), a constant.
+    // CWC_CONV_ANY_WIDTH=1 (tests of the field-arithmetic rounds) lifts the rule.
+    const bool any_width = getenv("CWC_CONV_ANY_WIDTH") != nullptr;
+    auto const_bits = [&](uint32_t i) -> uint32_t {
+        const Fr& v = g.const_values[g.nodes[i].a];
+        for (int w = 7; w >= 0; --w)
+            if (v.v[w]) return 32u * (uint32_t)w + 32u - (uint32_t)__builtin_clz(v.v[w]);
+        return 0;
+    };
+    auto limb_sized = [&](uint32_t i) -> bool {
+        const Node& n = g.nodes[i];
+        if (any_width) return true;
+        if (n.kind == N_CONST) return const_bits(i) <= 64;
+        if (n.kind == N_SCAN) return !(n.op & (SCAN_OP_DIV | SCAN_OP_ACC)) && scan_imm[i] <= 64;
+        if (n.kind == N_DUO && n.op == OP_BAND) return (g.nodes[n.a].kind == N_CONST && const_bits(n.a) <= 64) || (g.nodes[n.b].kind == N_CONST && const_bits(n.b) <= 64);
+        return false;
+    };
     std::vector<uint8_t> dead(N, 0), taken(N, 0);
     bool any = false;
     const bool debug = getenv("CWC_DEBUG_CONV") != nullptr;
@@ -825,7 +844,8 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
                 ix[x] = i;
             }
             if (!ok || X[0] != x0 || Y[0] != y0) continue;
-            for (uint32_t x : X) ok = ok && !jy.count(x);  // disjoint
+            for (uint32_t x : X) ok = ok && !jy.count(x) && limb_sized(x);  // disjoint; limbs
+            for (uint32_t y : Y) ok = ok && limb_sized(y);
             // every x has exactly the products x y_j, each in the tree of column i + j, each tree exactly one anti-diagonal
             std::vector<uint32_t> col_root(2 * k - 1, NONE);
             std::vector<uint32_t> prods;

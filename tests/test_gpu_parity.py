@@ -630,12 +630,21 @@ def test_convolution_bundles_on_the_gpu(pkg):
     B = 1 << 64
     for k, rounds, nb, tiles in ((32, 2, 64, (1,)), (16, 3, 64, (1, 2)), (8, 3, 100, (1, 2)), (5, 2, 130, (1, 2)), (3, 2, 32, (1, 2, 4)), (2, 3, 64, (1, 2))):
         data = C.build_bigint_class(k=k, rounds=rounds, n_bits=nb).to_bin()
-        g = pkg.Graph(data)
-        n = g.n_inputs - 1
-        rows = [[1] + [M - 1] * n, [1] + [0] * n, [1] + [B - 1] * n, [1] + [(1 << nb) - 1] * n] + scan_rows(rnd, g.n_inputs, 36)
-        g = _check(pkg, data, rows, tiles=tiles)
-        st = g.program_stats(tiles[0])
-        assert st["n_conv_products"] == k * k * rounds, (k, st["n_conv_products"])
+        # (the compiler makes convolution bundles of limbs known to fit 64 bits only; CWC_CONV_ANY_WIDTH lifts that for the wide cases)
+        os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+        if nb > 64:
+            os.environ["CWC_CONV_ANY_WIDTH"] = "1"
+        os.environ["CWC_CONV_ALWAYS"] = "1"   # (the unfused program competes and wins for the smallest products)
+        try:
+            g = pkg.Graph(data)
+            n = g.n_inputs - 1
+            rows = [[1] + [M - 1] * n, [1] + [0] * n, [1] + [B - 1] * n, [1] + [(1 << nb) - 1] * n] + scan_rows(rnd, g.n_inputs, 36)
+            g = _check(pkg, data, rows, tiles=tiles)
+            st = g.program_stats(tiles[0])
+            assert st["n_conv_products"] == k * k * rounds, (k, st["n_conv_products"])
+        finally:
+            os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+            os.environ.pop("CWC_CONV_ALWAYS", None)
 
 
 @pytest.mark.timeout(900)

@@ -309,20 +309,61 @@ def test_convolution_columns_are_exact(pkg):
     widths 32 / 64 / 100 / 130 bits, tile widths 1 and 2 (32 limbs fit tile width 1 only: 63 columns), inputs of every size;
     the programs hold no multiplication bundle any more, and a block whose products something else reads stays as it is."""
     rnd = random.Random(3)
-    for k, rounds, nb in ((8, 3, 64), (4, 2, 64), (16, 2, 64), (32, 1, 64), (8, 2, 100), (5, 2, 130), (3, 2, 32), (2, 3, 64)):
+    for k, rounds, nb, any_width in ((8, 3, 64, False), (4, 2, 64, False), (16, 2, 64, False), (32, 1, 64, False), (8, 2, 100, True), (5, 2, 130, True), (3, 2, 32, False), (2, 3, 64, False),
+                                     (8, 2, 100, False)):
         b = C.build_bigint_class(k=k, rounds=rounds, n_bits=nb)
         data = b.to_bin()
         nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        # (limbs that are not known to fit 64 bits keep their unfused products -- the bundle's rounds for such factors cost more --
+        # unless CWC_CONV_ANY_WIDTH lifts the rule: the field-arithmetic rounds stay covered)
+        os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+        if any_width:
+            os.environ["CWC_CONV_ANY_WIDTH"] = "1"
+        os.environ["CWC_CONV_ALWAYS"] = "1"   # (the unfused program competes and wins for the smallest products: below)
         g = pkg.Graph(data)
         for key in (1, 2):
             blob = pe.Blob(g.export_blob(key))
-            fits = 2 * k - 1 <= 64 // key
+            fits = 2 * k - 1 <= 64 // key and (nb <= 64 or any_width)
             assert blob.stats["n_conv_products"] == (k * k * rounds if fits else 0), (k, key)
             assert (blob.stats["class_bundles"][1] == 0) == fits, "the limb products left the multiplication bundles"
             for row in scan_rows(rnd, blob.n_inputs, 2 if k > 8 else 3):
                 got, st = pe.run(blob, row)
                 assert st == 0 and got == model.evaluate(nodes, row, wit), (k, key)
         assert pe.Blob(g.export_blob(4)).stats["n_conv_products"] == 0
+        os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+        os.environ.pop("CWC_CONV_ALWAYS", None)
+    # many small products side by side: the unfused program (a few full bundles for all of them) competes with one bundle per
+    # product, and the cost model picks; CWC_CONV_ALWAYS=1 keeps the convolution bundles
+    def blocks(n_blocks, k):
+        b = cwc_import.load().graphgen.builder.Builder()
+        xs, ys = b.input("x", n_blocks * k), b.input("y", n_blocks * k)
+        m, base = b.const((1 << 64) - 1), b.const(1 << 64)
+        xs, ys = [b.op("Band", v, m) for v in xs], [b.op("Band", v, m) for v in ys]
+        for blk in range(n_blocks):
+            cols = [None] * (2 * k - 1)
+            for i in range(k):
+                for j in range(k):
+                    pr = b.mul(xs[blk * k + i], ys[blk * k + j])
+                    cols[i + j] = pr if cols[i + j] is None else b.add(cols[i + j], pr)
+            carry = b.const(0)
+            for c in range(2 * k - 1):
+                t = b.add(cols[c], carry)
+                b.signal(b.op("Mod", t, base))
+                carry = b.signal(b.op("Idiv", t, base))
+        return b
+    data = blocks(14, 3).to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    picked = pe.Blob(pkg.Graph(data).export_blob(1))
+    os.environ["CWC_CONV_ALWAYS"] = "1"
+    try:
+        forced = pe.Blob(pkg.Graph(data).export_blob(1))
+    finally:
+        os.environ.pop("CWC_CONV_ALWAYS", None)
+    assert forced.stats["n_conv_products"] == 14 * 9 and picked.stats["n_conv_products"] == 0 and picked.n_bundles < forced.n_bundles
+    for blob in (picked, forced):
+        for row in scan_rows(rnd, blob.n_inputs, 3):
+            got, st = pe.run(blob, row)
+            assert st == 0 and got == model.evaluate(nodes, row, wit)
     # a product that a witness element names is no inner node: the block keeps its unfused nodes
     b = cwc_import.load().graphgen.builder.Builder()
     xs, ys = b.input("x", 3), b.input("y", 3)

@@ -33,6 +33,13 @@ def run(n_seeds, base, verbose=True):
             if rnd.random() < 0.25:  # (schoolbook limb products: convolution bundles where 2k - 1 columns fit the tile width's node slots)
                 b = C.build_bigint_class(k=rnd.choice([2, 3, 5, 8, 11, 16, 17, 24, 32, rnd.randrange(2, 33)]), rounds=rnd.randrange(1, 4),
                                          n_bits=rnd.choice([64, 64, 64, 16, 32, 63, 65, 100, 126]))
+                # (limbs beyond 64 bits keep their unfused products unless this is set: half of the graphs run the bundle's field-arithmetic rounds)
+                os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+                os.environ.pop("CWC_CONV_ALWAYS", None)
+                if rnd.random() < 0.5:
+                    os.environ["CWC_CONV_ANY_WIDTH"] = "1"
+                if rnd.random() < 0.7:  # (else the unfused program competes: the cost model's pick)
+                    os.environ["CWC_CONV_ALWAYS"] = "1"
             else:
                 b = C.build_limb_chains(rnd.choice([1, 31, 32, 33, 63, 64, 65, 100, 121, 127, 128, 129, 200, 253, rnd.randrange(1, 254)]),
                                         rnd.choice([1, 17, 32, 63, 64, 65, 121, 128, 253, rnd.randrange(1, 254)]), rnd.randrange(1, 80), rnd.randrange(1, 4),
