@@ -559,7 +559,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 const uint32_t key = scan_key_of((uint32_t)i);
                 if (scan_key_index(key) < 0) scan_keys.push_back(key);
                 const Node& pr = g.nodes[n.b];
-                if (pr.kind == N_SCAN && (pr.op & SCAN_OP_ACC) && scan_key_of(n.b) == key && scan_next[n.b] == 0xffffffffu) scan_next[n.b] = (uint32_t)i;
+                if (!(n.op & SCAN_OP_NOACC) && pr.kind == N_SCAN && (pr.op & SCAN_OP_ACC) && scan_key_of(n.b) == key && scan_next[n.b] == 0xffffffffu) scan_next[n.b] = (uint32_t)i;
             }
         }
         // Narrow multiplication bundles: when no more multiplications are ready than four-lane products fit a wave, the
@@ -741,7 +741,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     for (uint32_t cur = head; len_all < G / 2; ++len_all) {
                         const uint32_t nx = scan_next[scan_partner[cur]];
                         if (nx == 0xffffffffu || so[nx] != s || placed[nx]) break;
-                        contiguous = contiguous && indeg[nx] == 1 && indeg[scan_partner[nx]] == 1;
+                        contiguous = contiguous && indeg[nx] == 1 && indeg[scan_partner[nx]] == 1;  // (one producer left: the accumulator; users[] holds a user once per producer)
                         len_ready += contiguous;
                         cur = nx;
                     }
@@ -783,9 +783,10 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                             ++run;
                             if (picked.size() / 2 >= cap_steps) break;
                             const uint32_t nx = scan_next[scan_partner[cur]];
-                            if (nx == 0xffffffffu || so[nx] != s || placed[nx] || indeg[nx] != 1 || indeg[scan_partner[nx]] != 1) break;
+                            if (nx == 0xffffffffu || so[nx] != s || placed[nx]) break;
                             const Node& nn = g.nodes[nx];
-                            if (in_bundle(nn.a) || ((nn.op & SCAN_OP_DIV) && in_bundle(nn.c))) break;  // (x or the divisor comes out of this very bundle)
+                            if (indeg[nx] != 1 || indeg[scan_partner[nx]] != 1) break;
+                            if ((!(nn.op & SCAN_OP_NOX) && in_bundle(nn.a)) || ((nn.op & SCAN_OP_DIV) && in_bundle(nn.c))) break;  // (x or the divisor comes out of this very bundle)
                             cur = nx;
                         }
                         longest = std::max(longest, run);
@@ -1268,11 +1269,11 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         return false;
                     }
                     const uint32_t pair = js / 2;
-                    const bool start = pair == 0 || (order[k0 + 2 * pair - 1] & ~REQ_FLAG) != n.b;
+                    const bool start = pair == 0 || (n.op & SCAN_OP_NOACC) || (order[k0 + 2 * pair - 1] & ~REQ_FLAG) != n.b;
                     ctrl |= (is_acc ? SCAN_ROLE_ACC : 0u) | (start ? SCAN_START : 0u);
                     if (!is_acc) {
-                        enc_operand(n.a, 0);
-                        if (start) enc_operand(n.b, 1);
+                        if (!(n.op & SCAN_OP_NOX)) enc_operand(n.a, 0);  // (a chain end without this operand reads 0: the record's default)
+                        if (start && !(n.op & SCAN_OP_NOACC)) enc_operand(n.b, 1);
                         scan_run = start ? 1u : scan_run + 1u;
                         scan_longest = std::max(scan_longest, scan_run);
                         scan_bits = (is_div ? HDR_SCAN_DIV : 0u) | (scan_shift_of_node(i) << HDR_SCAN_SHIFT_SHIFT);

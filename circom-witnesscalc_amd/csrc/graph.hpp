@@ -31,7 +31,8 @@ enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES
                           // of one product).  a = x_c, b = y_c (c < k; the columns above name x_(k-1), y_(k-1)): every factor
                           // is the operand of exactly one column node, the bundle reads them all.
                           N_CONV = 7 };
-enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2 };
+// (chain ends: a step without an incoming accumulator / without an x reads the constant 0 there; the operand field repeats the other one)
+enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2, SCAN_OP_NOACC = 4, SCAN_OP_NOX = 8 };
 
 // graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into
 // Graph::const_values (canonical value, already reduced mod r as storage.rs:28 does on load).

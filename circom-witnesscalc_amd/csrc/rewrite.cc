@@ -620,7 +620,7 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
     };
     auto canon = [&](uint32_t o) { return g.nodes[o].kind == N_CONST || rep[o] == REP_C; };
     // the two users of every candidate t: (Band, Shr) or (Idiv, Mod)
-    std::vector<uint32_t> user_out(N, NONE), user_acc(N, NONE);
+    std::vector<uint32_t> user_out(N, NONE), user_acc(N, NONE), end_out(N, NONE), end_acc(N, NONE);
     for (size_t j = 0; j < N; ++j) {
         Node& n = g.nodes[j];
         if (n.kind != N_DUO) continue;
@@ -629,13 +629,17 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
             std::swap(n.a, n.b);
             vflags[j] = (uint8_t)((vflags[j] & ~(VF_A_CANON | VF_B_CANON)) | ((vflags[j] & VF_A_CANON) ? VF_B_CANON : 0) | ((vflags[j] & VF_B_CANON) ? VF_A_CANON : 0));
         }
-        if (g.nodes[n.a].kind != N_DUO || g.nodes[n.a].op != OP_ADD) continue;
         const uint8_t want = VF_A_CANON | VF_B_CANON | VF_OUT_CANON;
         if ((vflags[j] & want) != want) continue;
+        if (g.nodes[n.a].kind != N_CONST) {  // (chain ends, below: the pair on any value)
+            if (n.op == OP_BAND || n.op == OP_IDIV) end_out[n.a] = end_out[n.a] == NONE ? (uint32_t)j : NONE - 1;
+            else if (n.op == OP_SHR || n.op == OP_MOD) end_acc[n.a] = end_acc[n.a] == NONE ? (uint32_t)j : NONE - 1;
+        }
+        if (g.nodes[n.a].kind != N_DUO || g.nodes[n.a].op != OP_ADD) continue;
         if (n.op == OP_BAND || n.op == OP_IDIV) user_out[n.a] = user_out[n.a] == NONE ? (uint32_t)j : NONE - 1;
         else if (n.op == OP_SHR || n.op == OP_MOD) user_acc[n.a] = user_acc[n.a] == NONE ? (uint32_t)j : NONE - 1;
     }
-    struct Step { uint32_t t, out, acc, x, acc_in, d, imm; bool div; };
+    struct Step { uint32_t t, out, acc, x, acc_in, d, imm; bool div; uint8_t ends = 0; };
     std::vector<Step> steps;
     std::vector<uint32_t> step_of_acc(N, NONE);  // ACC node (Shr / Mod) -> step
     for (size_t t = 0; t < N; ++t) {
@@ -664,6 +668,52 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
             steps.push_back(Step{(uint32_t)t, o, a, x, base_b ? M.a : M.b, O.b, base_b ? M.b : M.a, true});
         }
     }
+    // Chain ends.  The first step of a carry chain whose incoming carry is the constant 0 has no Add node (t = x), nor has the step
+    // behind the last column (t = the last carry); the first step of a remainder chain is t = 0 * 2^k + x = x.  Left alone they are
+    // two-node bundles of their own (a Band / Shr pair, an Idiv / Mod pair) on the chain's critical path, ~2 k cycles each.  Such a
+    // pair on one value becomes a step whose other operand is absent (read as 0) -- exact: x + 0 and 0 * 2^k + x are x -- where it
+    // continues a chain or a chain continues it (its accumulator value is an operand of a regular step of the same kind, or its x
+    // is a regular step's accumulator value).
+    {
+        std::vector<uint8_t> is_t(N, 0);
+        std::vector<uint32_t> reg_of_acc(N, NONE), reg_of_operand(N, NONE);  // regular steps by their ACC node / by an operand (x or incoming accumulator)
+        for (size_t k = 0; k < steps.size(); ++k) {
+            is_t[steps[k].t] = 1;
+            reg_of_acc[steps[k].acc] = (uint32_t)k;
+            reg_of_operand[steps[k].x] = reg_of_operand[steps[k].acc_in] = (uint32_t)k;
+        }
+        const size_t n_regular = steps.size();
+        if (getenv("CWC_DEBUG_SCAN")) {
+            size_t pairs = 0, not_t = 0, can = 0, linked = 0;
+            for (size_t x = 0; x < N; ++x) {
+                if (end_out[x] >= NONE - 1 || end_acc[x] >= NONE - 1) continue;
+                ++pairs;
+                if (is_t[x]) continue;
+                ++not_t;
+                can += canon((uint32_t)x);
+                linked += reg_of_acc[x] != NONE || reg_of_operand[end_acc[x]] != NONE;
+            }
+            fprintf(stderr, "chain ends: %zu values with an OUT / ACC pair, %zu besides the regular steps, %zu canonical, %zu linked to a regular step\n", pairs, not_t, can, linked);
+        }
+        for (size_t x = 0; x < N && !getenv("CWC_NO_SCAN_ENDS"); ++x) {
+            const uint32_t o = end_out[x], a = end_acc[x];
+            if (o >= NONE - 1 || a >= NONE - 1 || is_t[x] || !canon((uint32_t)x)) continue;
+            const Node &O = g.nodes[o], &A = g.nodes[a];
+            // the regular step this one continues (x is its accumulator value) or that continues this one (reads this step's accumulator value)
+            const uint32_t before = reg_of_acc[x] < n_regular ? reg_of_acc[x] : NONE, after = reg_of_operand[a] < n_regular ? reg_of_operand[a] : NONE;
+            const uint32_t link = before != NONE ? before : after;
+            if (link == NONE) continue;
+            if (O.op == OP_BAND && A.op == OP_SHR) {
+                const int n = small_of(A.b);
+                if (n < 0 || mask_of(O.b) != n || steps[link].div || steps[link].imm != (uint32_t)n) continue;
+                steps.push_back(Step{NONE, o, a, (uint32_t)x, (uint32_t)x, 0, (uint32_t)n, false, (uint8_t)(before != NONE ? SCAN_OP_NOX : SCAN_OP_NOACC)});  // (x = the chain's carry: it is the accumulator)
+            } else if (O.op == OP_IDIV && A.op == OP_MOD && O.b == A.b && canon(O.b)) {
+                if (!steps[link].div || steps[link].d != O.b) continue;
+                if (before != NONE) continue;  // (a remainder chain's last step always has its x)
+                steps.push_back(Step{NONE, o, a, (uint32_t)x, (uint32_t)x, O.b, steps[link].imm, true, (uint8_t)SCAN_OP_NOACC});
+            }
+        }
+    }
     if (getenv("CWC_DEBUG_SCAN")) {
         size_t n_band = 0, n_shr = 0, pairs = 0, uses_ok = 0, rep_ok = 0, canon_ok = 0;
         for (size_t t = 0; t < N; ++t) {
@@ -690,10 +740,11 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
     // rewrite: OUT and ACC become N_SCAN nodes on the step's operands, the inner nodes (t, m) lose their users
     std::vector<uint8_t> dead(N, 0);
     for (const Step& st : steps) {
-        const uint8_t kind = st.div ? SCAN_OP_DIV : 0;
+        const uint8_t kind = (uint8_t)((st.div ? SCAN_OP_DIV : 0) | st.ends);
         g.nodes[st.out] = Node{N_SCAN, kind, st.x, st.acc_in, st.d};
         g.nodes[st.acc] = Node{N_SCAN, (uint8_t)(kind | SCAN_OP_ACC), st.x, st.acc_in, st.d};
         vflags[st.out] = vflags[st.acc] = 0;
+        if (st.t == NONE) continue;  // (a chain end: no inner nodes)
         dead[st.t] = 1;
         if (st.div) dead[g.nodes[st.t].a == st.x ? g.nodes[st.t].b : g.nodes[st.t].a] = 1;
     }

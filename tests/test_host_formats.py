@@ -326,6 +326,8 @@ def test_convolution_columns_are_exact(pkg):
             fits = 2 * k - 1 <= 64 // key and (nb <= 64 or any_width)
             assert blob.stats["n_conv_products"] == (k * k * rounds if fits else 0), (k, key)
             assert (blob.stats["class_bundles"][1] == 0) == fits, "the limb products left the multiplication bundles"
+            if nb == 64 and k >= 4:  # chain ends are steps too (the head without an incoming carry, the tail without an x, the division's head): 2k + 2k per round, no Idiv / Mod bundle left
+                assert blob.stats["n_scan_steps"] == 4 * k * rounds and blob.stats["class_bundles"][7] == 0, (k, key, blob.stats["n_scan_steps"])
             for row in scan_rows(rnd, blob.n_inputs, 2 if k > 8 else 3):
                 got, st = pe.run(blob, row)
                 assert st == 0 and got == model.evaluate(nodes, row, wit), (k, key)

@@ -6,8 +6,11 @@ import numpy as np, torch
 import subprocess
 # the stamped interpreter instances live in the diagnostic library (make diag): built on demand, loaded in place of the product's
 _PKG = os.path.join(ROOT, "circom-witnesscalc_amd")
-subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "diag"])
-os.environ["CWC_LIB_PATH"] = os.path.join(_PKG, "libcircom_witnesscalc_amd_diag.so")
+if os.environ.get("CLASSPROF_LIB"):  # (another diagnostic build, e.g. one whose first section row samples another class: -DCWC_PSEC_CLASS)
+    os.environ["CWC_LIB_PATH"] = os.environ["CLASSPROF_LIB"]
+else:
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "diag"])
+    os.environ["CWC_LIB_PATH"] = os.path.join(_PKG, "libcircom_witnesscalc_amd_diag.so")
 import cwc_import
 pkg = cwc_import.load()
 import cwc_import
