@@ -841,6 +841,59 @@ def build_chain_heavy(seed, n_chains=12, n_inputs=5):
     return b
 
 
+def build_limb_product_variants(seed):
+    """Schoolbook limb products in the shapes the convolution rewrite has to tell apart (rewrite.cc detect_convolutions): complete
+    k x k blocks, rectangular k x m blocks, squares (x * x: the cross products are shared nodes), blocks that share a factor
+    vector, columns with an extra addend, products that are witness elements, column trees of different shapes, one limb
+    missing from a block -- each followed by a carry chain so that the graph is a limb graph.  Whatever the compiler makes of
+    them, the witness must be exact."""
+    rnd = random.Random(seed)
+    b = Builder()
+    n_bits = rnd.choice([64, 64, 64, 32, 16, 63])
+    mask, base, zero = b.const((1 << n_bits) - 1), b.const(1 << n_bits), b.const(0)
+    n_vec = rnd.randrange(2, 5)
+    klen = [rnd.choice([2, 3, 4, 5, 8]) for _ in range(n_vec)]
+    vecs = [[b.op("Band", v, mask) for v in b.input("v%d" % i, klen[i])] for i in range(n_vec)]
+    (extra,) = b.input("e")
+    extra = b.op("Band", extra, mask)
+    for _blk in range(rnd.randrange(1, 5)):
+        shape = rnd.choice(["square_block", "square_block", "rect", "self", "shared", "extra", "signal", "hole", "chain"])
+        xi = rnd.randrange(n_vec)
+        yi = xi if shape == "self" else rnd.randrange(n_vec)
+        x, y = vecs[xi], vecs[yi]
+        if shape in ("square_block", "extra", "signal", "hole", "chain", "shared") and len(y) != len(x):
+            y = y[:len(x)] if len(y) > len(x) else y + [b.op("Band", b.add(v, extra), mask) for v in x[len(y):]]
+        cols = [None] * (len(x) + len(y) - 1)
+        order = [(i, j) for i in range(len(x)) for j in range(len(y))]
+        if rnd.random() < 0.5:
+            rnd.shuffle(order)
+        hole = rnd.choice(order) if shape == "hole" else None
+        for i, j in order:
+            if (i, j) == hole:
+                continue
+            pr = b.mul(x[i], y[j]) if rnd.random() < 0.5 else b.mul(y[j], x[i])
+            if shape == "signal" and rnd.random() < 0.15:
+                b.signal(pr)
+            if cols[i + j] is None:
+                cols[i + j] = pr
+            elif shape == "chain" or rnd.random() < 0.7:
+                cols[i + j] = b.add(cols[i + j], pr)
+            else:
+                cols[i + j] = b.add(pr, cols[i + j])
+        if shape == "extra":
+            c = rnd.randrange(len(cols))
+            cols[c] = b.add(cols[c], extra)
+        carry = zero
+        outs = []
+        for c in range(len(cols)):
+            t = b.add(cols[c], carry) if cols[c] is not None else carry
+            outs.append(b.signal(b.op("Mod", t, base)))
+            carry = b.signal(b.op("Idiv", t, base))
+        if rnd.random() < 0.5:   # the product's limbs are the next block's factors
+            vecs[rnd.randrange(n_vec)] = outs[:rnd.choice([2, 3, 4, len(outs)])]
+    return b
+
+
 def build_limb_chains(n_bits=64, k_bits=64, steps=10, chains=2, mask_inputs=False, fork=False):
     """Serial limb recurrences on operands that come straight from the inputs (any field element, unless mask_inputs): per
     chain a carry chain `t = x + carry; limb = t % 2^n; carry = t \\ 2^n` and a remainder chain `t = rem * 2^k + x;

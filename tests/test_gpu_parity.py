@@ -645,6 +645,17 @@ def test_convolution_bundles_on_the_gpu(pkg):
         finally:
             os.environ.pop("CWC_CONV_ANY_WIDTH", None)
             os.environ.pop("CWC_CONV_ALWAYS", None)
+    # the shapes the recognition has to tell apart (rectangular blocks, squares, shared factors, extra addends, holes, ...)
+    for seed in range(100, 130):
+        data = C.build_limb_product_variants(seed).to_bin()
+        g = pkg.Graph(data)
+        os.environ.pop("CWC_CONV_ALWAYS", None)
+        if seed % 2:
+            os.environ["CWC_CONV_ALWAYS"] = "1"
+        try:
+            _check(pkg, data, scan_rows(rnd, g.n_inputs, 12), tiles=(1, 2))
+        finally:
+            os.environ.pop("CWC_CONV_ALWAYS", None)
 
 
 @pytest.mark.timeout(900)

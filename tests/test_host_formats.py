@@ -366,6 +366,28 @@ def test_convolution_columns_are_exact(pkg):
         for row in scan_rows(rnd, blob.n_inputs, 3):
             got, st = pe.run(blob, row)
             assert st == 0 and got == model.evaluate(nodes, row, wit)
+    # the shapes the recognition has to tell apart (graphgen build_limb_product_variants: rectangular blocks, squares, shared factor
+    # vectors, columns with an extra addend, products that are witness elements, a limb missing from a block, operand orders and
+    # tree shapes): exact whatever becomes of them, with and without the competition of the unfused program
+    n_conv = 0
+    for seed in range(60):
+        data = C.build_limb_product_variants(seed).to_bin()
+        nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+        for always in (False, True):
+            os.environ.pop("CWC_CONV_ALWAYS", None)
+            if always:
+                os.environ["CWC_CONV_ALWAYS"] = "1"
+            try:
+                g = pkg.Graph(data)
+                for key in (1, 2):
+                    blob = pe.Blob(g.export_blob(key))
+                    n_conv += blob.stats["n_conv_products"]
+                    for row in scan_rows(rnd, blob.n_inputs, 2):
+                        got, st = pe.run(blob, row)
+                        assert st == 0 and got == model.evaluate(nodes, row, wit), (seed, key, always)
+            finally:
+                os.environ.pop("CWC_CONV_ALWAYS", None)
+    assert n_conv > 300
     # a product that a witness element names is no inner node: the block keeps its unfused nodes
     b = cwc_import.load().graphgen.builder.Builder()
     xs, ys = b.input("x", 3), b.input("y", 3)

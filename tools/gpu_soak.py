@@ -30,7 +30,13 @@ def run(n_seeds, base, verbose=True):
     for s in range(n_seeds):
         kind = rnd.choice(KINDS)
         if kind == "limb":  # serial limb recurrences: what the compiler runs as scan bundles (tile widths 1 and 2), every shift / base width
-            if rnd.random() < 0.25:  # (schoolbook limb products: convolution bundles where 2k - 1 columns fit the tile width's node slots)
+            if rnd.random() < 0.15:  # (limb products in the shapes the convolution rewrite has to tell apart)
+                os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+                os.environ.pop("CWC_CONV_ALWAYS", None)
+                if rnd.random() < 0.5:
+                    os.environ["CWC_CONV_ALWAYS"] = "1"
+                b = C.build_limb_product_variants(rnd.randrange(1 << 30))
+            elif rnd.random() < 0.25:  # (schoolbook limb products: convolution bundles where 2k - 1 columns fit the tile width's node slots)
                 b = C.build_bigint_class(k=rnd.choice([2, 3, 5, 8, 11, 16, 17, 24, 32, rnd.randrange(2, 33)]), rounds=rnd.randrange(1, 4),
                                          n_bits=rnd.choice([64, 64, 64, 16, 32, 63, 65, 100, 126]))
                 # (limbs beyond 64 bits keep their unfused products unless this is set: half of the graphs run the bundle's field-arithmetic rounds)
