@@ -561,6 +561,184 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             finish(r);
             continue;
         }
+        // Programs of the MODE 2 instances (limb and bit graphs): the scan class is tested here, in front of the switch's binary search of
+        // taken branches (~50 cycles each for a lone wave) -- config 5 44.2 -> 43.2 ms, and the smaller switch serves the other classes
+        // sooner: sha256_512 372 -> 380 k witnesses/s.  (The bit class moved here as well cost both 10-20 %: profiles/r04_dispatch_ab.txt.)
+        if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
+            uint32_t cls_scan = cls;
+            asm volatile("" : "+s"(cls_scan));
+            if (cls_scan == C_SCAN) {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
+                r = fr_zero();
+                if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
+                    if (h & HDR_SCAN_CONV) {  // the columns of a k x k limb product (program_dev.h): out_c = sum_{i + j = c} x_i y_j; graph.rs:105, 110
+                        const uint32_t k = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
+                        const bool holds_y = active && lane < k * (uint32_t)T;  // (the columns k and above name a factor only to name one)
+                        if (!wave_any(active && (a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
+                            uint32_t col[5];
+                            conv_limb_columns<T>(k, lane, ((uint64_t)a_op.v[1] << 32) | a_op.v[0], holds_y ? (((uint64_t)b_op.v[1] << 32) | b_op.v[0]) : 0ull, col);
+#pragma unroll
+                            for (int w = 0; w < 5; ++w) r.v[w] = col[w];
+                        } else {  // factors of any size: the same rounds with field products (x_i into Montgomery form, times the canonical y) and field sums
+                            Fr yy = u256_select(holds_y, b_op, fr_zero());
+                            for (uint32_t i = 0; i < k; ++i) {
+                                Fr xi;
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) {
+                                    if constexpr (T == 1) {
+                                        xi.v[w] = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)i);
+                                    } else {
+                                        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)(2 * i)), o = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)(2 * i + 1));
+                                        xi.v[w] = (lane & 1u) ? o : e;
+                                    }
+                                }
+                                r = fr_add_wave(r, fr_mul_wave(fr_mul_wave(xi, fr_r2(), pv), yy, pv), pv);
+#pragma unroll
+                                for (int w = 0; w < 8; ++w) yy.v[w] = wave_shr_lanes<T>(yy.v[w]);
+                            }
+                        }
+                        finish(r);
+                        continue;
+                    }
+                    // lanes of a pair: the OUT record's lanes, then the ACC record's (T each); both compute the whole step
+                    constexpr int QP_OUT = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x44 /* [0,1,0,1] */, QP_ACC = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xEE /* [2,3,2,3] */;
+                    constexpr int D = 2 * T;  // lanes from a pair to the next
+                    const uint32_t sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu, iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
+                    const bool start = (sub & SCAN_START) != 0, role_acc = (sub & SCAN_ROLE_ACC) != 0;
+                    const Fr x = fr_quad_perm<QP_OUT>(a_op), acc0 = fr_quad_perm<QP_OUT>(b_op);
+                    if (!(h & HDR_SCAN_DIV)) {
+                        // ---- carry chain: t = x + acc; limb = t & (2^n - 1); acc' = t >> n
+                        const bool small = !wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7]) != 0u) && sh >= 1u && sh <= 128u;
+                        // 64-bit limbs: every segment of the bundle at once (scan_carry_parallel) when x (+ the accumulator coming in) < 2^192
+                        const bool seg = start || !active;
+                        uint32_t xp[8];
+                        {
+                            uint32_t cy = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) xp[k] = adc32(active ? x.v[k] : 0u, start && active ? acc0.v[k] : 0u, cy);
+                            xp[7] |= cy;
+                        }
+                        if (sh == 64u && iters > 2u && !wave_any((xp[6] | xp[7]) != 0u)) {
+                            const uint32_t xw[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
+                            uint32_t limb[2], carry[6];
+                            scan_carry_parallel<T>(seg, lane, xw, limb, carry);
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) r.v[k] = role_acc ? carry[k] : (k < 2 ? limb[k] : 0u);
+                        } else if (small) {
+                            const uint32_t m[4] = {mask_word(sh, 0), mask_word(sh, 1), mask_word(sh, 2), mask_word(sh, 3)};
+                            const uint32_t xs[4] = {x.v[0], x.v[1], x.v[2], x.v[3]}, as[4] = {acc0.v[0], acc0.v[1], acc0.v[2], acc0.v[3]};
+                            uint32_t limb[4], carry[4];
+                            const uint32_t bs = sh & 31u;
+                            switch (sh >> 5) {
+                                case 0: scan_carry_rounds<0, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                case 1: scan_carry_rounds<1, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                case 2: scan_carry_rounds<2, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                case 3: scan_carry_rounds<3, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                                default: scan_carry_rounds<4, D>(iters, bs, m, start, xs, as, limb, carry); break;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r.v[k] = role_acc ? carry[k] : limb[k];
+                        } else {
+                            Fr c = fr_zero(), limb = fr_zero();
+                            for (uint32_t it = 0; it < iters; ++it) {
+                                Fr in;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const uint32_t sft = wave_shr_lanes<D>(c.v[k]);
+                                    in.v[k] = start ? acc0.v[k] : sft;
+                                }
+                                const Fr t = fr_add_wave(x, in, pv);
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) limb.v[k] = t.v[k] & mask_word(sh, (uint32_t)k);
+                                c = u256_shr(t, sh);
+                            }
+                            r = u256_select(role_acc, c, limb);
+                        }
+                    } else {
+                        // ---- long division by one limb: t = acc * 2^k + x; q = t idiv d; acc' = t mod d (d == 0: both 0)
+                        const Fr d = fr_quad_perm<QP_ACC>(a_op), bm = fr_quad_perm<QP_ACC>(b_op);
+                        const bool dz = u256_is_zero(d);
+                        Fr ds = d;
+                        ds.v[0] |= dz ? 1u : 0u;
+                        const bool small = !wave_any((x.v[2] | x.v[3] | x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[2] | acc0.v[3] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7] |
+                                                      d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) != 0u) && sh >= 1u && sh <= 64u;
+                        Fr quo = fr_zero(), rem = fr_zero();
+                        if (small) {
+                            // every remainder stays below 2^64 (below d, or 0), so t = rem * 2^k + x < 2^128.  The divisor is the
+                            // lane's own for all rounds: its normalisation shift and reciprocal are computed once
+                            // (fr_gfx950.hpp u128_divrem_64_recip), a round is two multiplications and two corrections.
+                            const uint64_t dv = ((uint64_t)ds.v[1] << 32) | ds.v[0];
+                            const uint32_t s = clz64_nonzero(dv);
+                            const uint64_t dn = dv << s, rv = recip64(dn);
+                            const uint64_t xl = ((uint64_t)x.v[1] << 32) | x.v[0];
+                            const uint64_t a0 = ((uint64_t)acc0.v[1] << 32) | acc0.v[0];
+                            uint64_t r64 = 0, qh = 0, ql = 0;
+                            // one divisor per segment, every incoming remainder below it: all segments at once (scan_div_parallel)
+                            const bool seg = start || !active;
+                            const uint64_t d_prev = ((uint64_t)wave_shr_lanes<D>((uint32_t)(dv >> 32)) << 32) | wave_shr_lanes<D>((uint32_t)dv);
+                            if (sh == 64u && iters > 2u && !wave_any(active && (dz || (start ? a0 >= dv : dv != d_prev)))) {
+                                scan_div_parallel<T>(seg, lane, iters, active ? dv : 1ull, active ? xl : 0ull, active ? a0 : 0ull, ql, r64);
+                            } else if (sh == 64u) {
+                                // t = rem : x -- the low word is the lane's own x for all rounds: its normalised parts are made once
+                                const uint64_t xn = xl << s, xh = (xl >> 1) >> (63u - s);
+                                for (uint32_t it = 0; it < iters; ++it) {
+                                    const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
+                                    const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
+                                    uint64_t q_h = 0, q_l, rr;
+                                    if (wave_any(in >= dv)) {  // (a chain's first step with an accumulator that is not below its divisor)
+                                        u128_divrem_64_recip(in, xl, dv, s, dn, rv, true, q_h, q_l, rr);
+                                    } else {
+                                        uint64_t rn;
+                                        div2by1((in << s) | xh, xn, dn, rv, q_l, rn);
+                                        rr = rn >> s;
+                                    }
+                                    qh = dz ? 0ull : q_h;
+                                    ql = dz ? 0ull : q_l;
+                                    r64 = dz ? 0ull : rr;
+                                }
+                            } else {
+                                for (uint32_t it = 0; it < iters; ++it) {
+                                    const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
+                                    const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
+                                    // in * 2^k (1 <= k < 64) + x
+                                    const uint64_t lo = in << sh, hi = (in >> 1) >> (63u - sh);
+                                    const uint64_t tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
+                                    uint64_t q_h, q_l, rr;
+                                    u128_divrem_64_recip(th, tl, dv, s, dn, rv, wave_any(th >= dv), q_h, q_l, rr);
+                                    qh = dz ? 0ull : q_h;
+                                    ql = dz ? 0ull : q_l;
+                                    r64 = dz ? 0ull : rr;
+                                }
+                            }
+                            quo.v[0] = (uint32_t)ql; quo.v[1] = (uint32_t)(ql >> 32); quo.v[2] = (uint32_t)qh; quo.v[3] = (uint32_t)(qh >> 32);
+                            rem.v[0] = (uint32_t)r64; rem.v[1] = (uint32_t)(r64 >> 32);
+                        } else {
+                            for (uint32_t it = 0; it < iters; ++it) {
+                                Fr in;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const uint32_t sft = wave_shr_lanes<D>(rem.v[k]);
+                                    in.v[k] = start ? acc0.v[k] : sft;
+                                }
+                                // (acc canonical) x (2^k in Montgomery form) = acc * 2^k mod r, canonical; any acc < 2^256 is reduced
+                                const Fr t = fr_add_wave(fr_mul_wave(in, bm, pv), x, pv);
+                                const uint32_t lx = u256_bitlen(t), ly = u256_bitlen(ds);
+                                const uint32_t my_dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;
+                                uint32_t dig = 0;
+#pragma unroll
+                                for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
+                                Fr q1, r1;
+                                u256_divrem_digits(q1, r1, t, ds, dig, ly);
+                                quo = u256_select(dz, fr_zero(), q1);
+                                rem = u256_select(dz, fr_zero(), r1);
+                            }
+                        }
+                        r = u256_select(role_acc, rem, quo);
+                    }
+                }
+                finish(r);
+                continue;
+            }
+        }
         switch (cls) {
             case C_INPUT: {  // graph.rs:376  Fr::new(inputs[i])
                 const uint32_t idx = crefs[(size_t)cref_row * G + j];
@@ -730,176 +908,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 }
                 break;
             }
-            case C_SCAN: {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
-                r = fr_zero();
-                if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
-                    if (h & HDR_SCAN_CONV) {  // the columns of a k x k limb product (program_dev.h): out_c = sum_{i + j = c} x_i y_j; graph.rs:105, 110
-                        const uint32_t k = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
-                        const bool holds_y = active && lane < k * (uint32_t)T;  // (the columns k and above name a factor only to name one)
-                        if (!wave_any(active && (a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
-                            uint32_t col[5];
-                            conv_limb_columns<T>(k, lane, ((uint64_t)a_op.v[1] << 32) | a_op.v[0], holds_y ? (((uint64_t)b_op.v[1] << 32) | b_op.v[0]) : 0ull, col);
-#pragma unroll
-                            for (int w = 0; w < 5; ++w) r.v[w] = col[w];
-                        } else {  // factors of any size: the same rounds with field products (x_i into Montgomery form, times the canonical y) and field sums
-                            Fr yy = u256_select(holds_y, b_op, fr_zero());
-                            for (uint32_t i = 0; i < k; ++i) {
-                                Fr xi;
-#pragma unroll
-                                for (int w = 0; w < 8; ++w) {
-                                    if constexpr (T == 1) {
-                                        xi.v[w] = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)i);
-                                    } else {
-                                        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)(2 * i)), o = (uint32_t)__builtin_amdgcn_readlane((int)a_op.v[w], (int)(2 * i + 1));
-                                        xi.v[w] = (lane & 1u) ? o : e;
-                                    }
-                                }
-                                r = fr_add_wave(r, fr_mul_wave(fr_mul_wave(xi, fr_r2(), pv), yy, pv), pv);
-#pragma unroll
-                                for (int w = 0; w < 8; ++w) yy.v[w] = wave_shr_lanes<T>(yy.v[w]);
-                            }
-                        }
-                        finish(r);
-                        continue;
-                    }
-                    // lanes of a pair: the OUT record's lanes, then the ACC record's (T each); both compute the whole step
-                    constexpr int QP_OUT = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x44 /* [0,1,0,1] */, QP_ACC = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xEE /* [2,3,2,3] */;
-                    constexpr int D = 2 * T;  // lanes from a pair to the next
-                    const uint32_t sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu, iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
-                    const bool start = (sub & SCAN_START) != 0, role_acc = (sub & SCAN_ROLE_ACC) != 0;
-                    const Fr x = fr_quad_perm<QP_OUT>(a_op), acc0 = fr_quad_perm<QP_OUT>(b_op);
-                    if (!(h & HDR_SCAN_DIV)) {
-                        // ---- carry chain: t = x + acc; limb = t & (2^n - 1); acc' = t >> n
-                        const bool small = !wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7]) != 0u) && sh >= 1u && sh <= 128u;
-                        // 64-bit limbs: every segment of the bundle at once (scan_carry_parallel) when x (+ the accumulator coming in) < 2^192
-                        const bool seg = start || !active;
-                        uint32_t xp[8];
-                        {
-                            uint32_t cy = 0;
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) xp[k] = adc32(active ? x.v[k] : 0u, start && active ? acc0.v[k] : 0u, cy);
-                            xp[7] |= cy;
-                        }
-                        if (sh == 64u && iters > 2u && !wave_any((xp[6] | xp[7]) != 0u)) {
-                            const uint32_t xw[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
-                            uint32_t limb[2], carry[6];
-                            scan_carry_parallel<T>(seg, lane, xw, limb, carry);
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) r.v[k] = role_acc ? carry[k] : (k < 2 ? limb[k] : 0u);
-                        } else if (small) {
-                            const uint32_t m[4] = {mask_word(sh, 0), mask_word(sh, 1), mask_word(sh, 2), mask_word(sh, 3)};
-                            const uint32_t xs[4] = {x.v[0], x.v[1], x.v[2], x.v[3]}, as[4] = {acc0.v[0], acc0.v[1], acc0.v[2], acc0.v[3]};
-                            uint32_t limb[4], carry[4];
-                            const uint32_t bs = sh & 31u;
-                            switch (sh >> 5) {
-                                case 0: scan_carry_rounds<0, D>(iters, bs, m, start, xs, as, limb, carry); break;
-                                case 1: scan_carry_rounds<1, D>(iters, bs, m, start, xs, as, limb, carry); break;
-                                case 2: scan_carry_rounds<2, D>(iters, bs, m, start, xs, as, limb, carry); break;
-                                case 3: scan_carry_rounds<3, D>(iters, bs, m, start, xs, as, limb, carry); break;
-                                default: scan_carry_rounds<4, D>(iters, bs, m, start, xs, as, limb, carry); break;
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) r.v[k] = role_acc ? carry[k] : limb[k];
-                        } else {
-                            Fr c = fr_zero(), limb = fr_zero();
-                            for (uint32_t it = 0; it < iters; ++it) {
-                                Fr in;
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    const uint32_t sft = wave_shr_lanes<D>(c.v[k]);
-                                    in.v[k] = start ? acc0.v[k] : sft;
-                                }
-                                const Fr t = fr_add_wave(x, in, pv);
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) limb.v[k] = t.v[k] & mask_word(sh, (uint32_t)k);
-                                c = u256_shr(t, sh);
-                            }
-                            r = u256_select(role_acc, c, limb);
-                        }
-                    } else {
-                        // ---- long division by one limb: t = acc * 2^k + x; q = t idiv d; acc' = t mod d (d == 0: both 0)
-                        const Fr d = fr_quad_perm<QP_ACC>(a_op), bm = fr_quad_perm<QP_ACC>(b_op);
-                        const bool dz = u256_is_zero(d);
-                        Fr ds = d;
-                        ds.v[0] |= dz ? 1u : 0u;
-                        const bool small = !wave_any((x.v[2] | x.v[3] | x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[2] | acc0.v[3] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7] |
-                                                      d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) != 0u) && sh >= 1u && sh <= 64u;
-                        Fr quo = fr_zero(), rem = fr_zero();
-                        if (small) {
-                            // every remainder stays below 2^64 (below d, or 0), so t = rem * 2^k + x < 2^128.  The divisor is the
-                            // lane's own for all rounds: its normalisation shift and reciprocal are computed once
-                            // (fr_gfx950.hpp u128_divrem_64_recip), a round is two multiplications and two corrections.
-                            const uint64_t dv = ((uint64_t)ds.v[1] << 32) | ds.v[0];
-                            const uint32_t s = clz64_nonzero(dv);
-                            const uint64_t dn = dv << s, rv = recip64(dn);
-                            const uint64_t xl = ((uint64_t)x.v[1] << 32) | x.v[0];
-                            const uint64_t a0 = ((uint64_t)acc0.v[1] << 32) | acc0.v[0];
-                            uint64_t r64 = 0, qh = 0, ql = 0;
-                            // one divisor per segment, every incoming remainder below it: all segments at once (scan_div_parallel)
-                            const bool seg = start || !active;
-                            const uint64_t d_prev = ((uint64_t)wave_shr_lanes<D>((uint32_t)(dv >> 32)) << 32) | wave_shr_lanes<D>((uint32_t)dv);
-                            if (sh == 64u && iters > 2u && !wave_any(active && (dz || (start ? a0 >= dv : dv != d_prev)))) {
-                                scan_div_parallel<T>(seg, lane, iters, active ? dv : 1ull, active ? xl : 0ull, active ? a0 : 0ull, ql, r64);
-                            } else if (sh == 64u) {
-                                // t = rem : x -- the low word is the lane's own x for all rounds: its normalised parts are made once
-                                const uint64_t xn = xl << s, xh = (xl >> 1) >> (63u - s);
-                                for (uint32_t it = 0; it < iters; ++it) {
-                                    const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
-                                    const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
-                                    uint64_t q_h = 0, q_l, rr;
-                                    if (wave_any(in >= dv)) {  // (a chain's first step with an accumulator that is not below its divisor)
-                                        u128_divrem_64_recip(in, xl, dv, s, dn, rv, true, q_h, q_l, rr);
-                                    } else {
-                                        uint64_t rn;
-                                        div2by1((in << s) | xh, xn, dn, rv, q_l, rn);
-                                        rr = rn >> s;
-                                    }
-                                    qh = dz ? 0ull : q_h;
-                                    ql = dz ? 0ull : q_l;
-                                    r64 = dz ? 0ull : rr;
-                                }
-                            } else {
-                                for (uint32_t it = 0; it < iters; ++it) {
-                                    const uint32_t s0 = wave_shr_lanes<D>((uint32_t)r64), s1 = wave_shr_lanes<D>((uint32_t)(r64 >> 32));
-                                    const uint64_t in = start ? a0 : (((uint64_t)s1 << 32) | s0);
-                                    // in * 2^k (1 <= k < 64) + x
-                                    const uint64_t lo = in << sh, hi = (in >> 1) >> (63u - sh);
-                                    const uint64_t tl = lo + xl, th = hi + (tl < lo ? 1ull : 0ull);
-                                    uint64_t q_h, q_l, rr;
-                                    u128_divrem_64_recip(th, tl, dv, s, dn, rv, wave_any(th >= dv), q_h, q_l, rr);
-                                    qh = dz ? 0ull : q_h;
-                                    ql = dz ? 0ull : q_l;
-                                    r64 = dz ? 0ull : rr;
-                                }
-                            }
-                            quo.v[0] = (uint32_t)ql; quo.v[1] = (uint32_t)(ql >> 32); quo.v[2] = (uint32_t)qh; quo.v[3] = (uint32_t)(qh >> 32);
-                            rem.v[0] = (uint32_t)r64; rem.v[1] = (uint32_t)(r64 >> 32);
-                        } else {
-                            for (uint32_t it = 0; it < iters; ++it) {
-                                Fr in;
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    const uint32_t sft = wave_shr_lanes<D>(rem.v[k]);
-                                    in.v[k] = start ? acc0.v[k] : sft;
-                                }
-                                // (acc canonical) x (2^k in Montgomery form) = acc * 2^k mod r, canonical; any acc < 2^256 is reduced
-                                const Fr t = fr_add_wave(fr_mul_wave(in, bm, pv), x, pv);
-                                const uint32_t lx = u256_bitlen(t), ly = u256_bitlen(ds);
-                                const uint32_t my_dig = lx >= ly ? (lx - ly + 32u) >> 5 : 0u;
-                                uint32_t dig = 0;
-#pragma unroll
-                                for (uint32_t dd = 1; dd <= 8; ++dd) dig = wave_any(my_dig >= dd) ? dd : dig;
-                                Fr q1, r1;
-                                u256_divrem_digits(q1, r1, t, ds, dig, ly);
-                                quo = u256_select(dz, fr_zero(), q1);
-                                rem = u256_select(dz, fr_zero(), r1);
-                            }
-                        }
-                        r = u256_select(role_acc, rem, quo);
-                    }
-                }
-                break;
-            }
+            case C_SCAN: r = fr_zero(); break;  // (MODE 2: handled in front of the switch; other instances never see the class)
             default: r = fr_zero(); break;
         }
         finish(r);
