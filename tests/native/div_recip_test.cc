@@ -49,6 +49,17 @@ int main() {
             }
         }
     }
+    // the reciprocal alone on structured divisors: both ends of the normalised range, powers of two +- small, all-ones prefixes
+    for (int iter = 0; iter < 6000000; ++iter) {
+        uint64_t dn = rnd64() | (1ull << 63);
+        if (iter % 7 == 0) dn = (1ull << 63) + rnd64() % 1000;
+        if (iter % 11 == 0) dn = ~0ull - rnd64() % 1000;
+        if (iter % 13 == 0) dn = (1ull << 63) | (1ull << (rnd64() % 63));
+        if (iter % 17 == 0) dn = (1ull << 63) | ((1ull << (rnd64() % 63)) - 1);
+        const unsigned __int128 vv = (((unsigned __int128)(~dn)) << 64 | ~0ull) / dn;
+        ++n;
+        if ((uint64_t)vv != recip64(dn)) { if (bad < 5) printf("reciprocal mismatch dn=%llx\n", (unsigned long long)dn); ++bad; }
+    }
     printf("u128_divrem_64_recip vs __int128: %ld mismatches of %ld\n", bad, n);
     return bad != 0;
 }
