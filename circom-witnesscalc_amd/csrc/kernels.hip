@@ -790,10 +790,20 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             }
             case C_CMPS: {  // graph.rs:130-133 with u_lt/u_gt/u_lte/u_gte :723-769
                 const Fr x = (h & HDR_A_CANON) ? a_op : fr_from_mont(a_op), y = (h & HDR_B_CANON) ? b_op : fr_from_mont(b_op);
-                const bool xn = u256_lt(fr_half(), x), yn = u256_lt(fr_half(), y);
+                // a < b as the borrow of a - b with the difference kept alive: left to itself the compiler turns a borrow-only chain into
+                // eight compare / and / or triples through scalar registers, ~600 cycles of latency per comparison on a lone wave
+                // (in the MODE 2 instances only -- limb graphs compare limbs every round; in the plain instances the change costs the hot
+                // paths 2-3 % through the loop's register allocation: 81.0 against 83.2 k witnesses/s at the headline)
+                auto less = [](const Fr& a, const Fr& b) {
+                    Fr t;
+                    const uint32_t borrow = u256_sub(t, a, b);
+                    if constexpr (MODE == 2) asm volatile("" ::"v"(t.v[7]));
+                    return borrow != 0;
+                };
+                const bool xn = less(fr_half(), x), yn = less(fr_half(), y);
                 const bool same = xn == yn;
-                const bool lt = same ? u256_lt(x, y) : xn;
-                const bool gt = same ? u256_lt(y, x) : yn;
+                const bool lt = same ? less(x, y) : xn;
+                const bool gt = same ? less(y, x) : yn;
                 const bool v = sub == SUB_LT ? lt : sub == SUB_GT ? gt : sub == SUB_LEQ ? !gt : !lt;
                 r = u256_select(v, one_out(), fr_zero());
                 break;
