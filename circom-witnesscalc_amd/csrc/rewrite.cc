@@ -695,7 +695,8 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
             }
             fprintf(stderr, "chain ends: %zu values with an OUT / ACC pair, %zu besides the regular steps, %zu canonical, %zu linked to a regular step\n", pairs, not_t, can, linked);
         }
-        for (size_t x = 0; x < N && !getenv("CWC_NO_SCAN_ENDS"); ++x) {
+        const bool no_ends = getenv("CWC_NO_SCAN_ENDS") != nullptr;
+        for (size_t x = 0; x < N && !no_ends; ++x) {
             const uint32_t o = end_out[x], a = end_acc[x];
             if (o >= NONE - 1 || a >= NONE - 1 || is_t[x] || !canon((uint32_t)x)) continue;
             const Node &O = g.nodes[o], &A = g.nodes[a];
