@@ -894,6 +894,40 @@ def build_limb_product_variants(seed):
     return b
 
 
+def build_limb_graph_with_divisions(k=6, rounds=2):
+    """A limb graph (schoolbook product, carry chain, long division by one limb) that also holds FIELD divisions: programs for
+    divider waves keep the limb arithmetic unfused (the interpreter instances with scan / convolution paths run without divider
+    waves), programs without them run the divisions in line beside scan and convolution bundles -- both must be exact, and the
+    cost model picks between them."""
+    b = Builder()
+    xs, ys = b.input("x", k), b.input("y", k)
+    (dv,) = b.input("d")
+    m, base, zero, one = b.const((1 << 64) - 1), b.const(1 << 64), b.const(0), b.const(1)
+    x = [b.op("Band", v, m) for v in xs]
+    y = [b.op("Band", v, m) for v in ys]
+    d = b.add(b.op("Band", dv, m), one)
+    for _ in range(rounds):
+        cols = [None] * (2 * k - 1)
+        for i in range(k):
+            for j in range(k):
+                pr = b.mul(x[i], y[j])
+                cols[i + j] = pr if cols[i + j] is None else b.add(cols[i + j], pr)
+        carry, prod = zero, []
+        for c in range(2 * k - 1):
+            t = b.add(cols[c], carry)
+            prod.append(b.signal(b.op("Mod", t, base)))
+            carry = b.signal(b.op("Idiv", t, base))
+        rem, quo = zero, []
+        for c in range(2 * k - 2, -1, -1):
+            t = b.add(b.mul(rem, base), prod[c])
+            quo.append(b.signal(b.op("Idiv", t, d)))
+            rem = b.signal(b.op("Mod", t, d))
+        inv = [b.signal(b.div(b.add(quo[i], one), b.add(prod[i], one))) for i in range(3)]
+        x = [b.op("Band", b.add(quo[i], inv[i % 3]), m) for i in range(k)]
+        y = [b.op("Band", b.add(prod[i], rem), m) for i in range(k)]
+    return b
+
+
 def build_limb_chains(n_bits=64, k_bits=64, steps=10, chains=2, mask_inputs=False, fork=False):
     """Serial limb recurrences on operands that come straight from the inputs (any field element, unless mask_inputs): per
     chain a carry chain `t = x + carry; limb = t % 2^n; carry = t \\ 2^n` and a remainder chain `t = rem * 2^k + x;

@@ -388,6 +388,19 @@ def test_convolution_columns_are_exact(pkg):
             finally:
                 os.environ.pop("CWC_CONV_ALWAYS", None)
     assert n_conv > 300
+    # a limb graph that also holds field divisions: without divider waves scan / convolution bundles beside in-line divisions,
+    # with them the unfused nodes (the instances with those paths exist for programs without divider waves)
+    data = C.build_limb_graph_with_divisions().to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    g = pkg.Graph(data)
+    for key in (1, 2, 1 | DIVIDER, 2 | DIVIDER, 1 | STREAMS4, 4):
+        blob = pe.Blob(g.export_blob(key))
+        limb_paths = key in (1, 2, 1 | STREAMS4)
+        assert (blob.stats["n_scan_steps"] > 0) == limb_paths and (blob.stats["n_conv_products"] > 0) == limb_paths, hex(key)
+        assert (blob.stats["class_bundles"][9] > 0) == bool(key & DIVIDER), "division requests in the programs for divider waves only"
+        for row in scan_rows(rnd, blob.n_inputs, 3):
+            got, st = pe.run(blob, row)
+            assert st == 0 and got == model.evaluate(nodes, row, wit), hex(key)
     # a product that a witness element names is no inner node: the block keeps its unfused nodes
     b = cwc_import.load().graphgen.builder.Builder()
     xs, ys = b.input("x", 3), b.input("y", 3)
