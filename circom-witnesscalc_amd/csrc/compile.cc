@@ -318,11 +318,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     // ---- one form per value: Montgomery or canonical (inserts the conversions; see infer_representations) ----
     std::vector<uint8_t> node_rep, node_vflags;
     // (limb-arithmetic graphs -- the probe's scan-aware depth is well below the plain one -- at tile widths with the MODE 2 instances)
-    // (The interpreter instances with scan / convolution / canonical-product paths exist for programs without divider waves, the
-    // ones with fused narrow bundles for none or one divider per interpreter: kernels.hip launch_interp.  A graph with limb
-    // chains AND field divisions is compiled both ways -- divisions in line beside scan bundles, or divider waves beside the
-    // unfused steps -- and the cost model picks, pipeline.cc candidate_keys.)
-    const bool mode2_ok = T <= SCAN_MAX_T && G >= 2 && divider == 0;
+    // (The interpreter instances with scan / convolution / canonical-product paths, like the ones with fused narrow bundles, exist for
+    // programs with no or one divider wave per interpreter: kernels.hip launch_interp.)
+    const bool mode2_ok = T <= SCAN_MAX_T && G >= 2 && divider <= 1;
     const bool limb_graph = mode2_ok && !getenv("CWC_NO_SCAN") && st.depth_scan * 10 < st.depth * 8;
     // bit graphs (sha256-like: one operation in thirty-two or more is a bit extract): canonical inputs, every product canonical
     const bool bit_graph = mode2_ok && !getenv("CWC_NO_BIT_GRAPH") && !policy.all_montgomery && st.n_bitx_nodes * 32 >= st.n_op && st.n_op > 0;

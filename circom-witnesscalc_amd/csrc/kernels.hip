@@ -1093,17 +1093,14 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
     const uint32_t mode = p.has_fused;  // 0, 1: fused narrow bundles, 2: scan bundles (validate_program: never both)
     static_assert(SCAN_MAX_T == COOP_FUSE_MAX_T, "the instances with a MODE are made for tile widths up to COOP_FUSE_MAX_T");
-    // the instances with a MODE: scan / convolution / canonical-product programs run without divider waves, fused narrow bundles with
-    // none or one divider per interpreter (compile.cc compiles nothing else, validate_program rejects it): 24 instances less
-    if (mode > 2 || (mode && T > COOP_FUSE_MAX_T) || (mode == 2 && W != 0) || (mode == 1 && W > 1)) return hipErrorInvalidValue;
+    // the instances with a MODE (fused narrow bundles; scan / convolution / canonical-product bundles) exist for programs with no or one
+    // divider wave per interpreter (compile.cc compiles nothing else, validate_program rejects it)
+    if (mode > 2 || (mode && (T > COOP_FUSE_MAX_T || W > 1))) return hipErrorInvalidValue;
 #define CWC_LAUNCH3(TT, PP, WW, KK)                                                                                                     \
     do {                                                                                                                                \
-        if constexpr ((uint32_t)(TT) <= COOP_FUSE_MAX_T && (WW) == 0) {                                                                 \
+        if constexpr ((uint32_t)(TT) <= COOP_FUSE_MAX_T && (WW) <= 1) {                                                                 \
             if (mode == 2) interp_kernel<TT, PP, WW, KK, 2><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
             else if (mode == 1) interp_kernel<TT, PP, WW, KK, 1><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
-            else interp_kernel<TT, PP, WW, KK, 0><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);     \
-        } else if constexpr ((uint32_t)(TT) <= COOP_FUSE_MAX_T && (WW) == 1) {                                                          \
-            if (mode == 1) interp_kernel<TT, PP, WW, KK, 1><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
             else interp_kernel<TT, PP, WW, KK, 0><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);     \
         } else {                                                                                                                        \
             interp_kernel<TT, PP, WW, KK, 0><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);          \

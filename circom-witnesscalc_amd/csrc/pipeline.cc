@@ -175,8 +175,6 @@ std::vector<uint32_t> candidate_keys(const ProgramStats& stats, size_t batch, ui
     size_t divider_tiles = 1024;
     if (const char* e = getenv("CWC_DIVIDER_TILES")) divider_tiles = (size_t)atol(e);
     const bool has_div = stats.class_nodes[C_DIV] > 0;
-    // (compile.cc limb_graph / bit_graph, from the probe's statistics: bit extracts are pairs of Shr and Band nodes there)
-    const bool mode2_graph = stats.depth_scan * 10 < stats.depth * 8 || (stats.n_op > 0 && stats.class_nodes[C_BIT] * 16 >= stats.n_op);
     const uint32_t t0 = rule & ~KEY_MODE_MASK;
     std::vector<uint32_t> keys;
     for (uint32_t t = std::max(min_t, t0 >= 4 ? t0 / 4 : 1u); t <= t0 * 2 && t <= 32 && (batch >= 64 || t == t0); t *= 2)  // (tiny batches: one tile either way)
@@ -186,9 +184,7 @@ std::vector<uint32_t> candidate_keys(const ProgramStats& stats, size_t batch, ui
             // divider waves: while every pair is resident; one divider per four interpreters: where a five-wave
             // workgroup per CU covers more than half of the batch at once
             const bool divider_fits = has_div && tiles <= divider_tiles;
-            // (measured: with every pair resident the divider program always wins -- but for limb / bit graphs, whose scan, convolution and
-            // canonical-product bundles exist in programs without divider waves only: there both kinds compete)
-            if (mode == 0 && divider_fits && !mode2_graph) continue;
+            if (mode == 0 && divider_fits) continue;  // (measured: with every pair resident the divider program always wins)
             if (mode == KEY_DIVIDER && !divider_fits) continue;
             if (mode == KEY_TRIPLE && !(has_div && tiles > 512 && tiles <= 768 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;
             if (mode == KEY_GROUP && !(has_div && tiles > 512 && tiles <= 1024 && !getenv("CWC_NO_GROUP_DIVIDER"))) continue;

@@ -128,7 +128,7 @@ bool validate_program(const Program& p, std::string& err) {
         if ((h & HDR_CLASS_MASK) == C_MUL && (h & HDR_MUL_CC) && (T > SCAN_MAX_T || (h & (HDR_LIN_ADD | HDR_LIN_SUB)))) return bad("canonical-product bundle");
     }
     if (any_fused && any_scan) return bad("fused and scan / canonical-product bundles in one program");
-    if ((any_scan && p.divider != 0) || (any_fused && p.divider > 1)) return bad("scan / fused bundles in a program for these divider waves");  // (kernels.hip launch_interp: which instances exist)
+    if ((any_scan || any_fused) && p.divider > 1) return bad("scan / fused bundles in a program for these divider waves");  // (kernels.hip launch_interp: which instances exist)
     if (in_flight || n_req != p.n_div_requests || n_get != n_req || stream_req != p.stream_div_requests[stream]) return bad("division requests");
     if (NS > 1 && n_posts != 1) return bad("streams without a post");
     for (uint32_t w : p.witness_refs)

@@ -388,14 +388,14 @@ def test_convolution_columns_are_exact(pkg):
             finally:
                 os.environ.pop("CWC_CONV_ALWAYS", None)
     assert n_conv > 300
-    # a limb graph that also holds field divisions: without divider waves scan / convolution bundles beside in-line divisions,
-    # with them the unfused nodes (the instances with those paths exist for programs without divider waves)
+    # a limb graph that also holds field divisions: scan / convolution bundles beside in-line divisions or beside the requests to
+    # a divider wave
     data = C.build_limb_graph_with_divisions().to_bin()
     nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
     g = pkg.Graph(data)
     for key in (1, 2, 1 | DIVIDER, 2 | DIVIDER, 1 | STREAMS4, 4):
         blob = pe.Blob(g.export_blob(key))
-        limb_paths = key in (1, 2, 1 | STREAMS4)
+        limb_paths = key != 4
         assert (blob.stats["n_scan_steps"] > 0) == limb_paths and (blob.stats["n_conv_products"] > 0) == limb_paths, hex(key)
         assert (blob.stats["class_bundles"][9] > 0) == bool(key & DIVIDER), "division requests in the programs for divider waves only"
         for row in scan_rows(rnd, blob.n_inputs, 3):
@@ -525,8 +525,8 @@ def test_scan_chains_are_exact(pkg):
     chains `t = r * 2^k + x; q = t \\ d; r' = t % d` -- become pairs of N_SCAN nodes that the scheduler places in consecutive
     pairs of node slots of scan bundles (class SCAN; compile.cc detect_scans).  The emulator runs the compiled programs on
     the stored words: every shift / base width, chains longer than a bundle, chains that fork, a step whose x is another
-    step's output, operands outside the limb range, d == 0; tile widths 1 and 2, also as stream programs (wider tiles and
-    programs for divider waves keep the unfused nodes)."""
+    step's output, operands outside the limb range, d == 0; tile widths 1 and 2, with divider waves and as stream programs
+    (wider tiles keep the unfused nodes)."""
     rnd = random.Random(12)
     total = 0
     for case in SCAN_CASES:
@@ -538,12 +538,12 @@ def test_scan_chains_are_exact(pkg):
             blob = pe.Blob(g.export_blob(key))
             total += blob.stats["n_scan_steps"]
             assert (blob.stats["class_bundles"][14] > 0) == (blob.stats["n_scan_steps"] > 0) and blob.stats["class_bundles"][13] == 0
-            assert (blob.stats["n_scan_steps"] > 0) == (key != (1 | DIVIDER)), "scan bundles exist in programs without divider waves (kernels.hip launch_interp: which instances exist)"
+            assert blob.stats["n_scan_steps"] > 0, "scan bundles in programs with no or one divider wave per interpreter (kernels.hip launch_interp: which instances exist)"
             for row in scan_rows(rnd, blob.n_inputs, 4):
                 got, st = pe.run(blob, row)
                 assert st == 0 and got == model.evaluate(nodes, row, wit), (case, key)
         assert pe.Blob(g.export_blob(4)).stats["n_scan_steps"] == 0
-    assert total > 1100
+    assert total > 1500
     # the bigint-class graph of BASELINE config 5: carry chains and the long division as scan bundles, a tenth of the bundles
     b = C.build_bigint_class(k=8, rounds=3)
     data = b.to_bin()
