@@ -243,6 +243,25 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 for (uint32_t o : {n.a, n.b})
                     if (g.nodes[o].kind == N_DUO && g.nodes[o].op == OP_MUL) step[o] = 1;
         }
+        // (round 5) the one-bit recurrences of multi-register integers (rewrite.cc detect_bit_scans): a selection on an ordered comparison,
+        // the comparison, and the short sums / differences under them (the arms x - y - bin, the comparand y + bin)
+        {
+            std::vector<uint8_t> reach(N, 0);  // how many more levels of Add / Sub below this node count as part of a step
+            auto is_lin = [&](uint32_t o) { return g.nodes[o].kind == N_DUO && (g.nodes[o].op == OP_ADD || g.nodes[o].op == OP_SUB); };
+            for (size_t i = N; i-- > 0;) {
+                const Node& n = g.nodes[i];
+                if (n.kind == N_TRES && g.nodes[n.a].kind == N_DUO && (g.nodes[n.a].op == OP_LT || g.nodes[n.a].op == OP_GT || g.nodes[n.a].op == OP_LEQ || g.nodes[n.a].op == OP_GEQ)) {
+                    step[i] = step[n.a] = 1;
+                    reach[n.a] = std::max<uint8_t>(reach[n.a], 1);
+                    for (uint32_t o : {n.b, n.c})
+                        if (is_lin(o)) reach[o] = std::max<uint8_t>(reach[o], 3);
+                }
+                if (n.kind != N_DUO || !reach[i]) continue;
+                if (is_lin((uint32_t)i)) step[i] = 1;
+                for (uint32_t o : {n.a, n.b})
+                    if (is_lin(o)) reach[o] = std::max<uint8_t>(reach[o], (uint8_t)(is_lin((uint32_t)i) ? reach[i] - 1 : 1));
+            }
+        }
         std::vector<float> lf(N, 0.0f);
         float deepest = 0.0f;
         for (size_t i = 0; i < N; ++i) {
@@ -333,6 +352,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     std::vector<uint32_t> scan_imm, scan_partner;
     if (mode2_ok && !getenv("CWC_NO_SCAN")) {
         detect_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
+        // borrow chains / most-significant-difference comparisons of multi-register integers (limb graphs: the step kinds live in the MODE 2 instances)
+        if (limb_graph) detect_bit_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
         // schoolbook limb products: the column sums of a k x k block as one bundle (2k - 1 columns, one node slot each)
         if (n_mul_cc && !policy.no_conv && !getenv("CWC_NO_CONV")) detect_convolutions(g, node_rep, node_vflags, scan_imm, scan_partner, G, st.n_conv_products);
         N = g.nodes.size();
@@ -361,7 +382,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 case C_IDIVMOD: return 1500;
                 case C_TERN: return 100;
                 case C_MULF: return 704.0 * (1 + (fused_op2(n.op) == FOP_MUL ? 1 : 0)) + 290.0 * ((fused_op2(n.op) > FOP_MUL ? 1 : 0) + (fused_op3(n.op) ? 1 : 0));
-                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : kCyclesScanStepCarry;  // (the serial rounds; chains of 64-bit limbs beat this "floor" with the parallel forms)
+                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : (n.op & (SCAN_OP_BORROW | SCAN_OP_LEX)) ? 20.0 : kCyclesScanStepCarry;  // (the serial rounds; chains of 64-bit limbs beat this "floor" with the parallel forms)
                 default: return 0;
             }
         };
@@ -525,7 +546,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         // Scan chains: a step is scheduled as a unit (its OUT node stands for both), consecutive steps of a chain go into
         // consecutive pairs of ONE bundle.  A bundle's steps share kind and shift: one ready heap per (kind, shift).
         const bool has_scans = st.n_scan_steps != 0 || st.n_conv_products != 0;
-        static const uint32_t kConvKey = 512;        // the heap of convolution groups (a group is named by its column-0 node)
+        static const uint32_t kConvKey = 1u << 20;   // the heap of convolution groups (a group is named by its column-0 node)
         std::unordered_map<uint32_t, std::vector<uint32_t>> conv_members;  // column-0 node -> the group's nodes in column order
         std::vector<uint32_t> scan_keys;             // distinct (kind << 8 | shift)
         std::vector<uint32_t> scan_next;             // ACC node -> OUT node of the step that continues its chain
@@ -536,7 +557,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 if (v.v[w]) return 32u * w + (uint32_t)__builtin_ctz(v.v[w]);
             return 0;
         };
-        auto scan_key_of = [&](uint32_t i) -> uint32_t { return ((g.nodes[i].op & SCAN_OP_DIV) ? 256u : 0u) | scan_shift_of(i); };
+        auto scan_key_of = [&](uint32_t i) -> uint32_t { return (scan_kind_bits(g.nodes[i].op) << 8) | scan_shift_of(i); };  // (kind bits 0x02 .. 0xf0, a shift below 254)
         auto scan_key_index = [&](uint32_t key) -> int {
             for (size_t k = 0; k < scan_keys.size(); ++k)
                 if (scan_keys[k] == key) return (int)k;
@@ -784,7 +805,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                             if (nx == 0xffffffffu || so[nx] != s || placed[nx]) break;
                             const Node& nn = g.nodes[nx];
                             if (indeg[nx] != 1 || indeg[scan_partner[nx]] != 1) break;
-                            if ((!(nn.op & SCAN_OP_NOX) && in_bundle(nn.a)) || ((nn.op & SCAN_OP_DIV) && in_bundle(nn.c))) break;  // (x or the divisor comes out of this very bundle)
+                            if ((!(nn.op & SCAN_OP_NOX) && in_bundle(nn.a)) || (scan_has_third(nn.op) && in_bundle(nn.c))) break;  // (x or the divisor / subtrahend / comparand comes out of this very bundle)
                             cur = nx;
                         }
                         longest = std::max(longest, run);
@@ -1274,10 +1295,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         if (start && !(n.op & SCAN_OP_NOACC)) enc_operand(n.b, 1);
                         scan_run = start ? 1u : scan_run + 1u;
                         scan_longest = std::max(scan_longest, scan_run);
-                        scan_bits = (is_div ? HDR_SCAN_DIV : 0u) | (scan_shift_of_node(i) << HDR_SCAN_SHIFT_SHIFT);
+                        scan_bits = (is_div ? HDR_SCAN_DIV : 0u) | ((n.op & SCAN_OP_BORROW) ? HDR_SCAN_BORROW : 0u) | ((n.op & SCAN_OP_LEX) ? HDR_SCAN_LEX : 0u) |
+                                    ((n.op & SCAN_OP_KG) ? HDR_SCAN_KG : 0u) | ((n.op & SCAN_OP_KL) ? HDR_SCAN_KL : 0u) | (scan_shift_of_node(i) << HDR_SCAN_SHIFT_SHIFT);
                     } else if (is_div) {
                         enc_to(n.c, 2, off[0], lds[0]);
                         off[1] = (uint32_t)mem_off(scan_imm[i]);
+                    } else if (scan_has_third(n.op)) {  // BORROW / LEX: y
+                        enc_to(n.c, 2, off[0], lds[0]);
                     }
                     break;
                 }
@@ -1325,6 +1349,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             uint32_t log_rounds = 0;
             while ((1u << log_rounds) < scan_longest) ++log_rounds;
             const double scan_cycles = (scan_bits & HDR_SCAN_CONV) ? kCyclesConvFront + (double)scan_longest * kCyclesConvStep
+                                       : (scan_bits & (HDR_SCAN_BORROW | HDR_SCAN_LEX)) ? kCyclesScanFront + kCyclesScanBits
                                        : (scan_bits & HDR_SCAN_DIV) ? kCyclesScanFrontDiv + (limbs64 ? kCyclesScanParDivFlat + log_rounds * kCyclesScanParDivRound : (double)scan_longest * kCyclesScanStepDiv)
                                                                     : kCyclesScanFront + (limbs64 ? kCyclesScanParCarry : (double)scan_longest * kCyclesScanStepCarry);
             form_saved = kCycles[C_SCAN] - scan_cycles;

@@ -49,7 +49,7 @@ inline int class_of(const Node& n) {
 // (a fused node's operands in a, b, c: the factor(s) of its product, then the operands of its second and third stage)
 inline int arity_of(const Node& n) {
     if (n.kind == N_FUSED) return fused_sq(n.op) ? 1 + (fused_op2(n.op) ? 1 : 0) + (fused_op3(n.op) ? 1 : 0) : 3;
-    if (n.kind == N_SCAN) return (n.op & SCAN_OP_DIV) ? 3 : 2;  // x, the accumulator coming in, the divisor
+    if (n.kind == N_SCAN) return scan_has_third(n.op) ? 3 : 2;  // x, the accumulator coming in, the divisor / subtrahend / other comparand
     if (n.kind == N_CONV) return 2;                              // x_c, y_c
     return n.kind == N_UNO ? 1 : n.kind == N_DUO ? 2 : n.kind == N_TRES ? 3 : 0;
 }
@@ -82,7 +82,7 @@ static inline uint64_t fused_cost50(uint8_t op) {
     return 12u + 15u + (fused_op2(op) == FOP_MUL ? 15u : fused_op2(op) ? 6u : 0u) + (fused_op3(op) ? 6u : 0u);
 }
 // a step of a scan bundle: its share of the bundle's front end and one round of the loop (cycles / 50; kCyclesScan* below)
-static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 10u : 4u; }
+static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 10u : (op & (SCAN_OP_BORROW | SCAN_OP_LEX)) ? 1u : 4u; }  // (the one-bit recurrences run all steps at once)
 static inline uint64_t node_cost(const uint32_t* table, const Node& n) {
     return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : n.kind == N_CONV ? 70u : cost_of(table, class_of(n));  // (a convolution bundle: ~3.5 k cycles)
 }
@@ -100,6 +100,8 @@ void reduce_tree_height(Graph& g, size_t kMaxLeaves, const uint32_t* class_cost)
 void infer_representations(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, uint64_t& n_conversions, uint64_t& n_canonical, bool all_montgomery,
                            bool allow_cc, uint64_t& n_cc, bool canonical_inputs);
 void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint64_t& n_steps);
+// borrow chains of register-wise subtractions and most-significant-difference comparisons (SCAN_OP_BORROW / SCAN_OP_LEX)
+void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint64_t& n_steps);
 // scan_imm[column node] = column | k << 8, scan_partner[column node] = the node of column 0 (the group's name)
 void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint32_t max_columns,
                          uint64_t& n_products);
@@ -124,6 +126,7 @@ static const double kCyclesConvFront = 900, kCyclesConvStep = 125;  // a convolu
 // chains of 64-bit limbs run all segments of a bundle at once (scan_gfx950.hpp): a flat carry-lookahead; log2 rounds of two products modulo d
 static const double kCyclesScanParCarry = 700, kCyclesScanParDivRound = 900, kCyclesScanParDivFlat = 900;
 static const double kCyclesScanFront = 1000, kCyclesScanFrontDiv = 2200, kCyclesScanStepCarry = 170, kCyclesScanStepDiv = 460;
+static const double kCyclesScanBits = 700;  // a bundle of one-bit recurrences (borrow chain, comparison): two comparisons, a carry-lookahead over the wave, one subtraction
 // a fused narrow bundle (C_MULF) is priced with all three stages (product, product, addition); what a bundle without
 // the second product / without additions saves
 static const double kCyclesFusedStageMul = 760, kCyclesFusedStageLin = 300;

@@ -32,7 +32,12 @@ enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES
                           // is the operand of exactly one column node, the bundle reads them all.
                           N_CONV = 7 };
 // (chain ends: a step without an incoming accumulator / without an x reads the constant 0 there; the operand field repeats the other one)
-enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2, SCAN_OP_NOACC = 4, SCAN_OP_NOX = 8 };
+// Round 5, one-bit recurrences of multi-register integers (rewrite.cc detect_bit_scans), operands a = x, b = the bit coming in, c = y:
+//   BORROW  the borrow chain of a register-wise subtraction: OUT = x - y - bin (+ 2^n when that is negative), ACC = the borrow going out
+//   LEX     a most-significant-difference comparison: ACC = x > y ? KG : x < y ? KL : the bit coming in (KG, KL: the two op bits); OUT unused
+enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2, SCAN_OP_NOACC = 4, SCAN_OP_NOX = 8, SCAN_OP_BORROW = 16, SCAN_OP_LEX = 32, SCAN_OP_KG = 64, SCAN_OP_KL = 128 };
+static inline bool scan_has_third(uint8_t op) { return (op & (SCAN_OP_DIV | SCAN_OP_BORROW | SCAN_OP_LEX)) != 0; }  // (a divisor / a subtrahend / the other comparand)
+static inline uint32_t scan_kind_bits(uint8_t op) { return op & (SCAN_OP_DIV | SCAN_OP_BORROW | SCAN_OP_LEX | SCAN_OP_KG | SCAN_OP_KL); }  // (what the steps of one bundle share, with the shift)
 
 // graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into
 // Graph::const_values (canonical value, already reduced mod r as storage.rs:28 does on load).

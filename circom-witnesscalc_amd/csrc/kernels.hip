@@ -605,7 +605,84 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     const uint32_t sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu, iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
                     const bool start = (sub & SCAN_START) != 0, role_acc = (sub & SCAN_ROLE_ACC) != 0;
                     const Fr x = fr_quad_perm<QP_OUT>(a_op), acc0 = fr_quad_perm<QP_OUT>(b_op);
-                    if (!(h & HDR_SCAN_DIV)) {
+                    if (h & (HDR_SCAN_BORROW | HDR_SCAN_LEX)) {
+                        // ---- one-bit recurrences (round 5), all steps of the bundle at once: c_out = gen | (prop & c_in), scan_bit_lookahead
+                        const Fr y = fr_quad_perm<QP_ACC>(a_op);
+                        const bool seg = start || !active;
+                        const uint32_t a0 = (start && active && !u256_is_zero(acc0)) ? 1u : 0u;  // the bit coming into a segment (a chain end without one reads 0; a comparison chain's may be a Montgomery-form boolean)
+                        auto less = [](const Fr& a, const Fr& b) {  // a < b as the borrow of a - b, the difference kept alive (see C_CMPS below)
+                            Fr t;
+                            const uint32_t borrow = u256_sub(t, a, b);
+                            asm volatile("" ::"v"(t.v[7]));
+                            return borrow != 0;
+                        };
+                        auto signed_lt = [&](const Fr& a, const Fr& b) {  // graph.rs:723-755: negative = above (r - 1) / 2
+                            const bool an = less(fr_half(), a), bn = less(fr_half(), b);
+                            return an == bn ? less(a, b) : an;
+                        };
+                        if (h & HDR_SCAN_LEX) {
+                            // acc' = x > y ? KG : x < y ? KL : acc (graph.rs:130-131, 221-225): generate = the registers differ and the winner's
+                            // constant is 1, propagate = they are equal
+                            const uint32_t kg = (h & HDR_SCAN_KG) ? 1u : 0u, kl = (h & HDR_SCAN_KL) ? 1u : 0u;
+                            const bool lt = active && signed_lt(x, y), gt = active && signed_lt(y, x);
+                            const bool gen = (gt && kg) || (lt && kl), prop = active && !gt && !lt;
+                            const uint32_t cin = scan_bit_lookahead<T>(seg, gen || (seg && prop && a0), prop, lane);
+                            const uint32_t bin = seg ? a0 : cin;
+                            const bool res = role_acc ? (gen || (prop && bin)) : bin != 0u;  // (the OUT value is read by nothing)
+                            r = u256_select(res, sh ? fr_one() : Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, fr_zero());  // (shift field 1: Montgomery-form booleans)
+                        } else {
+                            // borrow chain: s = y + bin; c = x >= s; out = c ? x - y - bin : x - y - bin + 2^n; acc' = c ? 0 : 1 (graph.rs:110-111, 133, 221-225)
+                            const uint32_t m[4] = {mask_word(sh, 0), mask_word(sh, 1), mask_word(sh, 2), mask_word(sh, 3)};
+                            const uint32_t above = (x.v[0] & ~m[0]) | (x.v[1] & ~m[1]) | (x.v[2] & ~m[2]) | (x.v[3] & ~m[3]) | x.v[4] | x.v[5] | x.v[6] | x.v[7] |
+                                                   (y.v[0] & ~m[0]) | (y.v[1] & ~m[1]) | (y.v[2] & ~m[2]) | (y.v[3] & ~m[3]) | y.v[4] | y.v[5] | y.v[6] | y.v[7];
+                            if (sh <= 126u && !wave_any(active && above != 0u)) {
+                                // registers below 2^n everywhere in the wave: everything is a small non-negative integer, the comparison unsigned;
+                                // generate = x < y, propagate = x == y
+                                uint32_t d[4], bw = 0;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) d[k] = sbb32(x.v[k], y.v[k], bw);
+                                const bool gen = active && bw != 0u, prop = active && (d[0] | d[1] | d[2] | d[3]) == 0u;
+                                const uint32_t cin = scan_bit_lookahead<T>(seg, gen || (seg && prop && a0), prop, lane);
+                                const uint32_t bin = seg ? a0 : cin;
+                                const bool bout = gen || (prop && bin);
+                                // x - y - bin, + 2^n when a borrow leaves (mod 2^128: the result is in [0, 2^n))
+                                uint32_t e[4], b2 = 0;
+                                e[0] = sbb32(d[0], bin, b2);
+#pragma unroll
+                                for (int k = 1; k < 4; ++k) e[k] = sbb32(d[k], 0u, b2);
+                                uint32_t cy = 0;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const uint32_t add = (bout && (sh >> 5) == (uint32_t)k) ? (1u << (sh & 31u)) : 0u;
+                                    e[k] = adc32(e[k], add, cy);
+                                }
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) r.v[k] = role_acc ? (k == 0 && bout ? 1u : 0u) : e[k];
+                            } else {
+                                // any operands: the unfused nodes' field arithmetic and signed comparison, round by round
+                                Fr pw = fr_zero();
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) pw.v[k] = (sh >> 5) == (uint32_t)k ? (1u << (sh & 31u)) : 0u;
+                                uint32_t bo = 0;
+                                Fr diff = fr_zero();
+                                const Fr xy = fr_sub_wave(x, y, pv);
+                                for (uint32_t it = 0; it < iters; ++it) {
+                                    const uint32_t sft = wave_shr_lanes<D>(bo);
+                                    Fr in = fr_zero();
+                                    in.v[0] = start ? a0 : sft;
+                                    const bool c = !signed_lt(x, fr_add_wave(y, in, pv));
+                                    const Fr d0 = fr_sub_wave(xy, in, pv);
+                                    diff = u256_select(c, d0, fr_add_wave(d0, pw, pv));
+                                    bo = c ? 0u : 1u;
+                                }
+                                r = diff;
+                                if (role_acc) {
+                                    r = fr_zero();
+                                    r.v[0] = bo;
+                                }
+                            }
+                        }
+                    } else if (!(h & HDR_SCAN_DIV)) {
                         // ---- carry chain: t = x + acc; limb = t & (2^n - 1); acc' = t >> n
                         const bool small = !wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | acc0.v[4] | acc0.v[5] | acc0.v[6] | acc0.v[7]) != 0u) && sh >= 1u && sh <= 128u;
                         // 64-bit limbs: every segment of the bundle at once (scan_carry_parallel) when x (+ the accumulator coming in) < 2^192

@@ -57,17 +57,23 @@ bool validate_program(const Program& p, std::string& err) {
             const uint32_t iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u, sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu;
             if (h & HDR_SCAN_CONV) {  // the 2k - 1 columns of a k x k limb product
                 if (T > SCAN_MAX_T || cnt != 2 * iters - 1 || iters < 2 || sh != 0 || (h & 0x7e800u)) return bad("bundle " + std::to_string(b) + ": convolution bundle");
-            } else if (T > SCAN_MAX_T || (cnt & 1u) || cnt == 0 || iters > cnt / 2 || sh >= 254u || (h & 0x7f000u)) return bad("bundle " + std::to_string(b) + ": scan bundle");
+            } else {
+                // one kind per bundle: carry chain, long division by one limb, borrow chain, comparison (the last with its two result bits; its shift field: 1 = the chain's bits in Montgomery form)
+                const uint32_t kinds = h & (HDR_SCAN_DIV | HDR_SCAN_BORROW | HDR_SCAN_LEX);
+                const bool kind_ok = (kinds & (kinds - 1u)) == 0 && (!(h & (HDR_SCAN_KG | HDR_SCAN_KL)) || (h & HDR_SCAN_LEX)) && (!(h & HDR_SCAN_LEX) || sh <= 1u);
+                if (T > SCAN_MAX_T || (cnt & 1u) || cnt == 0 || iters > cnt / 2 || sh >= 254u || (h & 0x61000u) || !kind_ok) return bad("bundle " + std::to_string(b) + ": scan bundle");
+            }
         }
         // posts and waits are C_SYNC bundles without nodes: stream 0 posts once, every other stream waits in its first bundle
-        // (nothing else is compiled)
-        if (((h & (HDR_POST | HDR_WAIT)) != 0) != (cls == C_SYNC) || (cls == C_SYNC && cnt != 0)) return bad("bundle " + std::to_string(b) + ": post / wait bits");
-        if ((h & HDR_POST) && !(NS > 1 && stream == 0 && executed && n_posts++ == 0)) return bad("bundle " + std::to_string(b) + ": post");
-        if (((h & HDR_WAIT) != 0) != (NS > 1 && stream != 0 && executed && b == p.stream_first[stream])) return bad("bundle " + std::to_string(b) + ": wait");
+        // (nothing else is compiled).  (Bits 11-18 of a scan bundle's header are its own -- kind, result bits --, checked above.)
+        const uint32_t hg = cls == C_SCAN ? (h & ~0x7f800u) : h;
+        if (((hg & (HDR_POST | HDR_WAIT)) != 0) != (cls == C_SYNC) || (cls == C_SYNC && cnt != 0)) return bad("bundle " + std::to_string(b) + ": post / wait bits");
+        if ((hg & HDR_POST) && !(NS > 1 && stream == 0 && executed && n_posts++ == 0)) return bad("bundle " + std::to_string(b) + ": post");
+        if (((hg & HDR_WAIT) != 0) != (NS > 1 && stream != 0 && executed && b == p.stream_first[stream])) return bad("bundle " + std::to_string(b) + ": wait");
         // the staging loads of the two bundles behind a wait are issued in front of it: they must not read anything
         if (NS > 1 && stream != 0 && executed && (b == p.stream_first[stream] + 1 || b == p.stream_first[stream] + 2) && cnt != 0) return bad("bundle " + std::to_string(b) + ": work right behind a wait");
-        if ((h & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
-        if ((h & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ || cls == C_INPUT)) return bad("bundle " + std::to_string(b) + ": result form bit");
+        if ((hg & (HDR_A_CANON | HDR_B_CANON)) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS)) return bad("bundle " + std::to_string(b) + ": operand form bits");
+        if ((hg & HDR_OUT_CANON) && !(cls == C_BIT || cls == C_IDIVMOD || cls == C_CMPS || cls == C_CMPZ || cls == C_INPUT)) return bad("bundle " + std::to_string(b) + ": result form bit");
         const uint32_t rep = cls == C_MULQ || cls == C_MULF ? COOP_LANES : 1u;
         if ((cnt == 0 && cls != C_LIN && cls != C_SYNC) || cnt * rep > G) return bad("bundle " + std::to_string(b) + ": node count");
         if (cls == C_MULF && T > COOP_FUSE_MAX_T) return bad("bundle " + std::to_string(b) + ": fused bundle at this tile width");
@@ -155,7 +161,7 @@ void program_blob_write(const Program& p, uint8_t* dst) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 18;  // (18: convolution bundles (C_SCAN with HDR_SCAN_CONV), one more statistics word.  17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
+    h.version = 19;  // (19: scan bundles of one-bit recurrences (HDR_SCAN_BORROW / HDR_SCAN_LEX).  18: convolution bundles (C_SCAN with HDR_SCAN_CONV), one more statistics word.  17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -186,7 +192,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 18 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 19 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

@@ -59,6 +59,11 @@ enum BundleClass : uint32_t {
     // start only), dst | ACTIVE | START?, x_lds | acc_lds << 16}, position 2p + 1 = its ACC record {d_off, (2^k)_Montgomery_off,
     // dst | ACTIVE | ROLE_ACC | START?, d_lds | B_lds << 16} (CARRY: both unused).  Header: bit 11 kind (0 CARRY, 1 DIV), bits
     // 19-26 the shift n / k (< 254), bits 27-31 iterations - 1 (the longest chain segment of the bundle), count = positions in use.
+    //   BORROW (header bit 13, round 5)  the borrow chain of a register-wise subtraction x - y (bigint long_sub): s = y + bin (graph.rs:110);
+    //          c = x >= s (:133, :756-769); out = c ? x - y - bin : x - y - bin + 2^n (:110-111, :221-225); acc' = c ? 0 : 1.  ACC record {y_off, -}.
+    //   LEX    (header bit 14, round 5)  a comparison decided by the most significant differing register (bigint long_gt):
+    //          acc' = x > y ? KG : x < y ? KL : acc (:130-131 with u_gt / u_lt :723-755, :221-225); KG, KL = header bits 15, 16; out unused; shift field 1: the chain's bits are Montgomery-form booleans (0 / 2^256 mod r), 0: the integers 0 / 1.
+    //          ACC record {y_off, -}.  The accumulators of both kinds are single bits (a chain starts from 0, 1 or another chain's bit).
     //   CONV (header bit 12, round 4): the 2k - 1 columns of a k x k schoolbook limb product, position c = column c: record
     //   {x_off, y_off, dst | ACTIVE, x_lds | y_lds << 16} names x_c and y_c for c < k (any value above); out_c = sum_{i + j = c}
     //   x_i y_j in the field on canonical integers (graph.rs:105, 110).  Header bits 27-31: k - 1.
@@ -67,6 +72,8 @@ enum BundleClass : uint32_t {
 };
 static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4, COOP_FUSE_MAX_T = 2, SCAN_MAX_T = 2;
 static const uint32_t HDR_SCAN_DIV = 1u << 11, HDR_SCAN_CONV = 1u << 12;
+// one-bit recurrences (round 5): bit 13 BORROW, bit 14 LEX with its two result bits KG (bit 15), KL (bit 16)
+static const uint32_t HDR_SCAN_BORROW = 1u << 13, HDR_SCAN_LEX = 1u << 14, HDR_SCAN_KG = 1u << 15, HDR_SCAN_KL = 1u << 16;
 static const int HDR_SCAN_SHIFT_SHIFT = 19, HDR_SCAN_ITER_SHIFT = 27;
 static const uint32_t SCAN_ROLE_ACC = 1u, SCAN_START = 2u;  // sub-op bits of a scan record
 // stage codes of a fused node (C_MULF): op2 in the low three bits of the main record's ctrl, op3 in the extra record's

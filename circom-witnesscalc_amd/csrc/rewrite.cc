@@ -761,6 +761,251 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
     compact_dead(g, dead, rep, vflags, scan_imm, scan_partner);  // (the dead inner nodes would be scheduled)
 }
 
+// ---- one-bit recurrences of multi-register integers (round 5) -------------------------------------------------------------
+// The witness hints of big-integer circuits whose registers are wider than a machine word (circom-bigint as zk-email's RSA verifier
+// uses it: 121-bit registers x 17; long_div by a k-register divisor) spend most of their dependent chain in two recurrences whose
+// state is ONE BIT per register:
+//   * the borrow chain of a register-wise subtraction (long_sub), per register, as the function's if / else predicated:
+//         s = y + bin;  c = x >= s;  diff = c ? x - y - bin : 2^n + x - y - bin;  bout = c ? 0 : 1
+//   * the comparison decided by the most significant differing register (long_gt), least significant register first:
+//         res = x > y ? 1 : (x < y ? 0 : res)
+// Unfused a register costs three (two) bundles on the graph's critical chain.  A step becomes a PAIR of N_SCAN nodes like the
+// steps of detect_scans -- BORROW: OUT = diff, ACC = bout; LEX: ACC = the outer selection, OUT = the inner one (read by nothing) --
+// and the kernel runs all steps of a bundle at once: both are carry chains (generate / propagate per register: x < y / x == y;
+// x != y with the winning constant / x == y), a carry-lookahead over the wave resolves them (scan_gfx950.hpp scan_bit_lookahead).
+// Recognition is by VALUE, not by shape: the arms of the difference are expanded to linear forms over the step's atoms (x, y, bin)
+// and compared with x - y - bin and x - y - bin + 2^n, whatever the front-end's association or the load-time optimiser's folding
+// (y = 0: `0 + bin`, `x - 0` are gone) made of them.  Exact: the kernel's step is the same field additions / subtractions, the
+// same signed comparisons (graph.rs:110-111, 130-133, 723-769) and selections (:221-225) on the same canonical integers;
+// nothing that can fail is involved.  Inner nodes that something else reads stay; the rest is removed by a sweep of unused
+// pure nodes.  scan_imm[node]: BORROW the register width n, LEX 0.
+namespace {
+struct LinForm {  // sum of coeff * node + k (field constant), at most 6 terms
+    std::pair<uint32_t, int> t[6];
+    int n = 0;
+    Fr k = fr_zero();
+    bool ok = true;
+    void add_term(uint32_t node, int c) {
+        for (int i = 0; i < n; ++i)
+            if (t[i].first == node) {
+                t[i].second += c;
+                if (!t[i].second) t[i] = t[--n];
+                return;
+            }
+        if (n == 6) { ok = false; return; }
+        t[n++] = {node, c};
+    }
+    void add_const(const Fr& v, int sign) { k = sign > 0 ? fr_add(k, v) : fr_sub(k, v); }
+};
+}  // namespace
+
+void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vflags, std::vector<uint32_t>& scan_imm, std::vector<uint32_t>& scan_partner, uint64_t& n_steps) {
+    const size_t N = g.nodes.size();
+    static const uint32_t NONE = 0xffffffffu;
+    if (getenv("CWC_NO_BIT_SCANS")) return;
+    if (scan_imm.size() != N) scan_imm.assign(N, 0);
+    if (scan_partner.size() != N) scan_partner.assign(N, NONE);
+    // users of every comparison node (CSR over the nodes that are candidates for a condition)
+    std::vector<uint32_t> uses(N, 0), first_user(N + 1, 0), user_list;
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) uses[ops[q]]++;
+    }
+    {
+        for (size_t i = 0; i < N; ++i) first_user[i + 1] = first_user[i] + uses[i];
+        user_list.assign(first_user[N], 0);
+        std::vector<uint32_t> fill(first_user.begin(), first_user.end() - 1);
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            const uint32_t ops[3] = {n.a, n.b, n.c};
+            for (int q = 0; q < arity_of(n); ++q) user_list[fill[ops[q]]++] = (uint32_t)i;
+        }
+    }
+    std::vector<uint32_t> wit_uses(N, 0);
+    for (uint32_t w : g.witness_signals) wit_uses[w]++;
+    auto const_value = [&](uint32_t idx) -> const Fr* { return g.nodes[idx].kind == N_CONST ? &g.const_values[g.nodes[idx].a] : nullptr; };
+    auto const_small = [&](uint32_t idx) -> int {  // 0 / 1 -> that, else -1
+        const Fr* v = const_value(idx);
+        if (!v) return -1;
+        for (int w = 1; w < 8; ++w)
+            if (v->v[w]) return -1;
+        return v->v[0] <= 1u ? (int)v->v[0] : -1;
+    };
+    auto pow2_value = [&](const Fr& v) -> int {
+        int k = -1, bits = 0;
+        for (int w = 0; w < 8; ++w)
+            if (v.v[w]) {
+                bits += __builtin_popcount(v.v[w]);
+                k = 32 * w + __builtin_ctz(v.v[w]);
+            }
+        return bits == 1 ? k : -1;
+    };
+    auto canon = [&](uint32_t o) { return g.nodes[o].kind == N_CONST || rep[o] == REP_C; };
+    auto is_cmp = [&](uint32_t i, uint8_t op) { return g.nodes[i].kind == N_DUO && g.nodes[i].op == op; };
+    // linear form of `root` over atoms: Add / Sub / Neg nodes are expanded (not the stop nodes, not beyond `budget` nodes)
+    auto expand = [&](uint32_t root, uint32_t s0, uint32_t s1, uint32_t s2) -> LinForm {
+        LinForm f;
+        std::pair<uint32_t, int> stack[24];
+        int sp = 0, budget = 16;
+        stack[sp++] = {root, 1};
+        while (sp && f.ok) {
+            const auto [i, sg] = stack[--sp];
+            const Node& n = g.nodes[i];
+            if (n.kind == N_CONST) {
+                f.add_const(g.const_values[n.a], sg);
+            } else if (i != s0 && i != s1 && i != s2 && budget > 0 && sp + 2 <= 24 && ((n.kind == N_DUO && (n.op == OP_ADD || n.op == OP_SUB)) || n.kind == N_UNO)) {
+                --budget;
+                if (n.kind == N_UNO) {
+                    if (n.op != 0) { f.ok = false; break; }  // (Neg only)
+                    stack[sp++] = {n.a, -sg};
+                } else {
+                    stack[sp++] = {n.a, sg};
+                    stack[sp++] = {n.b, n.op == OP_ADD ? sg : -sg};
+                }
+            } else {
+                f.add_term(i, sg);
+            }
+        }
+        return f;
+    };
+    // `f` == x - y - bin + extra with extra a constant: returns true and that constant
+    auto matches_difference = [&](LinForm f, uint32_t x, uint32_t y, uint32_t bin, Fr& extra) -> bool {
+        if (!f.ok) return false;
+        auto take = [&](uint32_t node, int sign) {  // f -= sign * node
+            if (node == NONE) return;
+            if (const Fr* v = const_value(node)) f.add_const(*v, -sign);
+            else f.add_term(node, -sign);
+        };
+        take(x, 1);
+        take(y, -1);
+        take(bin, -1);
+        if (!f.ok || f.n != 0) return false;
+        extra = f.k;
+        return true;
+    };
+    struct Step { uint32_t out, acc, x, acc_in, y, imm; uint8_t op; };
+    std::vector<Step> steps;
+    std::vector<uint8_t> bit_acc(N, 0);  // 1: the ACC node of a BORROW step, 2: of a LEX step (in node order: a step's incoming bit is an earlier step's)
+    std::vector<uint8_t> taken(N, 0);
+    size_t cand_borrow = 0, cand_lex = 0;
+    for (size_t j = 0; j < N; ++j) {
+        const Node& n = g.nodes[j];
+        if (n.kind != N_TRES || taken[j]) continue;
+        const int kb = const_small(n.b), kc = const_small(n.c);
+        // ---- BORROW: bout = Tern(x >= s, 0, 1) (or Tern(x < s, 1, 0)) and diff = Tern(the same condition, x - y - bin, x - y - bin + 2^n)
+        if (kb >= 0 && kc >= 0 && kb != kc && g.nodes[n.a].kind == N_DUO && rep[j] == REP_C) {
+            const Node& C = g.nodes[n.a];
+            uint32_t x = NONE, s = NONE;
+            bool cond_is_geq = true;  // the condition holds when NO borrow leaves
+            if (C.op == OP_GEQ) { x = C.a; s = C.b; }
+            else if (C.op == OP_LEQ) { x = C.b; s = C.a; }
+            else if (C.op == OP_LT) { x = C.a; s = C.b; cond_is_geq = false; }
+            else if (C.op == OP_GT) { x = C.b; s = C.a; cond_is_geq = false; }
+            if (x != NONE && (cond_is_geq ? (kb == 0 && kc == 1) : (kb == 1 && kc == 0))) {
+                ++cand_borrow;
+                // s = y + bin, bin the ACC node of an earlier BORROW step
+                uint32_t y = s, bin = NONE;
+                const uint32_t zero_node = cond_is_geq ? n.b : n.c;  // (a constant 0 that exists)
+                if (bit_acc[s] == 1) { bin = s; y = zero_node; }
+                else if (g.nodes[s].kind == N_DUO && g.nodes[s].op == OP_ADD) {
+                    if (bit_acc[g.nodes[s].a] == 1) { bin = g.nodes[s].a; y = g.nodes[s].b; }
+                    else if (bit_acc[g.nodes[s].b] == 1) { bin = g.nodes[s].b; y = g.nodes[s].a; }
+                }
+                if (canon(x) && canon(y)) {
+                    for (uint32_t q = first_user[n.a]; q < first_user[n.a + 1]; ++q) {
+                        const uint32_t u = user_list[q];
+                        const Node& D = g.nodes[u];
+                        if (u == j || taken[u] || D.kind != N_TRES || D.a != n.a || rep[u] != REP_C) continue;
+                        const uint32_t arm_then = cond_is_geq ? D.b : D.c, arm_else = cond_is_geq ? D.c : D.b;
+                        Fr e0, e1;
+                        if (!matches_difference(expand(arm_then, x, y, bin), x, y, bin, e0) || !u256_is_zero(e0)) continue;
+                        if (!matches_difference(expand(arm_else, x, y, bin), x, y, bin, e1)) continue;
+                        const int nbits = pow2_value(e1);
+                        if (nbits < 1 || nbits > 253) continue;
+                        steps.push_back(Step{u, (uint32_t)j, x, bin == NONE ? x : bin, y, (uint32_t)nbits, (uint8_t)(SCAN_OP_BORROW | (bin == NONE ? SCAN_OP_NOACC : 0))});
+                        taken[u] = taken[j] = 1;
+                        bit_acc[j] = 1;
+                        break;
+                    }
+                }
+                if (taken[j]) continue;
+            }
+        }
+        // ---- LEX: outer = Tern(c1, K1, inner), inner = Tern(c2, K2, acc), c1 / c2 the two strict comparisons of one pair (x, y)
+        if (kb >= 0 && g.nodes[n.c].kind == N_TRES && !taken[n.c] && uses[n.c] == 1 && !wit_uses[n.c] && rep[n.c] == rep[j]) {
+            const Node& I = g.nodes[n.c];
+            const int k2 = const_small(I.b);
+            const bool c1_ok = is_cmp(n.a, OP_GT) || is_cmp(n.a, OP_LT), c2_ok = is_cmp(I.a, OP_GT) || is_cmp(I.a, OP_LT);
+            if (k2 >= 0 && c1_ok && c2_ok) {
+                ++cand_lex;
+                const Node &C1 = g.nodes[n.a], &C2 = g.nodes[I.a];
+                const uint32_t x = C1.a, y = C1.b;
+                const int rel1 = C1.op == OP_GT ? 1 : -1;
+                int rel2 = 0;
+                if (C2.a == x && C2.b == y) rel2 = C2.op == OP_GT ? 1 : -1;
+                else if (C2.a == y && C2.b == x) rel2 = C2.op == OP_GT ? -1 : 1;
+                const int a0 = const_small(I.c);
+                // the bit coming in: a constant 0 / 1, an earlier step's, or any boolean of the chain's form (a comparison's result, a selection
+                // between 0 and 1 -- what is left of a chain's first step `x > y ? 1 : (x < y ? 0 : 0)` behind the load-time optimiser)
+                auto boolean_node = [&](uint32_t o) {
+                    const Node& b = g.nodes[o];
+                    if (b.kind == N_TRES) return const_small(b.b) >= 0 && const_small(b.c) >= 0;
+                    return b.kind == N_DUO && b.op >= OP_EQ && b.op <= OP_LOR;
+                };
+                const bool acc_ok = a0 >= 0 || ((bit_acc[I.c] == 2 || boolean_node(I.c)) && rep[I.c] == rep[j]);
+                if (rel2 && rel2 != rel1 && x != y && canon(x) && canon(y) && acc_ok) {
+                    const int kg = rel1 > 0 ? kb : k2, kl = rel1 > 0 ? k2 : kb;
+                    const uint8_t op = (uint8_t)(SCAN_OP_LEX | (kg ? SCAN_OP_KG : 0) | (kl ? SCAN_OP_KL : 0) | (a0 == 0 ? SCAN_OP_NOACC : 0));
+                    // (the chain's bits travel in the form representation inference gave the selections: the canonical 0 / 1, or -- selections
+                    // between constants default to it -- the Montgomery form 0 / 2^256 mod r; a bundle's steps share it: imm = 1)
+                    steps.push_back(Step{n.c, (uint32_t)j, x, a0 == 0 ? x : I.c, y, rep[j] == REP_M ? 1u : 0u, op});
+                    taken[n.c] = taken[j] = 1;
+                    bit_acc[j] = 2;
+                }
+            }
+        }
+    }
+    if (getenv("CWC_DEBUG_SCAN")) {
+        size_t nb = 0;
+        for (const Step& st : steps) nb += (st.op & SCAN_OP_BORROW) != 0;
+        fprintf(stderr, "bit scans: %zu borrow candidates, %zu comparison candidates; steps: %zu borrow, %zu comparison\n", cand_borrow, cand_lex, nb, steps.size() - nb);
+    }
+    if (steps.empty()) return;
+    for (const Step& st : steps) {
+        g.nodes[st.out] = Node{N_SCAN, st.op, st.x, st.acc_in, st.y};
+        g.nodes[st.acc] = Node{N_SCAN, (uint8_t)(st.op | SCAN_OP_ACC), st.x, st.acc_in, st.y};
+        vflags[st.out] = vflags[st.acc] = 0;
+        scan_imm[st.out] = scan_imm[st.acc] = st.imm;
+        scan_partner[st.out] = st.acc;
+        scan_partner[st.acc] = st.out;
+    }
+    n_steps += steps.size();
+    // sweep: pure nodes that nothing reads any more (the arms, the conditions, the sums under them); a step's nodes stay as a pair
+    std::vector<uint32_t> live_uses(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+        const Node& n = g.nodes[i];
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) live_uses[ops[q]]++;
+    }
+    for (uint32_t w : g.witness_signals) live_uses[w]++;
+    std::vector<uint8_t> dead(N, 0);
+    bool any_dead = false;
+    for (size_t i = N; i-- > 0;) {
+        const Node& n = g.nodes[i];
+        if (live_uses[i]) continue;
+        bool pure = false;
+        if (n.kind == N_UNO || n.kind == N_TRES) pure = true;
+        else if (n.kind == N_DUO) pure = n.op != OP_SHL && n.op != OP_BOR && n.op != OP_BXOR && n.op != OP_BAND;  // (what the load-time optimiser keeps as able to report, optimize.cc can_fail)
+        if (!pure) continue;
+        dead[i] = 1;
+        any_dead = true;
+        const uint32_t ops[3] = {n.a, n.b, n.c};
+        for (int q = 0; q < arity_of(n); ++q) live_uses[ops[q]]--;
+    }
+    if (any_dead) compact_dead(g, dead, rep, vflags, scan_imm, scan_partner);
+}
+
 // ---- limb products as convolutions (round 4) -----------------------------------------------------------------------------
 // A schoolbook product of two k-limb integers is k^2 limb products and, per column c, the sum of the products with
 // i + j = c: in the 10.5 M-node bigint-class graph 16 full bundles of canonical products and a tree of ~19 Add bundles per
@@ -846,7 +1091,7 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
         const Node& n = g.nodes[i];
         if (any_width) return true;
         if (n.kind == N_CONST) return const_bits(i) <= 64;
-        if (n.kind == N_SCAN) return !(n.op & (SCAN_OP_DIV | SCAN_OP_ACC)) && scan_imm[i] <= 64;
+        if (n.kind == N_SCAN) return !(n.op & (SCAN_OP_DIV | SCAN_OP_ACC | SCAN_OP_BORROW | SCAN_OP_LEX)) && scan_imm[i] <= 64;  // (the limb a carry step leaves: t mod 2^n)
         if (n.kind == N_DUO && n.op == OP_BAND) return (g.nodes[n.a].kind == N_CONST && const_bits(n.a) <= 64) || (g.nodes[n.b].kind == N_CONST && const_bits(n.b) <= 64);
         return false;
     };

@@ -52,6 +52,23 @@ __device__ __forceinline__ void scan_carry_rounds(uint32_t iters, uint32_t bs, c
     for (int k = 0; k < 4; ++k) carry[k] = c[k];
 }
 
+// One-bit recurrence over the pairs of a scan bundle, every segment at once: c_out = gen | (prop & c_in) with c_in = 0 where a
+// segment starts (`st`).  Lanes of set t = lane mod T; per pair the OUT lanes carry a gate bit (0 at a segment's start), the ACC
+// lanes the generate / propagate bits, and ONE 64-bit integer addition on the scalar unit ripples the carries through them
+// (carries into every bit = (a + b) ^ a ^ b).  Returns the carry INTO the lane's pair (the same in its OUT and ACC lanes).
+template <int T>
+__device__ __forceinline__ uint32_t scan_bit_lookahead(bool st, bool gen, bool prop, uint32_t lane) {
+    constexpr uint64_t OUT_LANES = T == 1 ? 0x5555555555555555ull : 0x3333333333333333ull;
+    const uint64_t b_gate = __ballot(!st) & OUT_LANES, b_pg = __ballot(gen || prop) & ~OUT_LANES, b_g = __ballot(gen) & ~OUT_LANES;
+    uint64_t cbits = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint64_t lt = T == 1 ? ~0ull : (t == 0 ? 0x5555555555555555ull : 0xAAAAAAAAAAAAAAAAull);
+        const uint64_t a = ((b_gate | b_pg) & lt) | ~lt, bb = b_g & lt;
+        cbits |= ((a + bb) ^ a ^ bb) & lt;
+    }
+    return (uint32_t)(cbits >> (lane | (uint32_t)T)) & 1u;
+}
 // Parallel forms of the two recurrences for 64-bit limbs (n = k = 64), a bundle's chain segments all at once instead of round by
 // round.  `st`: the lane's pair starts a segment (START, or an idle pair); values are the same in both lanes of a pair.
 // Carry chain.  X = sum x_p B^p (B = 2^64, a segment's incoming accumulator added to its first x), every x_p < 2^192 as three
@@ -81,17 +98,7 @@ __device__ __forceinline__ void scan_carry_parallel(bool st, uint32_t lane, cons
     const uint32_t w_sh = wave_shr_lanes<D>(w), wp = st ? 0u : w_sh;
     const uint64_t z = lo2 + wp;
     const bool gen = z < lo2, prop = z == ~0ull;
-    // lookahead: lanes of set t = lane mod T; OUT lanes carry the gate, ACC lanes generate / propagate
-    constexpr uint64_t OUT_LANES = T == 1 ? 0x5555555555555555ull : 0x3333333333333333ull;
-    const uint64_t b_gate = __ballot(!st) & OUT_LANES, b_pg = __ballot(gen || prop) & ~OUT_LANES, b_g = __ballot(gen) & ~OUT_LANES;
-    uint64_t cbits = 0;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const uint64_t lt = T == 1 ? ~0ull : (t == 0 ? 0x5555555555555555ull : 0xAAAAAAAAAAAAAAAAull);
-        const uint64_t a = ((b_gate | b_pg) & lt) | ~lt, bb = b_g & lt;
-        cbits |= ((a + bb) ^ a ^ bb) & lt;
-    }
-    const uint32_t cin = (uint32_t)(cbits >> (lane | (uint32_t)T)) & 1u;  // the carry into the pair's ACC lane of this set
+    const uint32_t cin = scan_bit_lookahead<T>(st, gen, prop, lane);  // the carry into the pair's ACC lane of this set
     const uint64_t dgt = z + cin;
     const uint32_t cout = (gen || (prop && cin)) ? 1u : 0u;
     limb[0] = (uint32_t)dgt;

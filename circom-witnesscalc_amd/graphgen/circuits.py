@@ -965,3 +965,137 @@ def build_limb_chains(n_bits=64, k_bits=64, steps=10, chains=2, mask_inputs=Fals
             b.signal(b.op("Idiv", t, ds[ch]))
             rem = b.signal(b.op("Mod", t, ds[ch]))
     return b
+
+
+# ---- zk-email RSA / long_div-class (BASELINE config 5's named class) -------------------------------------------------------
+# The reference front-end cannot compile such circuits at this commit (README.md:21: "we plan to add support ... long_div"), so
+# the graph can only be synthetic.  What is restated here are the PUBLIC witness-hint algorithms of circom-bigint as zk-email's
+# RSA verifier uses them (bigint_func.circom: long_scalar_mult, long_sub, long_gt, short_div_norm, short_div, long_div, and the
+# schoolbook product with `% 2^n` / `\ 2^n` carries; fp.circom FpMul: q, r <-- long_div(a * b, p) with Num2Bits range checks),
+# laid out as a symbolic executor would emit them node by node: every circom `var` expression is one Op node in source
+# order with no algebraic simplification (`0 + x` stays an Add node, as in the reference, whose `propagate` only folds
+# operations on two constants, graph.rs:394-428), and every signal-dependent branch is predicated -- both arms are ordinary
+# earlier nodes and a TernCond selects (what the reference does for the branches it supports):
+#     if (c) { v = A } else { v = B }                           ->  v = TernCond(c, A, B)
+#     for (i = k-1 .. 0) { if (a[i] > b[i]) return 1; if (a[i] < b[i]) return 0; } return 0
+#                                                               ->  res = 0; for i = 0 .. k-1: res = TernCond(a[i] > b[i], 1, TernCond(a[i] < b[i], 0, res))
+# Loop-invariant calls (the normalisation of the divisor in short_div: `scale`, `norm_b`) appear once, as they do behind the
+# reference's value numbering (graph.rs:540-578), which every reference-built `.bin` has been through.
+def _lsm(b, n_base, kk, a, bb, zero):
+    """long_scalar_mult(n, kk, a, bb) -> kk + 1 registers: temp = out[i] + a * bb[i]; out[i] = temp % 2^n; out[i+1] = out[i+1] + temp \\ 2^n"""
+    out = [zero] * (kk + 1)
+    for i in range(kk):
+        temp = b.add(out[i], b.mul(a, bb[i]))
+        out[i] = b.op("Mod", temp, n_base)
+        out[i + 1] = b.add(out[i + 1], b.op("Idiv", temp, n_base))
+    return out
+
+
+def _long_gt(b, kk, x, y, zero, one):
+    """long_gt(n, kk, x, y): 1 iff x > y as kk-register integers (most significant differing register decides)"""
+    res = zero
+    for i in range(kk):
+        res = b.tern(b.op("Gt", x[i], y[i]), one, b.tern(b.op("Lt", x[i], y[i]), zero, res))
+    return res
+
+
+def _long_sub(b, n_base, kk, x, y, zero, one):
+    """long_sub(n, kk, x, y) -> kk registers of x - y (x >= y), borrow chain as the function's if / else per register"""
+    diff, borrow = [], None
+    for i in range(kk):
+        if i == 0:
+            c = b.op("Geq", x[i], y[i])
+            d_then = b.sub(x[i], y[i])
+            d_else = b.add(b.sub(x[i], y[i]), n_base)
+        else:
+            c = b.op("Geq", x[i], b.add(y[i], borrow))
+            d_then = b.sub(b.sub(x[i], y[i]), borrow)
+            d_else = b.sub(b.sub(b.add(n_base, x[i]), y[i]), borrow)
+        diff.append(b.tern(c, d_then, d_else))
+        borrow = b.tern(c, zero, one)
+    return diff
+
+
+def _short_div_norm(b, n_base, n_max, kk, a, bb, zero, one, two):
+    """short_div_norm(n, kk, a[kk+1], bb[kk]): the quotient digit from the two leading registers, corrected at most twice"""
+    qhat = b.op("Idiv", b.add(b.mul(a[kk], n_base), a[kk - 1]), bb[kk - 1])
+    qhat = b.tern(b.op("Gt", qhat, n_max), n_max, qhat)
+    mult = _lsm(b, n_base, kk, qhat, bb, zero)
+    g1 = _long_gt(b, kk + 1, mult, a, zero, one)
+    mult2 = _long_sub(b, n_base, kk + 1, mult, list(bb) + [zero], zero, one)
+    g2 = _long_gt(b, kk + 1, mult2, a, zero, one)
+    return b.tern(b.op("Eq", g1, one), b.tern(b.op("Eq", g2, one), b.sub(qhat, two), b.sub(qhat, one)), qhat)
+
+
+def build_rsa_long_div_class(n=121, k=17, muls=2, range_checks=True, seed="rsa"):
+    """zk-email RSA / long_div-class graph: a chain of `muls` modular multiplications out = a * b mod p on k registers of n
+    bits (RSA-2048: n = 121, k = 17), in the pattern of x^65537 (sixteen squarings, then a multiplication by x, repeated).
+    Per multiplication, as fp.circom's FpMul computes its witness:
+      * the 2k-register product: schoolbook columns (Mul, Add), then the carry chain col % 2^n, col \\ 2^n   (Mod, Idiv)
+      * (q, r) = long_div(n, k, k, product, p): k + 1 quotient digits, each a short_div -- normalise (long_scalar_mult by
+        scale = 2^n \\ (1 + p[k-1])), estimate from the two leading registers (Idiv of a 2n-bit by an n-bit value), multiply
+        back (long_scalar_mult), compare (long_gt) and correct (long_sub, long_gt) -- then remainder -= digit * p << (n i)
+        (long_scalar_mult, long_sub over all 2k registers)
+      * q[i], r[i] as witness signals, each with its Num2Bits(n) range check's bit signals ((v >> j) & 1) when range_checks.
+    Inputs: x[k], p[k] -- any field elements; they are masked to n bits (what the circuit's range checks would constrain),
+    and p's leading register is brought into [2^(n-10), 2^(n-9)) like the 112-bit leading register of a 2048-bit modulus.
+    Values of a consistent input (x, p as above) stay far below r; nothing in the graph can fail (Idiv / Mod by 0 give 0).
+    Node count ~ muls * (1 330 (k + 1) k ... ) -- measured: n=121, k=17: ~23.9 k operations per multiplication + 8.2 k of range checks."""
+    b = Builder()
+    x_in = b.input("base", k)
+    p_in = b.input("modulus", k)
+    n_base, n_max, mask = b.const(1 << n), b.const((1 << n) - 1), b.const((1 << n) - 1)
+    zero, one, two = b.const(0), b.const(1), b.const(2)
+    x = [b.signal(b.op("Band", v, mask)) for v in x_in]
+    p = [b.signal(b.op("Band", v, mask)) for v in p_in[:-1]]
+    top_bits = max(n - 10, 1)
+    p.append(b.signal(b.add(b.op("Band", p_in[-1], b.const((1 << top_bits) - 1)), b.const(1 << top_bits))))
+    # short_div's loop invariants (once per graph behind value numbering): scale and the normalised divisor
+    scale = b.op("Idiv", n_base, b.add(one, p[k - 1]))
+    norm_b = _lsm(b, n_base, k, scale, p, zero)  # k + 1 registers
+
+    def short_div(a):
+        norm_a = _lsm(b, n_base, k + 1, scale, a, zero)  # k + 2 registers
+        wide = _short_div_norm(b, n_base, n_max, k + 1, norm_a, norm_b, zero, one, two)
+        narrow = _short_div_norm(b, n_base, n_max, k, norm_a, norm_b[:k], zero, one, two)
+        return b.tern(b.op("Neq", norm_b[k], zero), wide, narrow)
+
+    def long_div(a):  # a: 2k registers -> (k + 1 quotient digits, k remainder registers)
+        m = k
+        rem = list(a)
+        quo = [None] * (m + 1)
+        for i in range(m, -1, -1):
+            dividend = ([rem[j + m] for j in range(k)] + [zero]) if i == m else [rem[j + i] for j in range(k + 1)]
+            quo[i] = short_div(dividend)
+            mult_shift = _lsm(b, n_base, k, quo[i], p, zero)
+            subtrahend = [zero] * (m + k)
+            for j in range(k + 1):
+                if i + j < m + k:
+                    subtrahend[i + j] = mult_shift[j]
+            rem = _long_sub(b, n_base, m + k, rem, subtrahend, zero, one)
+        return quo, rem[:k]
+
+    def fp_mul(u, v):
+        cols = [None] * (2 * k - 1)
+        for i in range(k):
+            for j in range(k):
+                pr = b.mul(u[i], v[j])
+                cols[i + j] = pr if cols[i + j] is None else b.add(cols[i + j], pr)
+        carry, prod = zero, []
+        for c in range(2 * k - 1):
+            t = b.add(cols[c], carry)
+            prod.append(b.op("Mod", t, n_base))
+            carry = b.op("Idiv", t, n_base)
+        prod.append(carry)
+        quo, rem = long_div(prod)
+        for v_ in quo[:k] + rem:          # q[i] <-- ..., r[i] <-- ... and their range checks
+            b.signal(v_)
+            if range_checks:
+                for j in range(n):
+                    b.signal(b.op("Band", b.op("Shr", v_, b.const(j)), one))
+        return rem
+
+    acc = x
+    for s in range(muls):
+        acc = fp_mul(acc, x if s % 17 == 16 else acc)
+    return b

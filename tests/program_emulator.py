@@ -35,6 +35,8 @@ COOP_LANES, COOP_MAX_T = 4, 4
 HDR_MUL_CC = 1 << 13
 OFF_NOWHERE = 0xFFFF0000
 SCAN_MAX_T, HDR_SCAN_DIV, HDR_SCAN_CONV, HDR_SCAN_SHIFT_SHIFT, HDR_SCAN_ITER_SHIFT, SCAN_ROLE_ACC, SCAN_START = 2, 1 << 11, 1 << 12, 19, 27, 1, 2
+# one-bit recurrences (round 5): borrow chain of a register-wise subtraction, most-significant-difference comparison with its two result bits
+HDR_SCAN_BORROW, HDR_SCAN_LEX, HDR_SCAN_KG, HDR_SCAN_KL = 1 << 13, 1 << 14, 1 << 15, 1 << 16
 
 
 def blob_checksum(body):
@@ -112,7 +114,7 @@ def run(blob: Blob, inputs_row):
     # once, before the post, and the read is issued behind the wait.
     post_at = None
     for b in range(blob.stream_first[0], blob.stream_first[0] + blob.stream_count[0]):
-        if blob.hdr[b] & HDR_POST:
+        if blob.hdr[b] & HDR_POST and CLASS_NAMES[blob.hdr[b] & 0xF] != "SCAN":  # (bits 11-18 of a scan bundle's header are its own)
             assert post_at is None
             post_at = b
     assert (post_at is not None) == (blob.n_streams > 1)
@@ -153,6 +155,9 @@ def run(blob: Blob, inputs_row):
         h = blob.hdr[b]
         cls, cnt = h & 0xF, (h >> 4) & 0x7F
         name = CLASS_NAMES[cls]
+        h_scan = h
+        if name == "SCAN":
+            h &= ~0x7F800  # bits 11-18 of a scan bundle's header are its own (kind, result bits): the checks of the common bits skip them
         assert (h >> 19 == 0 or name == "SCAN") and (1 <= cnt <= G or (cnt == 0 and name in ("LIN", "SYNC")))
         assert (name == "SYNC") == bool(h & (HDR_POST | HDR_WAIT)) and not (name == "SYNC" and cnt)
         a_canon, b_canon, out_canon = bool(h & HDR_A_CANON), bool(h & HDR_B_CANON), bool(h & HDR_OUT_CANON)
@@ -187,6 +192,7 @@ def run(blob: Blob, inputs_row):
             assert 1 <= b - wb <= RING_BUNDLES, "ring cell too old"
             return val
         if name == "SCAN":
+            h = h_scan
             # The steps of serial limb recurrences in consecutive pairs of positions, chain segments one behind the other: a
             # step takes the accumulator of the pair in front of it unless its START bit says "my own operand".  All values
             # are canonical integers; the arithmetic is the unfused nodes' (x + acc, Band / Shr; acc * 2^k + x, Idiv / Mod).
@@ -208,7 +214,10 @@ def run(blob: Blob, inputs_row):
                 assert all(v < model.M for v in xs + ys)
                 for c in range(cnt):
                     results.append((dsts[c], sum(xs[i] * ys[c - i] for i in range(k) if 0 <= c - i < k) % model.M))
-            assert is_conv or (cnt % 2 == 0 and (h & 0x7F000) == 0 and sh < 254)
+            is_borrow, is_lex = bool(h & HDR_SCAN_BORROW), bool(h & HDR_SCAN_LEX)
+            assert is_conv or (cnt % 2 == 0 and (h & 0x61000) == 0 and sh < 254 and is_div + is_borrow + is_lex <= 1)
+            assert is_lex or not (h & (HDR_SCAN_KG | HDR_SCAN_KL))
+            assert not is_lex or sh <= 1  # (1: the chain's bits are Montgomery-form booleans)
             acc, seg, longest = None, 0, 0
             for pr in range(0 if is_conv else cnt // 2):
                 ro = blob.recs[(b * G + 2 * pr) * 4:(b * G + 2 * pr) * 4 + 4]
@@ -228,10 +237,25 @@ def run(blob: Blob, inputs_row):
                     assert bm == (1 << sh) * R_MONT % model.M, "the base operand is 2^k in Montgomery form"
                     t = (acc * (1 << sh) + x) % model.M
                     out, acc = (t // d, t % d) if d else (0, 0)
+                elif is_borrow or is_lex:
+                    y = fetch(ra[0], ra[3] & 0xFFFF, 0, 2 * pr + 1)
+                    one_bit = R_MONT if is_lex and sh else 1
+                    assert ra[1] == zero_off and y < model.M and (acc in (0, one_bit) or (co & SCAN_START and acc in (0, 1))), "the accumulators of the one-bit recurrences are bits"
+                    acc = 1 if acc else 0
+                    if is_borrow:  # the unfused nodes' arithmetic: s = y + bin; c = x >= s (signed, graph.rs:133); the two arms in the field
+                        c = model.eval_duo("Geq", x, (y + acc) % model.M)
+                        out, acc = ((x - y - acc) % model.M if c else (x - y - acc + (1 << sh)) % model.M), (0 if c else 1)
+                    else:
+                        gt, lt = model.eval_duo("Gt", x, y), model.eval_duo("Lt", x, y)
+                        out = None  # (the inner selection: read by nothing)
+                        acc = ((1 if h & HDR_SCAN_KG else 0) if gt else (1 if h & HDR_SCAN_KL else 0) if lt else acc) * one_bit
                 else:
                     assert ra[0] == zero_off and ra[1] == zero_off
                     t = (x + acc) % model.M
                     out, acc = t & ((1 << sh) - 1), t >> sh
+                if out is None:
+                    assert (ro[2] & ~CTRL_MASK) == trash, "a comparison step's OUT value has no slot"
+                    out = 0
                 results.append((ro[2] & ~CTRL_MASK, out))
                 results.append((ra[2] & ~CTRL_MASK, acc))
             assert is_conv or iters == longest, "the iteration count is the longest chain segment"
