@@ -422,6 +422,7 @@ class Graph:
         res = {n: tuple(int(x) for x in out[4 * i:4 * i + 4]) for i, n in enumerate(names)}
         res["MULF"] = tuple(int(x) for x in out[64:68])
         res["SCAN"] = tuple(int(x) for x in out[68:72])
+        res["_scan_kinds"] = {k: tuple(int(x) for x in out[72 + 4 * i:76 + 4 * i]) for i, k in enumerate(("carry", "division", "convolution", "borrow", "comparison"))}
         res["_sections"] = {"MUL": tuple(int(x) for x in out[48:54]), "LIN": tuple(int(x) for x in out[56:62])}
         n = int(out[63])
         res["_waves"] = {"n": n, "max_cycles": int(out[54]), "min_cycles": (1 << 40) - int(out[55]) if n else 0,

@@ -372,7 +372,12 @@ extern "C" int gwb_calc_witness_json_to_wtns(gwb_graph_t* g, const char* text, s
             if (drain_err.empty()) drain_err = "hipEventSynchronize failed";
             return;
         }
-        (void)hipMemcpy(st_host.data() + lo, bf.d_st[par], n * 4, hipMemcpyDeviceToHost);
+        // (the status words decide which sets get a file: a failed copy must not read as "every set is fine")
+        if (hipMemcpy(st_host.data() + lo, bf.d_st[par], n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            std::lock_guard<std::mutex> l2(err_mu);
+            if (drain_err.empty()) drain_err = "hipMemcpy of the status words failed";
+            return;
+        }
         // the copy of slice i + 1 is enqueued before the host waits for slice i: the copy engine never idles between slices
         const size_t n_slices = (n + slice_sets - 1) / slice_sets;
         auto issue = [&](size_t i) -> bool {

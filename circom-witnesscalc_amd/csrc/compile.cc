@@ -2,6 +2,8 @@
 // shared subexpressions and dead-node elimination), critical-path list scheduling into same-class bundles (linear riders,
 // request / collect divisions for the divider waves), operand routing (LDS ring vs. staged memory), liveness-based slot
 // allocation, program encoding (format v4) and the pointer-free program blob.  See program.hpp / program_dev.h.
+#include <map>
+
 #include "compile_internal.hpp"
 
 namespace cwc {
@@ -50,7 +52,19 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
     if (const char* e = getenv("CWC_WITNESS_SLOTS")) base.witness_slots = atoi(e) != 0;
     RewriteCache own_cache;
     RewriteCache& cache = shared && T >= 1 && T <= 64 && !(T & (T - 1)) ? shared->cache[__builtin_ctz(T)] : own_cache;
-    if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) return false;
+    if (!compile_variant(g, T, divider, true, base, out, err, &cache, false, streams)) {
+        // A fused form that cannot be scheduled must not fail the graph: the scan / convolution rewrites group nodes into one
+        // bundle, and a grouping the detection should have rejected (a member that depends on another member) shows up as a
+        // scheduler without ready nodes.  The program without convolution bundles, then without any scan chains, is always there.
+        if (err.find("no ready node") == std::string::npos) return false;
+        base.no_conv = true;
+        std::string err2;
+        if (!compile_variant(g, T, divider, true, base, out, err2, &cache, false, streams)) {
+            base.no_scans = true;
+            if (!compile_variant(g, T, divider, true, base, out, err2, &cache, false, streams)) return false;
+        }
+        err.clear();
+    }
     if (quick || getenv("CWC_NO_SCHEDULE_VARIANTS")) return true;  // (quick: the first call on a graph runs this one schedule while the search runs in the background)
     // (one after the other: side by side on two threads the two compiles were no faster, 0.55 s either way for the
     // authV2-class graph, and slower for multi-million-node graphs)
@@ -93,6 +107,7 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
         pol.all_montgomery = base.all_montgomery;
         pol.witness_slots = base.witness_slots;
         pol.no_conv = base.no_conv;
+        pol.no_scans = base.no_scans;
         Program alt;
         std::string err2;
         if (compile_variant(g, T, divider, fusion, pol, alt, err2, &cache, false, streams) && program_wave_cycles(alt) < program_wave_cycles(out)) {
@@ -350,7 +365,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     phase("representation inference");
     // ---- scan chains: the steps of serial limb recurrences as pairs of N_SCAN nodes (class C_SCAN) ----
     std::vector<uint32_t> scan_imm, scan_partner;
-    if (mode2_ok && !getenv("CWC_NO_SCAN")) {
+    if (mode2_ok && !getenv("CWC_NO_SCAN") && !policy.no_scans) {
         detect_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
         // borrow chains / most-significant-difference comparisons of multi-register integers (limb graphs: the step kinds live in the MODE 2 instances)
         if (limb_graph) detect_bit_scans(g, node_rep, node_vflags, scan_imm, scan_partner, st.n_scan_steps);
@@ -1062,6 +1077,35 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
     }
 
     phase("schedule");
+    if (getenv("CWC_DEBUG_NODE_MIX")) {  // diagnostic: what the scheduled graph is made of -- per (class, operation): nodes, and how their operands were produced
+        std::map<std::string, uint64_t> mix;
+        static const char* kOps[] = {"Mul", "Div", "Add", "Sub", "Pow", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land", "Lor", "Shl", "Shr", "Bor", "Band", "Bxor", "BitX"};
+        auto name_of = [&](const Node& n) -> std::string {
+            switch (n.kind) {
+                case N_CONST: return "const";
+                case N_INPUT: return "input";
+                case N_UNO: return "Neg";
+                case N_TRES: return "Tern";
+                case N_FUSED: return "fused";
+                case N_CONV: return "conv";
+                case N_SCAN: return std::string((n.op & SCAN_OP_LEX) ? "lex" : (n.op & SCAN_OP_BORROW) ? "borrow" : (n.op & SCAN_OP_DIV) ? "sdiv" : "carry") + ((n.op & SCAN_OP_ACC) ? ".acc" : ".out");
+                default: return n.op < sizeof kOps / sizeof *kOps ? kOps[n.op] : "?";
+            }
+        };
+        for (size_t i = 0; i < N; ++i) {
+            const Node& n = g.nodes[i];
+            if (n.kind == N_CONST) continue;
+            std::string key = name_of(n) + "(";
+            const uint32_t ops[3] = {n.a, n.b, n.c};
+            for (int q = 0; q < arity_of(n); ++q) key += (q ? ", " : "") + name_of(g.nodes[ops[q]]);
+            mix[key + ")"]++;
+        }
+        std::vector<std::pair<uint64_t, std::string>> v;
+        for (auto& kv : mix) v.push_back({kv.second, kv.first});
+        std::sort(v.rbegin(), v.rend());
+        fprintf(stderr, "node mix of the scheduled graph (T = %u):\n", T);
+        for (size_t k = 0; k < v.size() && k < 60; ++k) fprintf(stderr, "  %8llu  %s\n", (unsigned long long)v[k].first, v[k].second.c_str());
+    }
     // ---- operand routing -------------------------------------------------------------------------------
     // RING: produced at most RING_BUNDLES bundles ago (any node slot) -> read from the wave's result ring in LDS.
     // MEM : everything else (older values, constants, every third operand) -> its slot in the tile, staged into LDS
@@ -1142,6 +1186,23 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
         if (g.nodes[producer].kind == N_CONST) return (uint64_t)(ref[producer] & ~REF_CONST) * slot_bytes;
         return ((uint64_t)NC + ref[producer]) * slot_bytes;
     };
+    // (A DIV step names its constant 2^k only through the side table scan_imm -- the Mul node that read it is gone --, and the general path
+    // multiplies with that constant's Montgomery form: whatever passes run between the rewrite and here must have kept and renumbered it.)
+    for (size_t i = 0; i < N; ++i)
+        if (g.nodes[i].kind == N_SCAN && (g.nodes[i].op & SCAN_OP_DIV)) {
+            const uint32_t c = i < scan_imm.size() ? scan_imm[i] : 0xffffffffu;
+            bool pow2 = c < N && g.nodes[c].kind == N_CONST;
+            if (pow2) {
+                const Fr& v = g.const_values[g.nodes[c].a];
+                int bits = 0;
+                for (int w = 0; w < 8; ++w) bits += __builtin_popcount(v.v[w]);
+                pow2 = bits == 1;
+            }
+            if (!pow2) {
+                err = "internal error: a division step's base is not a constant power of two";
+                return false;
+            }
+        }
     auto scan_shift_of_node = [&](uint32_t i) -> uint32_t {  // CARRY: n; DIV: k of the constant 2^k
         if (!(g.nodes[i].op & SCAN_OP_DIV)) return scan_imm[i];
         const Fr& v = g.const_values[g.nodes[scan_imm[i]].a];

@@ -198,6 +198,7 @@ struct CoopPolicy {
     bool all_montgomery = false;  // no representation inference: every value in Montgomery form
     bool witness_slots = false;   // the slots of witness elements in witness order (see the slot allocation)
     bool no_conv = false;         // schoolbook limb products stay unfused (detect_convolutions off): a competitor where many small blocks run side by side
+    bool no_scans = false;        // no scan chains at all (detect_scans / detect_bit_scans / detect_convolutions off): the fallback when a fused form cannot be scheduled
     uint32_t fuse = 0;            // fused narrow chains (fuse_narrow_chains): 0 off, else 1 + the slack, in thousandths of the critical path, within which nodes are fused; + 0x10000: product + sum nodes only
 };
 }  // namespace cwc

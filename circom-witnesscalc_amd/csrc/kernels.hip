@@ -246,6 +246,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
     unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
     unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67]) / C_SCAN (prof[68], prof[71])
+    unsigned long long pf_scan[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};  // scan bundles by kind: carry, division, convolution, borrow, comparison (prof[72 + 4 k], prof[75 + 4 k])
     if (PROF) {
 #pragma unroll
         for (int c = 0; c < C_PROF; ++c) pf[c][0] = pf[c][1] = 0;
@@ -477,6 +478,13 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 if (MODE == 2 && cls == C_SCAN) {
                     pf_fused[0] += t_now - st0;
                     pf_fused[1] += 1;
+                    const int kind = (h & HDR_SCAN_CONV) ? 2 : (h & HDR_SCAN_BORROW) ? 3 : (h & HDR_SCAN_LEX) ? 4 : (h & HDR_SCAN_DIV) ? 1 : 0;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        if (kind == q) {
+                            pf_scan[q][0] += t_now - st0;
+                            pf_scan[q][1] += 1;
+                        }
                 }
                 if (cls == C_MUL || cls == C_LIN) {
                     unsigned long long* q = psec[cls == C_MUL ? 0 : 1];
@@ -528,6 +536,23 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     const uint32_t hi_a = a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7], hi_b = b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7];
                     if (!wave_any((hi_a | hi_b) != 0u)) {
                         r = limb_product(a_op, b_op);
+                    } else if (!wave_any(((a_op.v[3] | b_op.v[3]) >> 30 | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
+                        // registers wider than a word (round 5: the 121-bit registers of circom-bigint's RSA circuits): factors below 2^126 everywhere in
+                        // the wave multiply as integers, sixteen 32 x 32 multiply-adds; the product is below 2^252 < r, the canonical a * b mod r
+                        uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            uint32_t carry = 0;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const uint64_t t = (uint64_t)a_op.v[i] * b_op.v[jj] + z[i + jj] + carry;
+                                z[i + jj] = (uint32_t)t;
+                                carry = (uint32_t)(t >> 32);
+                            }
+                            z[i + 4] = carry;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) r.v[k] = z[k];
                     } else {
                         // small NEGATIVE factors (r - y with y < 2^64: the -1 of a bit circuit's 1 - 2b, a difference of bits): (-x) * y = -(x * y)
                         Fr na, nb;
@@ -624,7 +649,18 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             // acc' = x > y ? KG : x < y ? KL : acc (graph.rs:130-131, 221-225): generate = the registers differ and the winner's
                             // constant is 1, propagate = they are equal
                             const uint32_t kg = (h & HDR_SCAN_KG) ? 1u : 0u, kl = (h & HDR_SCAN_KL) ? 1u : 0u;
-                            const bool lt = active && signed_lt(x, y), gt = active && signed_lt(y, x);
+                            bool lt, gt;
+                            if (!wave_any(active && (x.v[4] | x.v[5] | x.v[6] | x.v[7] | y.v[4] | y.v[5] | y.v[6] | y.v[7]) != 0u)) {
+                                // registers below 2^128 everywhere in the wave: non-negative, one four-word subtraction decides
+                                uint32_t d[4], bw = 0;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) d[k] = sbb32(x.v[k], y.v[k], bw);
+                                lt = active && bw != 0u;
+                                gt = active && bw == 0u && (d[0] | d[1] | d[2] | d[3]) != 0u;
+                            } else {
+                                lt = active && signed_lt(x, y);
+                                gt = active && signed_lt(y, x);
+                            }
                             const bool gen = (gt && kg) || (lt && kl), prop = active && !gt && !lt;
                             const uint32_t cin = scan_bit_lookahead<T>(seg, gen || (seg && prop && a0), prop, lane);
                             const uint32_t bin = seg ? a0 : cin;
@@ -692,9 +728,34 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             uint32_t cy = 0;
 #pragma unroll
                             for (int k = 0; k < 8; ++k) xp[k] = adc32(active ? x.v[k] : 0u, start && active ? acc0.v[k] : 0u, cy);
-                            xp[7] |= cy;
+                            xp[7] |= cy << 31;  // (x + acc at or above 2^256: outside every parallel form)
                         }
-                        if (sh == 64u && iters > 2u && !wave_any((xp[6] | xp[7]) != 0u)) {
+                        // registers of any width up to 126 bits (round 5): x (+ the accumulator coming in) below min(2^(3n), 2^252) everywhere in the wave
+                        bool wide_ok = sh != 64u && sh >= 2u && sh <= 126u && iters > 2u;
+                        if (wide_ok) {
+                            const Fr xpf = Fr{{xp[0], xp[1], xp[2], xp[3], xp[4], xp[5], xp[6], xp[7]}};
+                            if (3u * sh >= 252u) {  // (registers of 84 bits and more: the bound is 2^252)
+                                wide_ok = !wave_any((xp[7] >> 28) != 0u);
+                            } else {
+                                const uint32_t top = 3u * sh;
+                                uint32_t hi_or = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) hi_or |= xp[k] & ~(top >= 32u * (k + 1) ? 0xffffffffu : top > 32u * k ? (1u << (top - 32u * k)) - 1u : 0u);
+                                wide_ok = !wave_any(hi_or != 0u);
+                            }
+                            if (wide_ok) {
+                                Fr limb, carry;
+                                switch (sh >> 5) {  // (the word part of the width as a template parameter: shifts with fixed register positions)
+                                    case 0: scan_carry_parallel_wide<T, 0>(seg, lane, sh, xpf, limb, carry); break;
+                                    case 1: scan_carry_parallel_wide<T, 1>(seg, lane, sh, xpf, limb, carry); break;
+                                    case 2: scan_carry_parallel_wide<T, 2>(seg, lane, sh, xpf, limb, carry); break;
+                                    default: scan_carry_parallel_wide<T, 3>(seg, lane, sh, xpf, limb, carry); break;
+                                }
+                                r = u256_select(role_acc, carry, limb);
+                            }
+                        }
+                        if (wide_ok) {
+                        } else if (sh == 64u && iters > 2u && !wave_any((xp[6] | xp[7]) != 0u)) {
                             const uint32_t xw[6] = {xp[0], xp[1], xp[2], xp[3], xp[4], xp[5]};
                             uint32_t limb[2], carry[6];
                             scan_carry_parallel<T>(seg, lane, xw, limb, carry);
@@ -1018,6 +1079,13 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         }
         atomicAdd(&prof[MODE == 2 ? 68 : 64], pf_fused[0]);  // C_MULF / C_SCAN
         atomicAdd(&prof[MODE == 2 ? 71 : 67], pf_fused[1]);
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                atomicAdd(&prof[72 + 4 * q], pf_scan[q][0]);
+                atomicAdd(&prof[75 + 4 * q], pf_scan[q][1]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll

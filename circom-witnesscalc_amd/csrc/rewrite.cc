@@ -932,6 +932,58 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
                 if (taken[j]) continue;
             }
         }
+        // ---- BORROW, last register: the borrow that leaves is read by nothing, so its selection is gone (the load-time optimiser's sweep) and
+        // only diff = Tern(x >= s, x - y - bin, x - y - bin + 2^n) is there.  The comparison, read by nothing else, becomes the step's ACC node.
+        if (g.nodes[n.a].kind == N_DUO && rep[j] == REP_C && uses[n.a] == 1 && !wit_uses[n.a] && !taken[n.a]) {
+            const Node& C = g.nodes[n.a];
+            uint32_t x = NONE, s = NONE;
+            bool cond_is_geq = true;
+            if (C.op == OP_GEQ) { x = C.a; s = C.b; }
+            else if (C.op == OP_LEQ) { x = C.b; s = C.a; }
+            else if (C.op == OP_LT) { x = C.a; s = C.b; cond_is_geq = false; }
+            else if (C.op == OP_GT) { x = C.b; s = C.a; cond_is_geq = false; }
+            if (x != NONE) {
+                uint32_t y = s, bin = NONE;
+                if (bit_acc[s] == 1) { bin = s; y = NONE; }
+                else if (g.nodes[s].kind == N_DUO && g.nodes[s].op == OP_ADD) {
+                    if (bit_acc[g.nodes[s].a] == 1) { bin = g.nodes[s].a; y = g.nodes[s].b; }
+                    else if (bit_acc[g.nodes[s].b] == 1) { bin = g.nodes[s].b; y = g.nodes[s].a; }
+                }
+                // (y = 0: the constant 0 is named through the chain's earlier step, whose selection held one -- a chain of one register is left alone)
+                if (y == NONE && bin != NONE) {
+                    const Node& pb = g.nodes[bin];  // (still the Tern(c, 0, 1) / Tern(c, 1, 0) it was recognised as: rewritten behind this loop)
+                    y = const_small(pb.b) == 0 ? pb.b : pb.c;
+                }
+                if (bin != NONE && y != NONE && canon(x) && canon(y)) {
+                    const uint32_t arm_then = cond_is_geq ? n.b : n.c, arm_else = cond_is_geq ? n.c : n.b;
+                    Fr e0, e1;
+                    if (matches_difference(expand(arm_then, x, y, bin), x, y, bin, e0) && u256_is_zero(e0) && matches_difference(expand(arm_else, x, y, bin), x, y, bin, e1)) {
+                        const int nbits = pow2_value(e1);
+                        if (nbits >= 1 && nbits <= 253) {
+                            ++cand_borrow;
+                            steps.push_back(Step{(uint32_t)j, n.a, x, bin, y, (uint32_t)nbits, (uint8_t)SCAN_OP_BORROW});
+                            taken[j] = taken[n.a] = 1;
+                            bit_acc[n.a] = 1;
+                            continue;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- LEX, first register: `x > y ? K1 : K0` is what the load-time optimiser leaves of `x > y ? K1 : (x < y ? K0 : K0)`: a step whose bit
+        // coming in is the constant K0.  The comparison, read by nothing else, becomes the step's OUT node (read by nothing).
+        if (kb >= 0 && kc >= 0 && (is_cmp(n.a, OP_GT) || is_cmp(n.a, OP_LT)) && uses[n.a] == 1 && !wit_uses[n.a] && !taken[n.a]) {
+            const Node& C1 = g.nodes[n.a];
+            if (C1.a != C1.b && canon(C1.a) && canon(C1.b)) {
+                ++cand_lex;
+                const int kg = C1.op == OP_GT ? kb : kc, kl = C1.op == OP_GT ? kc : kb;
+                const uint8_t op = (uint8_t)(SCAN_OP_LEX | (kg ? SCAN_OP_KG : 0) | (kl ? SCAN_OP_KL : 0) | (kc == 0 ? SCAN_OP_NOACC : 0));
+                steps.push_back(Step{n.a, (uint32_t)j, C1.a, kc == 0 ? C1.a : n.c, C1.b, rep[j] == REP_M ? 1u : 0u, op});
+                taken[n.a] = taken[j] = 1;
+                bit_acc[j] = 2;
+                continue;
+            }
+        }
         // ---- LEX: outer = Tern(c1, K1, inner), inner = Tern(c2, K2, acc), c1 / c2 the two strict comparisons of one pair (x, y)
         if (kb >= 0 && g.nodes[n.c].kind == N_TRES && !taken[n.c] && uses[n.c] == 1 && !wit_uses[n.c] && rep[n.c] == rep[j]) {
             const Node& I = g.nodes[n.c];
@@ -1164,6 +1216,38 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
             for (size_t j = 0; j < k && ok; ++j) ok = adj[Y[j]].size() == k;
             for (size_t c = 0; c < 2 * k - 1 && ok; ++c)
                 for (size_t c2 = 0; c2 < c && ok; ++c2) ok = col_root[c] != col_root[c2];
+            if (!ok) continue;
+            // No factor may depend on the block itself: the bundle needs every x_i, y_j up front, and a factor computed from one of the
+            // block's own products or column sums (x_1 = x_0 y_0 mod 2^64, say) would wait for the bundle that waits for it.  Walk up from
+            // the factors; only nodes behind the block's first product can depend on it (operands precede their users).
+            {
+                uint32_t first_prod = NONE;
+                for (uint32_t p : prods) first_prod = std::min(first_prod, p);
+                std::vector<uint32_t> stack, block;  // the block: its products and the sums above them up to the roots
+                for (uint32_t p : prods)
+                    for (uint32_t i = p;; i = user[i]) {
+                        block.push_back(i);
+                        if (i == root_of[p]) break;
+                    }
+                std::sort(block.begin(), block.end());
+                block.erase(std::unique(block.begin(), block.end()), block.end());
+                auto in_block = [&](uint32_t i) { return std::binary_search(block.begin(), block.end(), i); };
+                std::vector<uint32_t> seen;
+                for (uint32_t f : X) stack.push_back(f);
+                for (uint32_t f : Y) stack.push_back(f);
+                size_t visited = 0;
+                while (!stack.empty() && ok && !getenv("CWC_CONV_SKIP_DEPENDENCY_CHECK")) {  // (the knob: tests of compile_program's fallback)
+                    const uint32_t i = stack.back();
+                    stack.pop_back();
+                    if (i < first_prod || g.nodes[i].kind == N_CONST) continue;
+                    if (in_block(i) || ++visited > 100000) { ok = false; break; }  // (a walk that does not end is treated like a dependency)
+                    if (std::find(seen.begin(), seen.end(), i) != seen.end()) continue;
+                    if (seen.size() < 4096) seen.push_back(i);
+                    const Node& fn = g.nodes[i];
+                    const uint32_t fops[3] = {fn.a, fn.b, fn.c};
+                    for (int q = 0; q < arity_of(fn); ++q) stack.push_back(fops[q]);
+                }
+            }
             if (!ok) continue;
             // rewrite: the roots become the column nodes, everything below them dies
             for (uint32_t p : prods) {

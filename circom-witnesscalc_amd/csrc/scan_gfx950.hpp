@@ -117,6 +117,93 @@ __device__ __forceinline__ void scan_carry_parallel(bool st, uint32_t lane, cons
     carry[4] = c1 < x2 ? 1u : 0u;
     carry[5] = 0u;
 }
+// The same for registers of any width n <= 126 bits (round 5: the 121-bit registers of circom-bigint's RSA circuits), B = 2^n.
+// X = x + (a segment's incoming accumulator at its first position) < min(B^3, 2^252) everywhere in the wave: three digits d0 + d1 B +
+// d2 B^2 below 2^126 each, 128-bit arithmetic on four words; s_p = d0_p + d1_(p-1) + d2_(p-2) < 3 B <= 2^128; the two local rounds,
+// the lookahead, limb_p = (z_p + c_p) mod B and the carry leaving position p = d1_p + d2_(p-1) + ov_p + w_p + c_out + d2_p B are
+// those of scan_carry_parallel.  Below 2^252 no sum x_p + carry reaches r (carry <= t / 2): the serial recurrence's field
+// additions (graph.rs:110) are plain integer additions.
+template <int T, int WS>
+__device__ __forceinline__ void scan_carry_parallel_wide(bool st, uint32_t lane, uint32_t n, const Fr& xp, Fr& limb, Fr& carry) {
+    constexpr int D = 2 * T;
+    const uint32_t bs = n & 31u;  // n = 32 WS + bs
+    const uint32_t m[4] = {mask_word(n, 0), mask_word(n, 1), mask_word(n, 2), mask_word(n, 3)};
+    auto bit_n = [&](const uint32_t (&v)[4]) -> uint32_t { return (v[WS] >> bs) & 1u; };  // bit n of a value below 2^(n + 1) <= 2^127
+    auto add4 = [](const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&o)[4]) {
+        uint32_t cy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = adc32(a[k], b[k], cy);
+    };
+    auto add_small = [](const uint32_t (&a)[4], uint32_t b, uint32_t (&o)[4]) {
+        uint32_t cy = 0;
+        o[0] = adc32(a[0], b, cy);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) o[k] = adc32(a[k], 0u, cy);
+    };
+    auto prev4 = [&](const uint32_t (&v)[4], uint32_t (&o)[4]) {  // the previous pair's value, nothing at a segment's start
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t sft = wave_shr_lanes<D>(v[k]);
+            o[k] = st ? 0u : sft;
+        }
+    };
+    // t1 = X >> n (its words above 2^(256 - n) are zero), d2 = t1 >> n (below 2^n by the precondition)
+    uint32_t t1[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const uint32_t lo_w = k + WS < 8 ? xp.v[k + WS < 8 ? k + WS : 7] : 0u, hi_w = k + WS + 1 < 8 ? xp.v[k + WS + 1 < 8 ? k + WS + 1 : 7] : 0u;
+        t1[k] = __builtin_amdgcn_alignbit(hi_w, lo_w, bs);
+    }
+    uint32_t d0[4], d1[4], d2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d0[k] = xp.v[k] & m[k];
+        d1[k] = t1[k] & m[k];
+        d2[k] = __builtin_amdgcn_alignbit(t1[k + WS + 1], t1[k + WS], bs);
+    }
+    uint32_t y1[4], y2a[4], y2[4], s[4], s2[5];
+    prev4(d1, y1);
+    prev4(d2, y2a);
+    prev4(y2a, y2);
+    add4(d0, y1, s);
+    {
+        uint32_t cy = 0;  // (3 B may reach 2^128 at n = 126: keep the carry)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s2[k] = adc32(s[k], y2[k], cy);
+        s2[4] = cy;
+    }
+    const uint32_t ov = __builtin_amdgcn_alignbit(s2[WS + 1], s2[WS], bs) & 3u;  // s >> n: 0 .. 2
+    uint32_t lo[4], lo2[4], z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lo[k] = s2[k] & m[k];
+    const uint32_t ov_sh = wave_shr_lanes<D>(ov), ovp = st ? 0u : ov_sh;
+    add_small(lo, ovp, lo2);  // < B + 2
+    const uint32_t w = bit_n(lo2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lo2[k] &= m[k];
+    const uint32_t w_sh = wave_shr_lanes<D>(w), wp = st ? 0u : w_sh;
+    add_small(lo2, wp, z);  // <= B
+    const bool gen = bit_n(z) != 0u, prop = ((z[0] ^ m[0]) | (z[1] ^ m[1]) | (z[2] ^ m[2]) | (z[3] ^ m[3])) == 0u;
+    const uint32_t cin = scan_bit_lookahead<T>(st, gen, prop, lane);
+    uint32_t dg[4];
+    add_small(z, cin, dg);
+    limb = fr_zero();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) limb.v[k] = dg[k] & m[k];
+    const uint32_t cout = (gen || (prop && cin)) ? 1u : 0u;
+    uint32_t c0[4], c1[4];
+    add4(d1, y2a, c0);                  // < 2^127
+    add_small(c0, ov + w + cout, c1);   // < 2^127 + 4
+    // + d2 << n: word j of the shifted digit = (d2[j - WS] << bs) | (d2[j - WS - 1] >> (32 - bs))
+    uint32_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t hi_w = (j - WS >= 0 && j - WS < 4) ? d2[j - WS >= 0 && j - WS < 4 ? j - WS : 0] : 0u;
+        const uint32_t lo_w = (j - WS - 1 >= 0 && j - WS - 1 < 4) ? d2[j - WS - 1 >= 0 && j - WS - 1 < 4 ? j - WS - 1 : 0] : 0u;
+        const uint32_t sh_w = bs ? __builtin_amdgcn_alignbit(hi_w, lo_w, 32u - bs) : hi_w;
+        carry.v[j] = adc32(j < 4 ? c1[j < 4 ? j : 0] : 0u, sh_w, cy);
+    }
+}
 // Long division by one limb d (the same for all steps of a segment, every incoming remainder below it).  A step is the map
 // r -> (r B + x) mod d = (r m + v) mod d with m = B mod d, v = x mod d; maps compose ((m1, v1) then (m2, v2) = (m1 m2, v1 m2 + v2)),
 // so an inclusive segmented prefix over the pairs (log2 rounds; a segment's first step takes its incoming remainder in: m = 0,

@@ -102,12 +102,21 @@ class RcclComm:
                 N.gwb_free_status(ctypes.byref(st))
                 if rc != 0:
                     raise RuntimeError("%s: %s" % (what, msg))
+            # Every rank enters the broadcast whatever happened on the source: its failure travels as a flag byte behind the id and
+            # all ranks raise together (a source that raised first would leave the others waiting in the collective for good).
+            src_error = None
             if rank == src:
                 st = pkg.GwStatus()
-                check(N.gwb_rccl_unique_id(raw, ctypes.byref(st)), st, "gwb_rccl_unique_id")
-            t = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone().to(device)
+                try:
+                    check(N.gwb_rccl_unique_id(raw, ctypes.byref(st)), st, "gwb_rccl_unique_id")
+                except RuntimeError as e:
+                    src_error = str(e)
+            t = torch.frombuffer(bytearray(raw.raw + (b"\x00" if src_error is None else b"\x01")), dtype=torch.uint8).clone().to(device)
             dist.broadcast(t, src=src)
-            raw = ctypes.create_string_buffer(t.cpu().numpy().tobytes(), 128)
+            got = t.cpu().numpy().tobytes()
+            if got[128]:
+                raise RuntimeError(src_error or "rank %d could not draw a RCCL unique id" % src)
+            raw = ctypes.create_string_buffer(got[:128], 128)
             torch.cuda.set_device(device)
             self.comm = ctypes.c_void_p()
             st = pkg.GwStatus()
@@ -124,12 +133,13 @@ class RcclComm:
         L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rank, world = dist.get_rank(), dist.get_world_size()
         uid = UniqueId()
-        if rank == src and L.ncclGetUniqueId(ctypes.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
-        t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == src else bytes(128)), dtype=torch.uint8).clone().to(device)
+        src_failed = rank == src and L.ncclGetUniqueId(ctypes.byref(uid)) != 0  # (signalled through the broadcast: see above)
+        t = torch.frombuffer(bytearray((bytes(uid.internal) if rank == src else bytes(128)) + (b"\x01" if src_failed else b"\x00")), dtype=torch.uint8).clone().to(device)
         dist.broadcast(t, src=src)
         raw = t.cpu().numpy().tobytes()
-        ctypes.memmove(ctypes.byref(uid), raw, 128)
+        if raw[128]:
+            raise RuntimeError("ncclGetUniqueId failed on rank %d" % src)
+        ctypes.memmove(ctypes.byref(uid), raw[:128], 128)
         self.comm = ctypes.c_void_p()
         torch.cuda.set_device(device)
         rc = L.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank)

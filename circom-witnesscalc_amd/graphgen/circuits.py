@@ -1099,3 +1099,78 @@ def build_rsa_long_div_class(n=121, k=17, muls=2, range_checks=True, seed="rsa")
     for s in range(muls):
         acc = fp_mul(acc, x if s % 17 == 16 else acc)
     return b
+
+
+def build_bit_recurrence_variants(seed):
+    """The one-bit recurrences of multi-register integers in the shapes the compiler's recognition by value has to cope with
+    (rewrite.cc detect_bit_scans): register-wise subtractions whose borrow test is written with any of the four ordered
+    comparisons, whose arms are associated differently (x - y - b, x - (y + b), (x - b) - y; 2^n first, last, or inside), with
+    constant registers, with inner nodes that something else reads, with and without the last borrow; comparisons decided by the
+    most significant differing register with either strict comparison outside, swapped operands, every pair of result bits and
+    any boolean coming in -- on registers of any width (also beyond 128 bits and straight from the inputs: the kernels' general
+    paths), in chains longer than a bundle.  Whatever the compiler makes of them, the witness must be exact."""
+    rnd = random.Random(seed)
+    b = Builder()
+    n = rnd.choice([2, 7, 31, 32, 33, 55, 63, 64, 65, 100, 121, 126, 127, 128, 150, 200, 252])
+    k = rnd.choice([1, 2, 3, 5, 8, 17, 18, 33, 40])
+    base, zero, one = b.const(1 << n), b.const(0), b.const(1)
+    mask = b.const((1 << n) - 1)
+    raw = rnd.random() < 0.25   # registers straight from the inputs: any field element
+    xs_in, ys_in = b.input("x", k), b.input("y", k)
+    (f_in,) = b.input("f")
+    reg = (lambda v: v) if raw else (lambda v: b.op("Band", v, mask))
+    xs, ys = [reg(v) for v in xs_in], [reg(v) for v in ys_in]
+    flag = b.op("Lt", f_in, b.const(R // 3))   # some boolean
+    for _chain in range(rnd.randrange(1, 4)):
+        kind = rnd.choice(["sub", "sub", "cmp", "cmp", "sub_then_cmp"])
+        x = list(xs)
+        y = [rnd.choice([ys[i], ys[i], zero, xs[i], b.const(rnd.getrandbits(min(n, 250)))]) for i in range(k)]
+        if rnd.random() < 0.3:
+            x = [rnd.choice([x[i], b.const(rnd.getrandbits(min(n, 250)))]) for i in range(k)]
+        if kind in ("sub", "sub_then_cmp"):
+            cond_style = rnd.choice(["geq", "leq", "lt", "gt"])
+            diff, borrow = [], None
+            for i in range(k):
+                s = y[i] if borrow is None else (b.add(y[i], borrow) if rnd.random() < 0.5 else b.add(borrow, y[i]))
+                then_style, else_style = rnd.randrange(3), rnd.randrange(3)
+                bw = borrow if borrow is not None else zero
+                if borrow is None and rnd.random() < 0.7:   # the first register as circom-bigint writes it: no borrow term at all
+                    d_then = b.sub(x[i], y[i])
+                    d_else = b.add(b.sub(x[i], y[i]), base) if rnd.random() < 0.5 else b.sub(b.add(base, x[i]), y[i])
+                else:
+                    d_then = [lambda: b.sub(b.sub(x[i], y[i]), bw), lambda: b.sub(x[i], b.add(y[i], bw)), lambda: b.sub(b.sub(x[i], bw), y[i])][then_style]()
+                    d_else = [lambda: b.sub(b.sub(b.add(base, x[i]), y[i]), bw), lambda: b.add(b.sub(b.sub(x[i], y[i]), bw), base),
+                              lambda: b.sub(b.add(x[i], base), b.add(y[i], bw))][else_style]()
+                if rnd.random() < 0.08:
+                    b.signal(d_else)          # an arm that is a witness element stays
+                if cond_style == "geq":
+                    c = b.op("Geq", x[i], s)
+                elif cond_style == "leq":
+                    c = b.op("Leq", s, x[i])
+                elif cond_style == "lt":
+                    c = b.op("Lt", x[i], s)
+                else:
+                    c = b.op("Gt", s, x[i])
+                no_borrow_when_true = cond_style in ("geq", "leq")
+                diff.append(b.signal(b.tern(c, d_then, d_else) if no_borrow_when_true else b.tern(c, d_else, d_then)))
+                if i + 1 < k or rnd.random() < 0.5:
+                    borrow = b.tern(c, zero, one) if no_borrow_when_true else b.tern(c, one, zero)
+                    if rnd.random() < 0.1:
+                        b.signal(borrow)
+                if rnd.random() < 0.05:
+                    b.signal(c)
+            x = diff
+        if kind in ("cmp", "sub_then_cmp"):
+            kg, kl = rnd.randrange(2), rnd.randrange(2)
+            res = rnd.choice([zero, zero, one, flag])
+            gt_outside = rnd.random() < 0.5
+            for i in range(k):
+                gt = b.op("Gt", x[i], y[i]) if rnd.random() < 0.7 else b.op("Lt", y[i], x[i])
+                lt = b.op("Lt", x[i], y[i]) if rnd.random() < 0.7 else b.op("Gt", y[i], x[i])
+                c_kg, c_kl = (one if kg else zero), (one if kl else zero)
+                res = b.tern(gt, c_kg, b.tern(lt, c_kl, res)) if gt_outside else b.tern(lt, c_kl, b.tern(gt, c_kg, res))
+                if rnd.random() < 0.1:
+                    b.signal(res)
+            b.signal(b.tern(b.op("Eq", res, one), xs[0], ys[0]))
+            b.signal(res)
+    return b

@@ -696,6 +696,97 @@ def test_config5_named_size_ten_million_nodes_all_sets(pkg):
     assert g.program_stats(key)["n_conv_products"] == 32 * 32 * 4000 and g.program_stats(key)["n_scan_steps"] > 4000 * 120
 
 
+def _rsa_rows(rnd, n_inputs, n_bits, count):
+    """input sets of the RSA / long_div-class graph: uniform field elements (the graph's masks make registers of them), and
+    register-sized edge values -- all-ones and zero registers (borrows and carries that ripple, equal registers in the comparisons)"""
+    edge = [0, 1, (1 << n_bits) - 1, (1 << n_bits) - 2, 1 << (n_bits - 1)]
+    return [[1] + [rnd.randrange(M) if s % 4 else rnd.choice(edge + [rnd.randrange(1 << n_bits)]) for _ in range(n_inputs - 1)] for s in range(count)]
+
+
+def test_rsa_long_div_class_one_million_nodes_every_set(pkg):
+    """BASELINE config 5's named class (synthetic by necessity): the zk-email RSA / long_div-class graph -- 121-bit
+    registers x 17, schoolbook products with carries, long_div by the 17-register modulus digit by digit (short_div estimate,
+    long_scalar_mult, long_gt, long_sub), chained modular multiplications -- at 1.1 M nodes, every set against the oracle at tile
+    widths 1 and 2, and its q / r registers of the first multiplications against Python's divmod.  The program must run the
+    multi-register recurrences as scan bundles (carry chains of 121-bit registers, borrow chains, comparisons)."""
+    n, k, muls = 121, 17, 34
+    data = C.build_rsa_long_div_class(n=n, k=k, muls=muls).to_bin()
+    g = pkg.Graph(data)
+    assert g.n_nodes > 1000000
+    rnd = random.Random(21)
+    rows = _rsa_rows(rnd, g.n_inputs, n, 32)
+    inp = cbind.ints_to_array(rows)
+    og = cbind.Graph(data)
+    _, want, wst = cbind.time_batch_threads(og, inp, min(32, os.cpu_count() or 1))
+    assert not wst.any()
+    for tw in (1, 2):
+        g.set_tile_width(tw)
+        got, st = g.calc_witness_batch(inp)
+        assert not st.any() and np.array_equal(got, want), "tile width %d" % tw
+        ps = g.program_stats(tw)
+        assert ps["n_scan_steps"] > muls * 3000 and ps["class_bundles"].get("SCAN", 0) * 3 > ps["class_bundles"].get("TERN", 0), ps
+    # outside anchor: q, r of the first two multiplications = divmod(a * b, p) on Python integers
+    mask = (1 << n) - 1
+    for s in (0, 1, 5):
+        w = [int.from_bytes(bytes(got[s][i]), "little") for i in range(1 + 2 * k + 2 * (2 * k) * (n + 1))]
+        xs, ps_ = [v & mask for v in rows[s][1:1 + k]], [v & mask for v in rows[s][1 + k:1 + 2 * k]]
+        ps_[-1] = (rows[s][2 * k] & ((1 << (n - 10)) - 1)) + (1 << (n - 10))
+        X, P = sum(v << (n * i) for i, v in enumerate(xs)), sum(v << (n * i) for i, v in enumerate(ps_))
+        assert w[1:1 + k] == xs and w[1 + k:1 + 2 * k] == ps_
+        pos, acc = 1 + 2 * k, X
+        for _m in range(2):
+            Q, Rm = divmod(acc * acc, P)
+            regs = []
+            for _i in range(2 * k):
+                regs.append(w[pos])
+                assert w[pos + 1:pos + 1 + n] == [(w[pos] >> j) & 1 for j in range(n)]
+                pos += n + 1
+            assert sum(v << (n * i) for i, v in enumerate(regs[k:])) == Rm and sum(v << (n * i) for i, v in enumerate(regs[:k])) == Q % (1 << (n * k))
+            acc = Rm
+
+
+@pytest.mark.timeout(900)
+def test_config5_rsa_named_size_ten_million_nodes_all_sets(pkg):
+    """BASELINE config 5 at its named size on the named class: ten million nodes of the RSA / long_div-class graph (121-bit registers x
+    17, 310 chained modular multiplications = 18 RSA-65537 exponentiations), the 32 sets of one GPU's shard, every one against
+    the oracle, with the program the cost model picks for that batch."""
+    n, k, muls = 121, 17, 310
+    data = C.build_rsa_long_div_class(n=n, k=k, muls=muls).to_bin()
+    g = pkg.Graph(data)
+    assert g.n_nodes >= 10000000
+    rows = _rsa_rows(random.Random(22), g.n_inputs, n, 32)
+    inp = cbind.ints_to_array(rows)
+    og = cbind.Graph(data)
+    _, want, wst = cbind.time_batch_threads(og, inp, min(32, os.cpu_count() or 1))
+    key = g.pick_tile_width(32)
+    g.set_tile_width(key)
+    got, st = g.calc_witness_batch(inp)
+    assert not wst.any() and not st.any() and np.array_equal(got, want)
+    assert g.program_stats(key)["n_scan_steps"] > muls * 3000
+
+
+def test_bit_recurrence_variants_on_the_gpu(pkg, monkeypatch):
+    """Borrow chains and most-significant-difference comparisons in every shape the recognition by value has to cope with
+    (graphgen.circuits.build_bit_recurrence_variants: four comparison styles, three associations per arm, constant registers,
+    arms that are witness elements, dropped and kept last borrows, every pair of result bits, booleans coming in), on registers
+    of 2 .. 252 bits, masked and straight from the inputs -- the kernels' register-sized paths and their general ones -- at
+    tile widths 1 and 2 (scan bundles), 4 (none) and with the recognition switched off."""
+    rnd = random.Random(77)
+    n_scan = 0
+    for seed in range(60):
+        data = C.build_bit_recurrence_variants(seed).to_bin()
+        og = cbind.Graph(data)
+        rows = [[1] + [rnd.choice([0, 1, rnd.getrandbits(rnd.choice([8, 64, 121, 128, 200])), rnd.randrange(M), M - 1 - rnd.getrandbits(20)]) for _ in range(og.n_inputs - 1)]
+                for _s in range(rnd.choice([1, 3, 67]))]
+        g = _check(pkg, data, rows, tiles=(1, 2, 4, 1 | DIVIDER))
+        n_scan += g.program_stats(1)["n_scan_steps"]
+        if seed % 10 == 0:
+            monkeypatch.setenv("CWC_NO_BIT_SCANS", "1")
+            _check(pkg, data, rows, tiles=(1, 2))
+            monkeypatch.delenv("CWC_NO_BIT_SCANS")
+    assert n_scan > 300
+
+
 # BabyJubjub in twisted Edwards form a x^2 + y^2 = 1 + d x^2 y^2 (a = 168700, d = 168696), independent of the generator's
 # Montgomery-form gadgets: the unified addition law and double-and-add on Python integers.
 _BJ_A, _BJ_D = 168700, 168696

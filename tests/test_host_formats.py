@@ -388,6 +388,48 @@ def test_convolution_columns_are_exact(pkg):
             finally:
                 os.environ.pop("CWC_CONV_ALWAYS", None)
     assert n_conv > 300
+    # A factor that depends on the block itself (round 4's advisor: x_1 = x_0 y_0 mod 2^64 -- the bundle would wait for x_1 and x_1 for
+    # column 0): the block is left alone; and should a grouping that cannot be scheduled ever get through (here: with the dependency
+    # check switched off), compile_program falls back to the program without convolution bundles instead of failing the graph.
+    def dependent_block():
+        b = cwc_import.load().graphgen.builder.Builder()
+        xin, yin, cin = b.input("x", 3), b.input("y", 3), b.input("c", 40)
+        m, base, zero = b.const((1 << 64) - 1), b.const(1 << 64), b.const(0)
+        x0, x2 = b.op("Band", xin[0], m), b.op("Band", xin[2], m)
+        y = [b.op("Band", v, m) for v in yin]
+        p00 = b.mul(x0, y[0])
+        x = [x0, b.op("Band", p00, m), x2]
+        cols = [None] * 5
+        for i in range(3):
+            for j in range(3):
+                pr = p00 if (i, j) == (0, 0) else b.mul(x[i], y[j])
+                cols[i + j] = pr if cols[i + j] is None else b.add(cols[i + j], pr)
+        for c in range(1, 5):
+            b.signal(b.op("Band", cols[c], m))
+        b.signal(x[1])
+        carry = zero   # (an unrelated carry chain: the graph counts as a limb graph)
+        for v in cin:
+            t = b.add(b.op("Band", v, m), carry)
+            b.signal(b.op("Mod", t, base))
+            carry = b.signal(b.op("Idiv", t, base))
+        return b
+    data = dependent_block().to_bin()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    for skip_check in (False, True):
+        os.environ.pop("CWC_CONV_SKIP_DEPENDENCY_CHECK", None)
+        os.environ["CWC_CONV_ALWAYS"] = "1"
+        if skip_check:
+            os.environ["CWC_CONV_SKIP_DEPENDENCY_CHECK"] = "1"
+        try:
+            for key in (1, 2):
+                blob = pe.Blob(pkg.Graph(data).export_blob(key))
+                assert blob.stats["n_conv_products"] == 0 and blob.stats["n_scan_steps"] > 0
+                for row in scan_rows(rnd, blob.n_inputs, 3):
+                    got, st = pe.run(blob, row)
+                    assert st == 0 and got == model.evaluate(nodes, row, wit)
+        finally:
+            os.environ.pop("CWC_CONV_SKIP_DEPENDENCY_CHECK", None)
+            os.environ.pop("CWC_CONV_ALWAYS", None)
     # a limb graph that also holds field divisions: scan / convolution bundles beside in-line divisions or beside the requests to
     # a divider wave
     data = C.build_limb_graph_with_divisions().to_bin()
@@ -518,6 +560,198 @@ def test_parallel_scan_algorithms_on_plain_integers():
         xd = [pick(64) for _ in range(L)]
         a0d = [rnd.randrange(ds[p]) if starts[p] else None for p in range(L)]
         assert serial_div(xd, starts, a0d, ds) == par_div(xd, starts, a0d, ds)
+
+
+def test_wide_register_scan_algorithms_on_plain_integers():
+    """Round 5 (csrc/scan_gfx950.hpp scan_carry_parallel_wide, scan_bit_lookahead and the BORROW / LEX paths of kernels.hip) restated
+    on plain integers against the serial recurrences: the carry chain's parallel form for registers of any width n <= 126
+    (three digits below 2^n, x below min(2^(3n), 2^252)), and the two one-bit recurrences -- the borrow chain of a register-wise
+    subtraction and the most-significant-difference comparison -- as generate / propagate bits resolved by one integer addition."""
+    from oracle import model
+    M = model.M
+
+    def lookahead(starts, gen, prop):
+        a = b = 0
+        for p in range(len(starts)):
+            a |= (0 if starts[p] else 1) << (2 * p) | (1 if gen[p] or prop[p] else 0) << (2 * p + 1)
+            b |= (1 if gen[p] else 0) << (2 * p + 1)
+        cbits = (a + b) ^ a ^ b
+        return [(cbits >> (2 * p + 1)) & 1 for p in range(len(starts))]
+
+    def serial_carry(n, xs, starts, a0s):
+        limb, carry, c = [], [], 0
+        for p, x in enumerate(xs):
+            t = (x + (a0s[p] if starts[p] else c)) % M   # graph.rs:110, the field addition of the unfused step
+            limb.append(t & ((1 << n) - 1))
+            c = t >> n
+            carry.append(c)
+        return limb, carry
+
+    def par_carry(n, xs, starts, a0s):
+        B, L = 1 << n, len(xs)
+        xp = [xs[p] + (a0s[p] if starts[p] else 0) for p in range(L)]
+        d0, d1, d2 = [v % B for v in xp], [(v >> n) % B for v in xp], [v >> (2 * n) for v in xp]
+        assert all(v < B for v in d2)
+        prev = lambda a: [0 if starts[p] else v for p, v in enumerate([0] + a[:-1])]
+        y1, y2a = prev(d1), prev(d2)
+        y2 = prev(y2a)
+        s = [d0[p] + y1[p] + y2[p] for p in range(L)]
+        assert all(v < (1 << 128) for v in s)
+        lo, ov = [v % B for v in s], [v >> n for v in s]
+        u = [a + c for a, c in zip(lo, prev(ov))]
+        lo2, w = [v % B for v in u], [(v >> n) & 1 for v in u]
+        z = [a + c for a, c in zip(lo2, prev(w))]
+        gen, prop = [(v >> n) & 1 == 1 for v in z], [v == B - 1 for v in z]
+        cin = lookahead(starts, gen, prop)
+        limb = [(z[p] + cin[p]) % B for p in range(L)]
+        cout = [1 if gen[p] or (prop[p] and cin[p]) else 0 for p in range(L)]
+        return limb, [d1[p] + y2a[p] + ov[p] + w[p] + cout[p] + (d2[p] << n) for p in range(L)]
+
+    def serial_borrow(n, xs, ys, starts, a0s):
+        out, acc, b = [], [], 0
+        for p in range(len(xs)):
+            bi = a0s[p] if starts[p] else b
+            c = model.eval_duo("Geq", xs[p], (ys[p] + bi) % M)
+            out.append((xs[p] - ys[p] - bi) % M if c else (xs[p] - ys[p] - bi + (1 << n)) % M)
+            b = 0 if c else 1
+            acc.append(b)
+        return out, acc
+
+    def par_borrow(n, xs, ys, starts, a0s):   # registers below 2^n
+        L = len(xs)
+        gen, prop = [xs[p] < ys[p] for p in range(L)], [xs[p] == ys[p] for p in range(L)]
+        gs = [gen[p] or (starts[p] and prop[p] and a0s[p] == 1) for p in range(L)]
+        cin = lookahead(starts, gs, prop)
+        bi = [a0s[p] if starts[p] else cin[p] for p in range(L)]
+        bout = [1 if gen[p] or (prop[p] and bi[p]) else 0 for p in range(L)]
+        return [((xs[p] - ys[p] - bi[p]) + (bout[p] << n)) % (1 << 128) for p in range(L)], bout
+
+    def serial_lex(kg, kl, xs, ys, starts, a0s):
+        acc, b = [], 0
+        for p in range(len(xs)):
+            bi = a0s[p] if starts[p] else b
+            b = kg if model.eval_duo("Gt", xs[p], ys[p]) else kl if model.eval_duo("Lt", xs[p], ys[p]) else bi
+            acc.append(b)
+        return acc
+
+    def par_lex(kg, kl, xs, ys, starts, a0s):
+        L = len(xs)
+        gt, lt = [model.eval_duo("Gt", xs[p], ys[p]) for p in range(L)], [model.eval_duo("Lt", xs[p], ys[p]) for p in range(L)]
+        gen = [bool((gt[p] and kg) or (lt[p] and kl)) for p in range(L)]
+        prop = [not gt[p] and not lt[p] for p in range(L)]
+        cin = lookahead(starts, [gen[p] or (starts[p] and prop[p] and a0s[p] == 1) for p in range(L)], prop)
+        bi = [a0s[p] if starts[p] else cin[p] for p in range(L)]
+        return [1 if gen[p] or (prop[p] and bi[p]) else 0 for p in range(L)]
+
+    rnd = random.Random(12)
+
+    def pick(bits):
+        k = rnd.random()
+        return (1 << bits) - 1 if k < 0.2 else 0 if k < 0.3 else ((1 << bits) - 1) ^ rnd.getrandbits(3) if k < 0.4 else rnd.getrandbits(bits)
+
+    for trial in range(3000):
+        L = rnd.choice([16, 32])
+        n = rnd.choice([2, 7, 31, 32, 33, 55, 63, 65, 96, 100, 121, 126])
+        starts = [p == 0 or rnd.random() < 0.1 for p in range(L)]
+        top = min(3 * n, 252)
+        xs = [(1 << n) - 1] * L if rnd.random() < 0.3 else [pick(rnd.choice([n, min(2 * n, top), top])) for _ in range(L)]
+        a0s = [pick(rnd.choice([1, n, min(n + 6, top)])) if starts[p] else None for p in range(L)]
+        if all(xs[p] + (a0s[p] or 0) < (1 << top) for p in range(L)):
+            assert serial_carry(n, xs, starts, a0s) == par_carry(n, xs, starts, a0s), (n, trial)
+        # one-bit recurrences on registers below 2^n, equal registers and borrows that ripple among them
+        xr = [pick(n) & ((1 << n) - 1) for _ in range(L)]
+        yr = [xr[p] if rnd.random() < 0.4 else pick(n) & ((1 << n) - 1) for p in range(L)]
+        b0 = [rnd.randrange(2) if starts[p] else None for p in range(L)]
+        assert serial_borrow(n, xr, yr, starts, b0) == par_borrow(n, xr, yr, starts, b0), (n, trial)
+        kg, kl = rnd.randrange(2), rnd.randrange(2)
+        # (the comparison is the reference's signed one: operands anywhere in the field)
+        xf = [rnd.choice([xr[p], M - 1 - xr[p], rnd.randrange(M), M // 2, M // 2 + 1]) for p in range(L)]
+        yf = [xf[p] if rnd.random() < 0.4 else rnd.choice([yr[p], M - 1 - yr[p], rnd.randrange(M), M // 2, M // 2 + 1]) for p in range(L)]
+        assert serial_lex(kg, kl, xf, yf, starts, b0) == par_lex(kg, kl, xf, yf, starts, b0), (n, trial)
+
+
+def test_rsa_long_div_class_generator_against_plain_integers(pkg):
+    """graphgen.circuits.build_rsa_long_div_class restates circom-bigint's witness hints (schoolbook product with carries, long_div
+    by a k-register divisor: short_div estimate, long_scalar_mult, long_gt, long_sub) node by node.  Outside anchor: for every
+    chained multiplication the graph's q and r registers, evaluated by the C oracle, are divmod(a * b, p) on Python integers, and the
+    range-check bits are the registers' bits -- over register widths 16 .. 126 and 1 .. 17 registers."""
+    from oracle import cbind
+    rnd = random.Random(31)
+    for n, k, muls in [(121, 17, 2), (64, 4, 3), (55, 5, 18), (100, 3, 2), (126, 2, 2), (16, 3, 3), (121, 1, 2)]:
+        data = C.build_rsa_long_div_class(n=n, k=k, muls=muls).to_bin()
+        og = cbind.Graph(data)
+        rows = [[1] + [rnd.randrange(model.M) if s % 2 == 0 else rnd.choice([0, 1, (1 << n) - 1, rnd.randrange(1 << n)]) for _ in range(2 * k)] for s in range(5)]
+        want, st = og.evaluate_batch(cbind.ints_to_array(rows))
+        assert not st.any()
+        mask = (1 << n) - 1
+        for s, row in enumerate(rows):
+            w = [int.from_bytes(bytes(want[s][i]), "little") for i in range(want.shape[1])]
+            xs, ps = [v & mask for v in row[1:1 + k]], [v & mask for v in row[1 + k:1 + 2 * k]]
+            tb = max(n - 10, 1)
+            ps[-1] = (row[2 * k] & ((1 << tb) - 1)) + (1 << tb)
+            X, P = sum(v << (n * i) for i, v in enumerate(xs)), sum(v << (n * i) for i, v in enumerate(ps))
+            assert w[0] == 1 and w[1:1 + k] == xs and w[1 + k:1 + 2 * k] == ps
+            pos, acc = 1 + 2 * k, X
+            for m in range(muls):
+                Q, Rm = divmod(acc * (X if m % 17 == 16 else acc), P)
+                regs = []
+                for _i in range(2 * k):
+                    regs.append(w[pos])
+                    assert w[pos + 1:pos + 1 + n] == [(w[pos] >> j) & 1 for j in range(n)]
+                    pos += n + 1
+                assert sum(v << (n * i) for i, v in enumerate(regs[k:])) == Rm and sum(v << (n * i) for i, v in enumerate(regs[:k])) == Q % (1 << (n * k))
+                acc = Rm
+            assert pos == len(w)
+
+
+def test_bit_recurrence_scans_are_exact(pkg, monkeypatch):
+    """Round 5: the one-bit recurrences of multi-register integers -- the borrow chain of a register-wise subtraction, the
+    comparison decided by the most significant differing register -- become scan bundles (rewrite.cc detect_bit_scans; steps
+    recognised by VALUE through linear forms of the arms).  The emulator runs the exported programs of the RSA / long_div-class graph
+    and of the variants generator (every comparison style, arm association, constant registers, kept / dropped last borrow, result
+    bits, incoming booleans, registers of 2 .. 252 bits) against the Python model at tile widths 1, 2 (scan bundles) and 4, and with
+    the recognition off; the RSA program must hold all three kinds of wide-register chains."""
+    rnd = random.Random(41)
+
+    def kinds(blob):
+        scan = [h for h in blob.hdr if (h & 0xF) == pe.CLASS_NAMES.index("SCAN")]
+        return (sum(1 for h in scan if h & pe.HDR_SCAN_BORROW), sum(1 for h in scan if h & pe.HDR_SCAN_LEX),
+                sum(1 for h in scan if not h & (pe.HDR_SCAN_BORROW | pe.HDR_SCAN_LEX | pe.HDR_SCAN_DIV | pe.HDR_SCAN_CONV)))
+
+    for n, k, muls in [(121, 17, 1), (64, 4, 2), (33, 6, 1)]:
+        b = C.build_rsa_long_div_class(n=n, k=k, muls=muls, range_checks=(k < 17))
+        nodes, wit, _ = b.finalize()
+        g = pkg.Graph(b.to_bin())
+        rows = [[1] + [rnd.randrange(model.M) if s == 0 else rnd.choice([0, 1, (1 << n) - 1, rnd.randrange(1 << n)]) for _ in range(2 * k)] for s in range(2)]
+        for tw in (1, 2, 4):
+            blob = pe.Blob(g.export_blob(tw))
+            nb, nl, nc = kinds(blob)
+            assert (nb > 0 and nl > 0 and nc > 0) == (tw <= 2), (tw, nb, nl, nc)
+            for row in rows:
+                got, st = pe.run(blob, row)
+                assert st == 0 and got == model.evaluate(nodes, row, wit)
+    tot_b = tot_l = 0
+    for seed in range(40):
+        b = C.build_bit_recurrence_variants(seed)
+        nodes, wit, _ = b.finalize()
+        data = b.to_bin()
+        rows = [[1] + [rnd.choice([0, 1, rnd.getrandbits(rnd.choice([8, 64, 121, 128, 200])), rnd.randrange(model.M), model.M - 1 - rnd.getrandbits(20)]) for _ in range(b.n_inputs - 1)] for _s in range(2)]
+        want = [model.evaluate(nodes, row, wit) for row in rows]
+        for no_scans in (False, True) if seed % 8 == 0 else (False,):
+            if no_scans:
+                monkeypatch.setenv("CWC_NO_BIT_SCANS", "1")
+            g = pkg.Graph(data)
+            for tw in (1, 2, 4):
+                blob = pe.Blob(g.export_blob(tw))
+                nb, nl, _ = kinds(blob)
+                assert not no_scans or (nb == 0 and nl == 0)
+                if tw == 1:
+                    tot_b, tot_l = tot_b + nb, tot_l + nl
+                for row, w in zip(rows, want):
+                    got, st = pe.run(blob, row)
+                    assert st == 0 and got == w, (seed, tw)
+            monkeypatch.delenv("CWC_NO_BIT_SCANS", raising=False)
+    assert tot_b > 10 and tot_l > 10
 
 
 def test_scan_chains_are_exact(pkg):

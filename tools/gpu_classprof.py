@@ -16,7 +16,9 @@ pkg = cwc_import.load()
 import cwc_import
 C = cwc_import.load().graphgen.circuits
 kind = os.environ.get("PROBE_GRAPH", "authv2")
-b = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else C.build_bigint_class(k=32, rounds=int(os.environ.get("BIGINT_ROUNDS", "400")))
+b = (C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else
+     C.build_rsa_long_div_class(n=int(os.environ.get("RSA_N", "121")), k=int(os.environ.get("RSA_K", "17")), muls=int(os.environ.get("RSA_MULS", "4"))) if kind == "rsa" else
+     C.build_bigint_class(k=32, rounds=int(os.environ.get("BIGINT_ROUNDS", "400"))))
 g = pkg.Graph(b.to_bin())
 B = int(os.environ.get("PROBE_B", "1024"))
 rng = np.random.default_rng(1)
@@ -37,6 +39,7 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     tiles = (B + (tw & 0xff) - 1) // (tw & 0xff)
     nw = max(1, tiles // 64 + (1 if tiles % 64 else 0))
     sections = prof.pop("_sections")
+    scan_kinds = prof.pop("_scan_kinds")
     wv = prof.pop("_waves")
     tot = sum(v[0] for v in prof.values())
     print("T=%d%s B=%d product interp %.1f ms; stamped build: sampled waves=%d total cycles/wave %.3g" % (tw & 0xff, " + divider wave" if tw & 0x100 else "", B, t["interp_ms"], nw, tot / nw))
@@ -44,6 +47,9 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     for k, (cyc, _a, _b, n) in prof.items():
         if n:
             print("   %-8s bundles/wave %7d  cycles/bundle %8.0f  share %.1f%%" % (k, n // nw, cyc / n, 100.0 * cyc / tot))
+    for k, (cyc, _a, _b, n) in scan_kinds.items():
+        if n:
+            print("   scan bundles, %-11s bundles/wave %7d  cycles/bundle %8.0f" % (k, n // nw, cyc / n))
     for k, v in sections.items():
         if v[5]:
             print("   %s sections (cycles/bundle, each includes one ~40-cycle stamp): top+vmcnt wait %.0f | LDS reads + previous stores %.0f | staging issue %.0f | arithmetic %.0f | ring write %.0f" % (

@@ -30,7 +30,15 @@ def run(n_seeds, base, verbose=True):
     for s in range(n_seeds):
         kind = rnd.choice(KINDS)
         if kind == "limb":  # serial limb recurrences: what the compiler runs as scan bundles (tile widths 1 and 2), every shift / base width
-            if rnd.random() < 0.15:  # (limb products in the shapes the convolution rewrite has to tell apart)
+            if rnd.random() < float(os.environ.get("SOAK_WIDE_SHARE", "0.3")):  # round 5: registers wider than a word -- borrow chains, comparisons, multi-register long division
+                os.environ.pop("CWC_CONV_ANY_WIDTH", None)
+                os.environ.pop("CWC_CONV_ALWAYS", None)
+                if rnd.random() < 0.6:
+                    b = C.build_bit_recurrence_variants(rnd.randrange(1 << 30))
+                else:
+                    b = C.build_rsa_long_div_class(n=rnd.choice([55, 64, 100, 121, 121, rnd.randrange(12, 127)]), k=rnd.choice([1, 2, 3, 4, 6]), muls=rnd.randrange(1, 3),
+                                                   range_checks=rnd.random() < 0.3)
+            elif rnd.random() < 0.15:  # (limb products in the shapes the convolution rewrite has to tell apart)
                 os.environ.pop("CWC_CONV_ANY_WIDTH", None)
                 os.environ.pop("CWC_CONV_ALWAYS", None)
                 if rnd.random() < 0.5:
