@@ -17,8 +17,11 @@ line on rank 0.  Outside `value`, the same line carries (N = 1 unless said other
   config4_per_gpu    BASELINE config 4's per-GPU share: 8192 authV2-class sets, sampled sets against the oracle
   config4            (every N) the config-4 job itself: a global batch of 8192 x N sets, contiguous shards, per-set checksums
                      of all ranks hashed and compared with the same job recomputed on rank 0 alone
-  config5            BASELINE config 5 at its named size: the 10.5 M-node bigint / long_div-class graph, 32 sets on this GPU
-                     (generation ~10 s, compile ~6 s, 3 timed steps, 4 sets against the oracle = its CPU baseline sample)
+  config5            BASELINE config 5 at its named size on the builder's first generator: the 10.5 M-node bigint / long_div-class graph (64-bit
+                     limbs x 32, division by ONE limb), 32 sets on this GPU (3 timed steps, 4 sets against the oracle = its CPU baseline sample)
+                     and, in `all_256_sets_on_one_gpu`, the whole 256-set batch on this one GPU
+  config5_rsa        the same on the class BASELINE names: the zk-email RSA / long_div-class graph, 121-bit registers x 17, long_div by the
+                     17-register modulus (circom-bigint's witness hints), 310 chained modular multiplications = 10.0 M nodes
   json_front_end     sets/s of the batched NDJSON -> rows front-end
   e2e_json_to_wtns   NDJSON -> `.wtns` files on tmpfs through the streaming pipeline (parse | kernels | D2H slices | writers)
   pcie_inclusive     the host-buffer entry point (never `value`)
@@ -84,15 +87,29 @@ class Workload:
             self.name = "graph file %s" % os.path.basename(path)
             self.source = "CWC_GRAPH_BIN"
         else:
-            # (bigint: BASELINE config 5's shape -- 32 limbs x 4000 rounds of multiply / long-divide / compare = 10.5 M nodes,
-            # depth 1.29 M; ~10 s of generation and ~6 s of graph compilation in front of the timed steps)
-            builder = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512) if kind == "sha256" else C.build_bigint_class(k=32, rounds=4000)
-            nodes, wit, self.inputs = builder.finalize()
-            self.stats = graph_stats(nodes, wit)
-            self.data = builder.to_bin()
-            self.name = {"authv2": "authV2-class graph", "sha256": "sha256_512 graph", "bigint": "bigint / long_div-class graph"}[kind]
-            self.source = "generated (circom-witnesscalc_amd/graphgen, written through the C-ABI producer gwb_builder_*): real circom graphs cannot be built offline"
+            self.name = {"authv2": "authV2-class graph", "sha256": "sha256_512 graph", "bigint": "bigint / long_div-class graph (64-bit limbs x 32, division by one limb)",
+                         "rsa": "zk-email RSA / long_div-class graph (121-bit registers x 17, long_div by the 17-register modulus)"}[kind]
+            if kind in ("bigint", "rsa"):
+                # BASELINE config 5's two class graphs at the named size, ten million nodes each, from the native generators (gwb_graphgen_*:
+                # the same bytes as the Python generator library writes, tests/test_host_formats.py; ~2 s instead of ~20 s).  bigint: 32 limbs
+                # x 4000 rounds of multiply / long-divide by one limb / compare; rsa: 310 chained modular multiplications = 18 RSA-65537
+                # exponentiations as circom-bigint's witness hints compute them.  Statistics come from the loaded handle (stats_from).
+                self.data = pkg.graphgen_native("bigint", k=32, n_bits=64, rounds=4000) if kind == "bigint" else pkg.graphgen_native("rsa", n=121, k=17, muls=310)
+                self.inputs, self.stats = None, None
+                self.source = "generated natively (gwb_graphgen_*; specification: circom-witnesscalc_amd/graphgen/circuits.py, byte-equal): the reference front-end cannot compile such circuits"
+            else:
+                builder = C.build_authv2_class() if kind == "authv2" else C.build_sha256(512)
+                nodes, wit, self.inputs = builder.finalize()
+                self.stats = graph_stats(nodes, wit)
+                self.data = builder.to_bin()
+                self.source = "generated (circom-witnesscalc_amd/graphgen, written through the C-ABI producer gwb_builder_*): real circom graphs cannot be built offline"
         self.input_kind = "bits" if kind == "sha256" else "field"
+
+    def stats_from(self, g):
+        """statistics of a natively generated graph from its loaded handle (no Python node list exists)"""
+        if self.stats is None:
+            self.stats = {"N": g.n_nodes, "N_op": g.n_op, "W": g.n_witness, "depth": g.depth, "hist": g.op_histogram()}
+        return self.stats
 
     def first_row(self, g):
         if self.kind == "authv2" and self.source != "CWC_GRAPH_BIN":  # global set 0 = the reference's own input file through the JSON path
@@ -212,6 +229,9 @@ def dry_run(args, real_stdout):
         g = pkg.Graph(pkg.graphgen.circuits.build_gadgets().to_bin())
         key = g.pick_tile_width(per)   # host-only: the cost model needs no device
         blob = g.export_blob(key)
+    if os.environ.get("BENCH_DRYRUN_DIE_RANK") == str(rank):  # (test hook: a rank that dies in front of the collective must fail the job, not hang it)
+        log("bench.py --dry-run: rank %d exits before the broadcast (BENCH_DRYRUN_DIE_RANK)" % rank)
+        os._exit(7)
     if distributed:
         with Watchdog(float(os.environ.get("BENCH_BCAST_TIMEOUT", "120")), "program broadcast (gloo)"):
             blob = cdist.broadcast_blob(blob, src=0, device="cpu")
@@ -246,6 +266,14 @@ def dry_run(args, real_stdout):
         group_ranks = dist.get_world_size()
     else:
         cs_all, group_ranks = cs, 1
+    n1_ms = None
+    if distributed:  # the N = 1 step of the same run, as the real line has it: rank 0 alone repeats its shard while the others wait
+        if rank == 0:
+            t1 = time.perf_counter()
+            for _ in range(max(1, args.steps)):
+                evaluate(lo, hi)
+            n1_ms = (time.perf_counter() - t1) / max(1, args.steps) * 1e3
+        dist.barrier()
     if rank == 0:
         digest = hashlib.sha256(cs_all.numpy().tobytes()).hexdigest()
         single = hashlib.sha256(evaluate(0, total)[0].numpy().tobytes()).hexdigest()
@@ -255,7 +283,8 @@ def dry_run(args, real_stdout):
                "data": "synthetic", "dry_run": True,
                "config": {"workload": "DRY RUN on CPU: gadget graph, %d sets per rank on the program emulator (launch-path rehearsal, not a measurement)" % per,
                           "tile_width": prog.T, "parallelism": "contiguous shards of one global batch x%d, program blob broadcast over gloo" % world},
-               "rccl_ranks": None, "group_ranks": group_ranks, "program_key": key, "digest_of_set_checksums": digest, "single_gpu_digest": single,
+               "rccl_ranks": None, "group_ranks": group_ranks, "program_key": key, "n1_ms_per_step_same_run": n1_ms,
+               "efficiency_vs_n1": (n1_ms / (elapsed / steps * 1e3)) if n1_ms else None, "digest_of_set_checksums": digest, "single_gpu_digest": single,
                "matches_single_gpu_digest": digest == single, "sets_with_error_status": int(bad)}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
@@ -281,7 +310,10 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0 = only the timed metric (no sub-records)")
     ap.add_argument("--extra-batch", type=int, default=None, help=argparse.SUPPRESS)   # (round-1 flags, still accepted)
     ap.add_argument("--host-path", type=int, default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--pmc-selfcheck", action="store_true", help="fail (exit 5) unless the committed PMC summary behind roofline.traffic is of this library's kernel sources")
+    ap.add_argument("--pmc-selfcheck", action="store_true", help="fail (exit 5) unless the committed PMC summary behind roofline.traffic is of this library's kernel sources "
+                                                                 "(the comparison itself always runs: roofline.traffic_kernel_hash_matches)")
+    ap.add_argument("--config5-graph", choices=["rsa", "bigint"], default="rsa", help="--config 5: the class BASELINE names (zk-email RSA / long_div: 121-bit registers x 17) or the "
+                                                                                       "builder's first generator (64-bit limbs x 32, division by one limb)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank flow: gloo, program emulator, toy graph (no GPU, no timing claim)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -297,7 +329,7 @@ def main():
     global CPU_SAMPLE
     CPU_SAMPLE = args.cpu_sample
     cfg = args.config
-    kind = "sha256" if cfg == 3 else "bigint" if cfg == 5 else "authv2"
+    kind = "sha256" if cfg == 3 else args.config5_graph if cfg == 5 else "authv2"
     B = args.batch_per_gpu or {2: 1024, 3: 4096, 4: 8192, 5: 32}[cfg]
     if cfg == 5:
         args.extras = 0  # (the sub-records belong to the default run)
@@ -369,6 +401,7 @@ def main():
         if args.pmc_selfcheck and PMC_CHECK["same_kernels"] is not True:
             log("bench.py --pmc-selfcheck: %s" % traffic_source)
             sys.exit(5)
+        wl.stats_from(g)
         eq_per_set = modmul_equivalents(wl.stats["hist"], g.n_witness)
         # the ceiling that binds: one-lane Montgomery products per second, chip-wide, with the multiplier the interpreter's
         # full-width bundles use (fr_mul_wave, 322 issue slots; its pinned accumulators allow two waves per SIMD) -- beside it
@@ -376,6 +409,7 @@ def main():
         peak_blk2, peak_blk1 = pkg.ubench_modmul(2, 1000, block=True), pkg.ubench_modmul(1, 1000, block=True)
         peak4 = pkg.ubench_modmul(4, 1000)
         peak = max(peak_blk2, peak_blk1, peak4)
+        PEAK["modmul_per_s"] = peak or None
         ps = g.program_stats()
         out = {
             "metric": "witnesses/sec", "value": value, "unit": "witnesses/s", "n_gpus": world, "steps": args.steps,
@@ -396,26 +430,29 @@ def main():
             "scaling_note": "weak scaling: every rank evaluates its own 1/N shard of one global batch of B x N sets; efficiency_vs_n1 = "
                             "the step time of rank 0 alone on its shard (same run, other ranks idle) over the slowest rank's step time with "
                             "all ranks busy.  No scaling curve has been measured by the builder: the GPU boxes of this pool have one GPU." if distributed else None,
-            "roofline": {"binding": "valu_issue: lone-wave instruction issue along the graph's dependency chain (see `compute`); the hbm "
-                                    "figures below are SURVEY 8(d)'s algorithmic-byte model, which this kernel does not run into "
-                                    "(operands are forwarded on chip: measured traffic is a fraction of the algorithmic bytes)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         # the same algorithmic bytes over the whole step (interpreter + pack kernel), and what the counters say
-                         # the memory system really moved over the interpreter's time: the figure that tells how far from the HBM
-                         # roofline this kernel runs (it is bound by instruction issue, see `binding`)
-                         "frac_step": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
-                         "hbm_measured_frac": (traffic / avg_interp_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": "interp_kernel<T=%d>" % tm["tile_width"],
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_interp_s * 1e3,
-                         "pack_kernel_avg_ms": float(np.mean(pack_ms)),
+            # What binds this kernel is instruction issue on lone wavefronts along the graph's dependency chain, not memory: `bound`,
+            # `achieved`, `peak`, `frac` are that ceiling (modmul-equivalents/s against the chip's one-lane Montgomery product rate measured
+            # in this run); SURVEY 8(d)'s algorithmic-byte model against the HBM peak is the `hbm` block beside it, with the counter traffic.
+            "roofline": {"bound": "valu_issue", "unit": "modmul-equivalents/s", "achieved": eq_per_set * B / avg_interp_s, "peak": peak or None,
+                         "frac": (eq_per_set * B / avg_interp_s / peak) if peak else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_kernel_hash_matches": PMC_CHECK["same_kernels"],
+                         "binding": "valu_issue: lone-wave instruction issue along the graph's dependency chain; the hbm block is SURVEY 8(d)'s "
+                                    "algorithmic-byte model, which this kernel does not run into (operands are forwarded on chip: measured traffic is a "
+                                    "fraction of the algorithmic bytes)",
+                         "kernel": "interp_kernel<T=%d>" % tm["tile_width"], "avg_launch_ms": avg_interp_s * 1e3, "pack_kernel_avg_ms": float(np.mean(pack_ms)),
                          "binding_resource": "valu_issue",
+                         "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": alg_bytes,
+                                 # the same algorithmic bytes over the whole step (interpreter + pack kernel), and what the counters say the
+                                 # memory system really moved over the interpreter's time
+                                 "frac_step": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                 "hbm_measured_frac": (traffic / avg_interp_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
                          "lanes_active_mean": ps["lanes_active_mean"], "values_per_bundle_mean": ps["values_per_bundle_mean"],
                          "lanes_active_note": "of a wavefront's 64 lanes, the mean number that hold work of a node of the graph (the four "
                                               "lanes that share a narrow bundle's product all count), and the mean number of field elements a "
                                               "bundle produces (64 = one per lane); both weighted by the modelled time of the bundles (program "
                                               "statistics).  What a lone wave pays per bundle does not depend on either, which is why "
-                                              "compute.frac is what it is",
+                                              "frac is what it is",
                          "program": {"class_bundles": ps["class_bundles"], "class_nodes": ps["class_nodes"], "fused_nodes": ps["n_fused_nodes"],
                                      "scan_steps": ps["n_scan_steps"], "model_wave_cycles": ps["model_wave_cycles"]},
                          # the floor of this execution model (one wave walks the whole graph): the compiled graph's longest dependent
@@ -478,10 +515,17 @@ def extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, o
         if cfg != 5 and os.environ.get("BENCH_SKIP_CONFIG5") is None:
             t0 = time.perf_counter()
             try:
-                out["config5"] = config5_point(pkg, dev)
+                out["config5"] = config5_point(pkg, dev, "bigint")
             except Exception as e:  # (a sub-record: its failure is reported, not fatal)
                 out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
             log("config5: %.1f s" % (time.perf_counter() - t0))
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            try:   # the class BASELINE names: zk-email RSA / long_div (121-bit registers x 17, multi-register divisor)
+                out["config5_rsa"] = config5_point(pkg, dev, "rsa")
+            except Exception as e:
+                out["config5_rsa"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("config5_rsa: %.1f s" % (time.perf_counter() - t0))
     if wl is None or wl.kind == "authv2" or world > 1:
         t0 = time.perf_counter()
         rec = config4_job(pkg, cdist, wl, dev, rank, world, distributed)
@@ -627,6 +671,16 @@ def timed_batch(g, d_in, d_out, d_st, steps=3, key=0):
     return dt, tm, float(np.mean(interp_ms)), float(np.mean(pack_ms))
 
 
+def compute_block(hist, n_witness, batch, interp_ms):
+    """modmul-equivalents/s of a sub-record's interpreter launches against the chip's one-lane Montgomery product rate measured in this
+    run (main: PEAK) -- the ceiling that binds, beside the algorithmic-byte figure that stopped telling how far a kernel is from the machine"""
+    eq = modmul_equivalents(hist, n_witness)
+    ach = eq * batch / (interp_ms * 1e-3)
+    peak = PEAK["modmul_per_s"]
+    return {"unit": "modmul-equivalents/s", "achieved": ach, "peak": peak, "frac": (ach / peak) if peak else None, "modmul_equivalents_per_set": eq,
+            "peak_source": "roofline.compute of this line (measured in this run)"}
+
+
 def config3_point(pkg, dev, batch=4096, cpu_sample=256):
     """BASELINE config 3: sha256_512, 4096 sets on one GPU; EVERY set's 256 output bits against hashlib (an anchor outside
     this repository's arithmetic), 8 sets against the oracle as whole witnesses."""
@@ -653,7 +707,7 @@ def config3_point(pkg, dev, batch=4096, cpu_sample=256):
         if "all_cores" in cpu:
             cpu["gpu_over_all_cores"] = (batch / dt) / cpu["all_cores"]["value"]
     return {"workload": "sha256_512 graph, %d input sets, 1 GPU (BASELINE config 3)" % batch, "value": batch / dt, "unit": "witnesses/s",
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "compute": compute_block(wl.stats["hist"], g.n_witness, batch, interp_ms),
             "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms, "tile_width": tm["tile_width"],
             "n_op": g.n_op, "n_witness": g.n_witness, "bundles": tm["n_bundles"],
             "sets_with_error_status": int((d_st != 0).sum().item()),
@@ -679,42 +733,64 @@ def config4_per_gpu_point(pkg, wl, dev, batch=8192):
     return {"workload": "%s, %d input sets on one GPU (per-GPU share of BASELINE config 4)" % (wl.name, batch), "value": batch / dt,
             "unit": "witnesses/s", "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms,
             "tile_width": tm["tile_width"], "interpreter_waves_per_divider_wave": tm["divider"], "launches": tm["n_launches"],
-            "roofline_frac": achieved / HBM_PEAK_GBS, "sets_with_error_status": int((d_st != 0).sum().item()),
+            "roofline_frac": achieved / HBM_PEAK_GBS, "compute": compute_block(wl.stats_from(g)["hist"], g.n_witness, batch, interp_ms),
+            "sets_with_error_status": int((d_st != 0).sum().item()),
             "matches_oracle": bool(np.array_equal(got, want) and not st.any()), "sets_checked_against_oracle": len(sample)}
 
 
-def config5_point(pkg, dev, batch=32, steps=3, cpu_sample=4):
-    """BASELINE config 5 at its named size: the 10.5 M-node bigint / long_div-class graph (32 limbs x 4000 rounds), 32 input
-    sets on one GPU (256 over 8), library-chosen program.  `cpu_sample` sets against the oracle as whole witnesses -- the same
-    sets are the CPU baseline's sample (one pinned core, then every core)."""
-    from oracle import cbind
+def config5_point(pkg, dev, kind="bigint", batch=32, steps=3, cpu_sample=4, batch_one_gpu=256):
+    """BASELINE config 5 at its named size on one of its two class graphs -- "bigint": 64-bit limbs x 32, long division by ONE limb (the
+    builder's first generator); "rsa": the class BASELINE names, zk-email RSA / long_div: 121-bit registers x 17, long_div by the
+    17-register modulus, 310 chained modular multiplications -- ten million nodes each, 32 input sets on one GPU (256 over 8),
+    library-chosen program.  `cpu_sample` sets against the oracle as whole witnesses -- the same sets are the CPU baseline's sample (one
+    pinned core, then every core).  `all_256_sets_on_one_gpu`: the whole config-5 batch on THIS GPU (the 32-set shard occupies 32 of
+    the chip's 1024 SIMDs, one wavefront per set: splitting 256 sets over 8 GPUs buys latency, not throughput)."""
     t0 = time.perf_counter()
-    wl = Workload("bigint")
+    wl = Workload(kind)
     t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
     g = pkg.Graph(wl.data)
-    rows = make_inputs(wl, g, batch, 5)
+    t_load = time.perf_counter() - t0
+    wl.stats_from(g)
+    rows = make_inputs(wl, g, batch_one_gpu, 5)
     t0 = time.perf_counter()
     key = g.pick_tile_width(batch)
     g.set_tile_width(key)
     blob_len = len(g.export_blob(key))   # (compiles the chosen program on the host; the blob is what a multi-GPU job broadcasts)
     t_compile = time.perf_counter() - t0
     d_in = torch.from_numpy(rows).to(dev)
-    d_out = torch.empty((batch, g.n_witness, 32), dtype=torch.uint8, device=dev)
-    d_st = torch.zeros(batch, dtype=torch.int32, device=dev)
-    dt, tm, interp_ms, pack_ms = timed_batch(g, d_in, d_out, d_st, steps=steps, key=key)
+    d_out = torch.empty((batch_one_gpu, g.n_witness, 32), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(batch_one_gpu, dtype=torch.int32, device=dev)
+    dt, tm, interp_ms, pack_ms = timed_batch(g, d_in[:batch], d_out[:batch], d_st[:batch], steps=steps, key=key)
     cpu = None
     if cpu_sample > 0 and CPU_SAMPLE > 0:
-        cpu = cpu_baseline(wl.data, rows, d_out, min(cpu_sample, batch), parse_reps=1, all_cores_sets=batch)
+        cpu = cpu_baseline(wl.data, rows[:batch], d_out[:batch], min(cpu_sample, batch), parse_reps=1, all_cores_sets=batch)
         cpu["gpu_over_one_core"] = (batch / dt) / cpu["value"]
         if "all_cores" in cpu:
             cpu["gpu_over_all_cores"] = (batch / dt) / cpu["all_cores"]["value"]
     ps = g.program_stats()
+    bad = int((d_st[:batch] != 0).sum().item())
+    # the whole batch of config 5 on this one GPU
+    one_gpu = None
+    if batch_one_gpu > batch:
+        try:
+            key_all = g.pick_tile_width(batch_one_gpu)
+            dt2, tm2, interp2, pack2 = timed_batch(g, d_in, d_out, d_st, steps=steps, key=key_all)
+            one_gpu = {"value": batch_one_gpu / dt2, "unit": "witnesses/s", "sets": batch_one_gpu, "ms_per_step": dt2 * 1e3, "interp_kernel_ms": interp2, "pack_kernel_ms": pack2,
+                       "tile_width": tm2["tile_width"], "bundles": tm2["n_bundles"], "sets_with_error_status": int((d_st != 0).sum().item()),
+                       "step_time_over_32_set_step": dt2 / dt, "compute": compute_block(wl.stats["hist"], g.n_witness, batch_one_gpu, interp2),
+                       "note": "all 256 sets of BASELINE config 5 on one GPU: %.2f x the 32-set step's time for 8 x the sets" % (dt2 / dt)}
+        except Exception as e:  # (a sub-record: its failure is reported, not fatal)
+            one_gpu = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"workload": "%s, %d nodes, %d input sets on one GPU (BASELINE config 5: 256 sets over 8 GPUs)" % (wl.name, g.n_nodes, batch),
-            "value": batch / dt, "unit": "witnesses/s", "ms_per_step": dt * 1e3, "steps": steps, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms,
-            "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth, "tile_width": tm["tile_width"],
-            "bundles": tm["n_bundles"], "slots": tm["n_slots"], "generate_seconds": t_gen, "compile_and_export_seconds": t_compile,
-            "program_bytes": blob_len, "class_bundles": ps["class_bundles"], "lanes_active_mean": ps["lanes_active_mean"],
-            "field_ops_per_sec": batch / dt * g.n_op, "sets_with_error_status": int((d_st != 0).sum().item()),
+            "graph": wl.source, "value": batch / dt, "unit": "witnesses/s", "ms_per_step": dt * 1e3, "steps": steps, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms,
+            "n_nodes": g.n_nodes, "n_op": g.n_op, "n_witness": g.n_witness, "depth": g.depth, "op_histogram": wl.stats["hist"], "tile_width": tm["tile_width"],
+            "bundles": tm["n_bundles"], "slots": tm["n_slots"], "generate_seconds": t_gen, "load_seconds": t_load, "compile_and_export_seconds": t_compile,
+            "program_bytes": blob_len, "class_bundles": ps["class_bundles"], "scan_steps": ps["n_scan_steps"], "lanes_active_mean": ps["lanes_active_mean"],
+            "field_ops_per_sec": batch / dt * g.n_op, "nodes_per_sec": batch / dt * g.n_nodes, "sets_with_error_status": bad,
+            "compute": compute_block(wl.stats["hist"], g.n_witness, batch, interp_ms),
+            "hbm_model_frac": g.algorithmic_bytes_per_set * batch / (interp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "all_256_sets_on_one_gpu": one_gpu,
             "cpu_baseline": cpu, "matches_oracle": (cpu or {}).get("matches_gpu"), "sets_checked_against_oracle": min(cpu_sample, batch) if cpu else 0}
 
 
@@ -803,6 +879,7 @@ def committed_traffic(graph_kind, batch, tile_width, kernel_hash=None):
     return best, src or "none: no committed PMC profile matches this graph / batch / tile width"
 
 
+PEAK = {"modmul_per_s": None}  # chip-wide one-lane Montgomery products per second measured in this run (main): the denominator of every `compute` block
 PMC_CHECK = {"same_kernels": None}  # --pmc-selfcheck: the committed PMC summary must be of the kernels this library was built from
 
 

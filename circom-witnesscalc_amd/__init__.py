@@ -82,6 +82,7 @@ EXPORTED_SYMBOLS = [
     "gwb_builder_new", "gwb_builder_free", "gwb_builder_input", "gwb_builder_constant", "gwb_builder_uno", "gwb_builder_duo", "gwb_builder_tres",
     "gwb_builder_witness", "gwb_builder_input_signal", "gwb_builder_node_count", "gwb_builder_finish",
     "gwb_ubench_modmul_block", "gwb_program_stats", "gwb_calc_witness_json_to_wtns", "gwb_model_class_cycles",
+    "gwb_graphgen_bigint_class", "gwb_graphgen_rsa_long_div_class", "gwb_graph_op_histogram",
     "gwb_kernel_source_hash", "gwb_rccl_unique_id", "gwb_rccl_comm_init", "gwb_rccl_comm_ranks", "gwb_rccl_comm_destroy",
 ]
 
@@ -138,6 +139,9 @@ def lib():
         L.gwb_graph_export.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
         L.gwb_graph_import.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
         L.gwb_free_status.argtypes = [stp]
+        L.gwb_graphgen_bigint_class.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+        L.gwb_graphgen_rsa_long_div_class.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+        L.gwb_graph_op_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), sz]
         L.gwb_profile_classes.argtypes = [vp, vp, sz, vp, vp, vp, stp]
         L.gwb_inputs_from_json_batch.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), stp]
         L.gwb_wtns_save_batch.argtypes = [vp, sz, sz, ctypes.c_char_p, stp]
@@ -217,6 +221,25 @@ def model_cycles():
     return {n: float(lib().gwb_model_class_cycles(c)) for c, n in enumerate(CLASS_NAMES)}
 
 
+def graphgen_native(kind, **kw):
+    """`.bin` bytes of one of BASELINE config 5's class graphs from the native generators (gwb_graphgen_*): kind "bigint" (k, n_bits,
+    rounds) or "rsa" (n, k, muls, range_checks) -- the same bytes as graphgen.circuits.build_bigint_class / build_rsa_long_div_class
+    write, without ten million nodes passing through Python."""
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), GwStatus()
+    L = lib()
+    if kind == "bigint":
+        rc = L.gwb_graphgen_bigint_class(int(kw.get("k", 8)), int(kw.get("n_bits", 64)), int(kw.get("rounds", 4)), ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    elif kind == "rsa":
+        rc = L.gwb_graphgen_rsa_long_div_class(int(kw.get("n", 121)), int(kw.get("k", 17)), int(kw.get("muls", 2)), 1 if kw.get("range_checks", True) else 0,
+                                               ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    else:
+        raise ValueError(kind)
+    _check(rc, st)
+    data = ctypes.string_at(out.value, n.value)
+    _libc.free(out)
+    return data
+
+
 def pick_tile_width(batch):
     """Input sets per wavefront the library uses for a batch of this size (gwb_pick_tile_width)."""
     return int(lib().gwb_pick_tile_width(batch))
@@ -288,6 +311,15 @@ class Graph:
         rc = lib().gwb_graph_import(blob, len(blob), ctypes.byref(h), ctypes.byref(st))
         _check(rc, st)
         return cls(_handle=h)
+
+    def op_histogram(self):
+        """{operation name: nodes} of the graph as loaded (gwb_graph_op_histogram)"""
+        h = (ctypes.c_uint64 * 24)()
+        if lib().gwb_graph_op_histogram(self._h, h, 24) != 0:
+            raise WitnessCalcError("gwb_graph_op_histogram failed")
+        names = ["Mul", "Div", "Add", "Sub", "Pow", "Idiv", "Mod", "Eq", "Neq", "Lt", "Gt", "Leq", "Geq", "Land", "Lor", "Shl", "Shr", "Bor", "Band", "Bxor",
+                 "Neg", "TernCond", "Input", "Const"]
+        return dict(sorted(((nm, int(h[i])) for i, nm in enumerate(names) if h[i]), key=lambda kv: -kv[1]))
 
     def export_blob(self, tile_width):
         out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), GwStatus()

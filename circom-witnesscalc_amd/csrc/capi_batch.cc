@@ -58,6 +58,19 @@ int gwb_graph_info(const gwb_graph_t* g, gwb_graph_info_t* info) {
     return 0;
 }
 
+int gwb_graph_op_histogram(const gwb_graph_t* g, uint64_t* out, size_t n) {
+    if (!g || !out || n < 24 || !g->has_graph) return 1;
+    memset(out, 0, n * sizeof *out);
+    for (const Node& nd : g->graph.nodes) {
+        if (nd.kind == N_DUO && nd.op < 20) out[nd.op]++;
+        else if (nd.kind == N_UNO) out[20]++;
+        else if (nd.kind == N_TRES) out[21]++;
+        else if (nd.kind == N_INPUT) out[22]++;
+        else if (nd.kind == N_CONST) out[23]++;
+    }
+    return 0;
+}
+
 int gwb_graph_serialize(const gwb_graph_t* g, void** out, size_t* out_len, gw_status_t* status) {
     return guarded(status, [&]() -> int {
     if (!g || !out || !out_len) return fail(status, "null argument");

@@ -75,6 +75,20 @@ uint64_t gwb_builder_node_count(const gwb_builder_t *b);
  * and in the reference's deserialize_witnesscalc_graph). */
 int gwb_builder_finish(const gwb_builder_t *b, void **out, size_t *out_len, gw_status_t *status);
 
+/* The two class graphs of BASELINE config 5 as `.bin` bytes (malloc'ed: the caller frees), generated natively.  The reference
+ * front-end cannot compile such circuits (README.md:21), so these graphs are synthetic; the specification of both is the Python
+ * generator library of the package (graphgen/circuits.py build_bigint_class / build_rsa_long_div_class), whose bytes these equal.
+ *   bigint: `rounds` rounds of a k x k schoolbook product with n_bits-bit limbs, long division by ONE limb, limb-wise min.
+ *   rsa:    `muls` chained modular multiplications on k registers of n bits (RSA-2048: n = 121, k = 17) as circom-bigint's
+ *           witness hints compute them -- schoolbook product with carries, long_div by the k-register modulus (short_div estimate,
+ *           long_scalar_mult, long_gt, long_sub per quotient digit) -- with the Num2Bits(n) range-check bits of q and r when
+ *           range_checks is not 0. */
+int gwb_graphgen_bigint_class(uint32_t k, uint32_t n_bits, uint32_t rounds, void **out, size_t *out_len, gw_status_t *status);
+int gwb_graphgen_rsa_long_div_class(uint32_t n, uint32_t k, uint32_t muls, int range_checks, void **out, size_t *out_len, gw_status_t *status);
+/* Operation histogram of a loaded graph: out[0..19] DuoOp wire codes (Mul .. Bxor), out[20] Neg, out[21] TernCond, out[22] Input nodes,
+ * out[23] constants (n >= 24 entries). */
+int gwb_graph_op_histogram(const gwb_graph_t *g, uint64_t *out, size_t n);
+
 /* JSON -> one inputs row of n_inputs x 32 bytes, canonical little-endian, row[0] = 1
  * (deserialize_inputs + get_inputs_buffer + populate_inputs, src/lib.rs:195-247, 177-181, 154-168). */
 int gwb_inputs_from_json(const gwb_graph_t *g, const char *inputs_json, void *row, gw_status_t *status);

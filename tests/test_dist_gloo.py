@@ -165,6 +165,44 @@ def test_bench_self_launch_two_ranks_dry_run():
     assert "x2" in j["config"]["parallelism"]
 
 
+@pytest.mark.timeout(420)
+def test_bench_self_launch_eight_ranks_dry_run():
+    """The launch the driver makes at round end -- `python bench.py --gpus 8` -- rehearsed on CPU with all eight ranks: one line,
+    n_gpus == 8, a process group of eight, eight contiguous shards whose gathered checksums hash to the single-process digest,
+    and the line's self-validation fields (the N = 1 step of the same run, efficiency_vs_n1) computed.  gloo + the program
+    emulator: the launch path and the shard arithmetic, not a measurement."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--dry-run", "--batch-per-gpu", "3"],
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["group_ranks"] == 8 and j["dry_run"] is True
+    assert j["matches_single_gpu_digest"] is True and j["sets_with_error_status"] == 0
+    assert "x8" in j["config"]["parallelism"] and j["efficiency_vs_n1"] is not None and j["n1_ms_per_step_same_run"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_rank_dying_before_the_broadcast_fails_the_job():
+    """A rank that dies in front of the program broadcast must end the job with a non-zero exit code -- the launcher ends the
+    ranks that wait in the collective, and the watchdog around the broadcast ends them by itself if the launcher does not --
+    within the watchdog's time, and no JSON line may be printed."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_DRYRUN_DIE_RANK="1", BENCH_BCAST_TIMEOUT="20", OMP_NUM_THREADS="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0, r.stdout
+    assert time.time() - t0 < 150
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_rejects_world_size_mismatch():
     """a launcher with fewer ranks than --gpus says (or none, with RANK set) is an error, not a silent one-GPU run"""
     import subprocess
