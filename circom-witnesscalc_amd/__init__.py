@@ -139,9 +139,10 @@ def lib():
         L.gwb_graph_export.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
         L.gwb_graph_import.argtypes = [vp, sz, ctypes.POINTER(vp), stp]
         L.gwb_free_status.argtypes = [stp]
-        L.gwb_graphgen_bigint_class.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
-        L.gwb_graphgen_rsa_long_div_class.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
-        L.gwb_graph_op_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), sz]
+        if hasattr(L, "gwb_graphgen_bigint_class"):  # (absent from an older build loaded through CWC_LIB_PATH for a same-box A/B)
+            L.gwb_graphgen_bigint_class.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+            L.gwb_graphgen_rsa_long_div_class.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(sz), stp]
+            L.gwb_graph_op_histogram.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), sz]
         L.gwb_profile_classes.argtypes = [vp, vp, sz, vp, vp, vp, stp]
         L.gwb_inputs_from_json_batch.argtypes = [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(sz), stp]
         L.gwb_wtns_save_batch.argtypes = [vp, sz, sz, ctypes.c_char_p, stp]

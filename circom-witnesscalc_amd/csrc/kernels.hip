@@ -93,6 +93,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                                                     const uint4* __restrict__ inputs, uint32_t* __restrict__ status,
                                                     unsigned long long* __restrict__ prof) {
     constexpr int G = 64 / T;
+    // MODE 2: scan / convolution / canonical-product bundles.  MODE 3 (round 5): the same plus the kinds for registers wider than a machine
+    // word -- borrow chains, comparisons, parallel carry chains of any width, 128-bit canonical products -- in instances of their own.
+    constexpr bool M2 = MODE == 2 || MODE == 3, WIDE = MODE == 3;
     constexpr uint32_t HI = 16u * T;  // byte distance between the two 16-byte halves of a value in a slot
     constexpr bool DIVIDER = W > 0;
     constexpr uint32_t NW = (W > 0 ? (uint32_t)W : 1u) * (uint32_t)PACK;  // interpreter waves per workgroup
@@ -475,7 +478,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                         pf[c][0] += t_now - st0;  // cycles of this bundle in the pipelined loop (stamp bookkeeping excluded)
                         pf[c][1] += 1;
                     }
-                if (MODE == 2 && cls == C_SCAN) {
+                if (M2 && cls == C_SCAN) {
                     pf_fused[0] += t_now - st0;
                     pf_fused[1] += 1;
                     const int kind = (h & HDR_SCAN_CONV) ? 2 : (h & HDR_SCAN_BORROW) ? 3 : (h & HDR_SCAN_LEX) ? 4 : (h & HDR_SCAN_DIV) ? 1 : 0;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         }
         wait_and_stage();
         if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
-            if constexpr (MODE == 2) {
+            if constexpr (M2) {
                 if (h & HDR_MUL_CC) {  // canonical x canonical -> canonical: limb-sized factors (below 2^64 everywhere in the wave) multiply as integers
                     auto limb_product = [&](const Fr& x, const Fr& y) -> Fr {  // x, y < 2^64
                         const uint64_t p00 = (uint64_t)x.v[0] * y.v[0], p01 = (uint64_t)x.v[0] * y.v[1], p10 = (uint64_t)x.v[1] * y.v[0], p11 = (uint64_t)x.v[1] * y.v[1];
@@ -536,7 +539,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     const uint32_t hi_a = a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7], hi_b = b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7];
                     if (!wave_any((hi_a | hi_b) != 0u)) {
                         r = limb_product(a_op, b_op);
-                    } else if (!wave_any(((a_op.v[3] | b_op.v[3]) >> 30 | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
+                    } else if (WIDE && !wave_any(((a_op.v[3] | b_op.v[3]) >> 30 | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
                         // registers wider than a word (round 5: the 121-bit registers of circom-bigint's RSA circuits): factors below 2^126 everywhere in
                         // the wave multiply as integers, sixteen 32 x 32 multiply-adds; the product is below 2^252 < r, the canonical a * b mod r
                         uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -589,12 +592,12 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // Programs of the MODE 2 instances (limb and bit graphs): the scan class is tested here, in front of the switch's binary search of
         // taken branches (~50 cycles each for a lone wave) -- config 5 44.2 -> 43.2 ms, and the smaller switch serves the other classes
         // sooner: sha256_512 372 -> 380 k witnesses/s.  (The bit class moved here as well cost both 10-20 %: profiles/r04_dispatch_ab.txt.)
-        if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
+        if constexpr (M2 && (uint32_t)T <= SCAN_MAX_T) {
             uint32_t cls_scan = cls;
             asm volatile("" : "+s"(cls_scan));
             if (cls_scan == C_SCAN) {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
                 r = fr_zero();
-                if constexpr (MODE == 2 && (uint32_t)T <= SCAN_MAX_T) {
+                if constexpr (M2 && (uint32_t)T <= SCAN_MAX_T) {
                     if (h & HDR_SCAN_CONV) {  // the columns of a k x k limb product (program_dev.h): out_c = sum_{i + j = c} x_i y_j; graph.rs:105, 110
                         const uint32_t k = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
                         const bool holds_y = active && lane < k * (uint32_t)T;  // (the columns k and above name a factor only to name one)
@@ -630,7 +633,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     const uint32_t sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu, iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
                     const bool start = (sub & SCAN_START) != 0, role_acc = (sub & SCAN_ROLE_ACC) != 0;
                     const Fr x = fr_quad_perm<QP_OUT>(a_op), acc0 = fr_quad_perm<QP_OUT>(b_op);
-                    if (h & (HDR_SCAN_BORROW | HDR_SCAN_LEX)) {
+                    // (MODE 3: compiled into the MODE 2 instances the round-5 kinds cost BASELINE config 5's first graph 10 % -- same box, same program,
+                    // same register count; laid out behind the older paths with `unlikely`, 13 %: a lone wave pays for the code it has to fetch)
+                    if (WIDE && (h & (HDR_SCAN_BORROW | HDR_SCAN_LEX))) {
                         // ---- one-bit recurrences (round 5), all steps of the bundle at once: c_out = gen | (prop & c_in), scan_bit_lookahead
                         const Fr y = fr_quad_perm<QP_ACC>(a_op);
                         const bool seg = start || !active;
@@ -731,7 +736,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             xp[7] |= cy << 31;  // (x + acc at or above 2^256: outside every parallel form)
                         }
                         // registers of any width up to 126 bits (round 5): x (+ the accumulator coming in) below min(2^(3n), 2^252) everywhere in the wave
-                        bool wide_ok = sh != 64u && sh >= 2u && sh <= 126u && iters > 2u;
+                        // (instances for widths of 32 .. 63 and 96 .. 126 bits -- 55-bit and 100 / 121-bit registers of big-integer libraries; other widths
+                        // take the serial rounds below)
+                        bool wide_ok = WIDE && sh != 64u && ((sh >= 32u && sh <= 63u) || (sh >= 96u && sh <= 126u)) && iters > 2u;
                         if (wide_ok) {
                             const Fr xpf = Fr{{xp[0], xp[1], xp[2], xp[3], xp[4], xp[5], xp[6], xp[7]}};
                             if (3u * sh >= 252u) {  // (registers of 84 bits and more: the bound is 2^252)
@@ -745,12 +752,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             }
                             if (wide_ok) {
                                 Fr limb, carry;
-                                switch (sh >> 5) {  // (the word part of the width as a template parameter: shifts with fixed register positions)
-                                    case 0: scan_carry_parallel_wide<T, 0>(seg, lane, sh, xpf, limb, carry); break;
-                                    case 1: scan_carry_parallel_wide<T, 1>(seg, lane, sh, xpf, limb, carry); break;
-                                    case 2: scan_carry_parallel_wide<T, 2>(seg, lane, sh, xpf, limb, carry); break;
-                                    default: scan_carry_parallel_wide<T, 3>(seg, lane, sh, xpf, limb, carry); break;
-                                }
+                                // (the word part of the width as a template parameter: shifts with fixed register positions)
+                                if (sh >= 96u) scan_carry_parallel_wide<T, 3>(seg, lane, sh, xpf, limb, carry);
+                                else scan_carry_parallel_wide<T, 1>(seg, lane, sh, xpf, limb, carry);
                                 r = u256_select(role_acc, carry, limb);
                             }
                         }
@@ -935,7 +939,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 auto less = [](const Fr& a, const Fr& b) {
                     Fr t;
                     const uint32_t borrow = u256_sub(t, a, b);
-                    if constexpr (MODE == 2) asm volatile("" ::"v"(t.v[7]));
+                    if constexpr (M2) asm volatile("" ::"v"(t.v[7]));
                     return borrow != 0;
                 };
                 const bool xn = less(fr_half(), x), yn = less(fr_half(), y);
@@ -1077,9 +1081,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             atomicAdd(&prof[c * 4 + 0], pf[c][0]);
             atomicAdd(&prof[c * 4 + 3], pf[c][1]);
         }
-        atomicAdd(&prof[MODE == 2 ? 68 : 64], pf_fused[0]);  // C_MULF / C_SCAN
-        atomicAdd(&prof[MODE == 2 ? 71 : 67], pf_fused[1]);
-        if (MODE == 2) {
+        atomicAdd(&prof[M2 ? 68 : 64], pf_fused[0]);  // C_MULF / C_SCAN
+        atomicAdd(&prof[M2 ? 71 : 67], pf_fused[1]);
+        if (M2) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 atomicAdd(&prof[72 + 4 * q], pf_scan[q][0]);
@@ -1236,15 +1240,16 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
         dims.stream_div_requests[0] = n_div_requests;
     }
     const uint4* recs = reinterpret_cast<const uint4*>(p.recs);
-    const uint32_t mode = p.has_fused;  // 0, 1: fused narrow bundles, 2: scan bundles (validate_program: never both)
+    const uint32_t mode = p.has_fused;  // 0, 1: fused narrow bundles, 2: scan bundles (validate_program: never both), 3: scan bundles with the wide-register kinds
     static_assert(SCAN_MAX_T == COOP_FUSE_MAX_T, "the instances with a MODE are made for tile widths up to COOP_FUSE_MAX_T");
     // the instances with a MODE (fused narrow bundles; scan / convolution / canonical-product bundles) exist for programs with no or one
     // divider wave per interpreter (compile.cc compiles nothing else, validate_program rejects it)
-    if (mode > 2 || (mode && (T > COOP_FUSE_MAX_T || W > 1))) return hipErrorInvalidValue;
+    if (mode > 3 || (mode && (T > COOP_FUSE_MAX_T || W > 1))) return hipErrorInvalidValue;
 #define CWC_LAUNCH3(TT, PP, WW, KK)                                                                                                     \
     do {                                                                                                                                \
         if constexpr ((uint32_t)(TT) <= COOP_FUSE_MAX_T && (WW) <= 1) {                                                                 \
-            if (mode == 2) interp_kernel<TT, PP, WW, KK, 2><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
+            if (mode == 3) interp_kernel<TT, PP, WW, KK, 3><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
+            else if (mode == 2) interp_kernel<TT, PP, WW, KK, 2><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
             else if (mode == 1) interp_kernel<TT, PP, WW, KK, 1><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof); \
             else interp_kernel<TT, PP, WW, KK, 0><<<grid, block, 0, stream>>>(p.hdr, recs, p.crefs, dims, wst, in, status, prof);     \
         } else {                                                                                                                        \

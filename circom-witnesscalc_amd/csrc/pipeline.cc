@@ -51,6 +51,17 @@ std::string upload_program(DeviceProgram& dp) {
     dp.dev.trash_off = p.trash_off;
     dp.dev.has_fused = 0;  // (from the bundle headers themselves: an imported program's statistics are not what the kernel runs)
     for (uint32_t h : p.hdr) dp.dev.has_fused |= (h & HDR_CLASS_MASK) == C_MULF ? 1u : ((h & HDR_CLASS_MASK) == C_SCAN || ((h & HDR_CLASS_MASK) == C_MUL && (h & HDR_MUL_CC))) ? 2u : 0u;
+    // Round 5: the kinds for registers wider than a machine word (borrow chains, comparisons, carry chains of widths other than 64 bits with
+    // their parallel form, 128-bit canonical products) live in interpreter instances of their own (MODE 3): a program with a borrow /
+    // comparison bundle, or a carry-chain bundle of another width than 64 bits, runs there; every other limb program in the MODE 2
+    // instances, whose code these kinds would only push apart (kernels.hip).
+    if (dp.dev.has_fused == 2u)
+        for (uint32_t h : p.hdr)
+            if ((h & HDR_CLASS_MASK) == C_SCAN && !(h & HDR_SCAN_CONV) &&
+                ((h & (HDR_SCAN_BORROW | HDR_SCAN_LEX)) || (!(h & HDR_SCAN_DIV) && ((h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu) != 64u))) {
+                dp.dev.has_fused = 3u;
+                break;
+            }
     dp.dev.n_streams = p.n_streams;
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dp.dev.stream_first[s] = p.stream_first[s];

@@ -172,7 +172,7 @@ struct ProgramDev {
     const uint32_t* div_lanes;     // [n_div_requests] active lanes (node slots x T) of each division request
     uint32_t n_bundles, n_slots, n_inputs, n_witness, n_const;
     uint32_t trash_off;            // where results without a slot go: OFF_NOWHERE, or (programs compiled with CWC_NOWHERE=0) the tile's trash slot
-    uint32_t has_fused;            // 1: the program has C_MULF bundles, 2: C_SCAN bundles (the interpreter instance with their path is launched)
+    uint32_t has_fused;            // 1: the program has C_MULF bundles, 2: C_SCAN bundles, 3: C_SCAN bundles of the wide-register kinds (the interpreter instance with their path is launched)
     uint32_t n_streams, stream_first[4], stream_count[4], stream_div_requests[4], stream_cref_first[4];  // (program.hpp; MAX_STREAMS entries)
 };
 
