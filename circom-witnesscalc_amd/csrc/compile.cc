@@ -397,7 +397,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 case C_IDIVMOD: return 1500;
                 case C_TERN: return 100;
                 case C_MULF: return 704.0 * (1 + (fused_op2(n.op) == FOP_MUL ? 1 : 0)) + 290.0 * ((fused_op2(n.op) > FOP_MUL ? 1 : 0) + (fused_op3(n.op) ? 1 : 0));
-                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : (n.op & (SCAN_OP_BORROW | SCAN_OP_LEX)) ? 20.0 : kCyclesScanStepCarry;  // (the serial rounds; chains of 64-bit limbs beat this "floor" with the parallel forms)
+                case C_SCAN: return n.kind == N_CONV ? kCyclesConvStep * 32 : (n.op & SCAN_OP_DIV) ? kCyclesScanStepDiv : scan_is_sel(n.op) ? 150.0 : (n.op & (SCAN_OP_BORROW | SCAN_OP_LEX)) ? 20.0 : kCyclesScanStepCarry;  // (the serial rounds; chains of 64-bit limbs beat this "floor" with the parallel forms)
                 default: return 0;
             }
         };
@@ -437,6 +437,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             return lin_operand && node_rep[i] == REP_C;
         }
         if (c == C_TERN) return q >= 1 && node_rep[i] == REP_C;
+        if (c == C_SCAN && n.kind == N_SCAN && scan_is_sel(n.op))  // a selection moves words: its arms in the form of its value, a comparison's operands canonical, a condition either way
+            return (n.op & SCAN_OP_ACC) ? node_rep[i] == REP_C : true;
         if (c == C_SCAN) return true;  // x, the accumulator, the divisor: canonical integers
         if (c == C_MUL) return (node_vflags[i] & VF_MUL_CC) != 0;  // canonical products (bit graphs: with a constant's canonical copy)
         return false;  // Mul / Div: Montgomery form
@@ -593,7 +595,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 const uint32_t key = scan_key_of((uint32_t)i);
                 if (scan_key_index(key) < 0) scan_keys.push_back(key);
                 const Node& pr = g.nodes[n.b];
-                if (!(n.op & SCAN_OP_NOACC) && pr.kind == N_SCAN && (pr.op & SCAN_OP_ACC) && scan_key_of(n.b) == key && scan_next[n.b] == 0xffffffffu) scan_next[n.b] = (uint32_t)i;
+                if (!(n.op & SCAN_OP_NOACC) && !scan_is_sel(n.op) && pr.kind == N_SCAN && (pr.op & SCAN_OP_ACC) && scan_key_of(n.b) == key && scan_next[n.b] == 0xffffffffu) scan_next[n.b] = (uint32_t)i;  // (a selection stands alone)
             }
         }
         // Narrow multiplication bundles: when no more multiplications are ready than four-lane products fit a wave, the
@@ -641,7 +643,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
             const int NH = (int)C_COUNT * (17 + (int)scan_keys.size());  // (scan steps: heap C_SCAN + C_COUNT * (17 + key index))
             std::vector<std::vector<Key>> heap(NH);
             std::vector<uint8_t> placed;  // scan nodes that sit in a bundle already (a step's successor inside its own bundle is released with it)
+            std::vector<uint8_t> sel_queued;  // selection steps that sit in their ready heap
             if (has_scans) placed.assign(N, 0);
+            if (has_scans) sel_queued.assign(N, 0);
             std::unordered_map<uint32_t, uint32_t> conv_ready;  // group -> how many of its nodes have their operands
             auto push = [&](uint32_t i) {
                 int hc = class_of(g.nodes[i]);
@@ -653,6 +657,15 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     for (uint32_t u : m) hgt = std::max(hgt, height[u]);
                     auto& hs = heap[(int)C_SCAN + (int)C_COUNT * (17 + scan_key_index(kConvKey))];
                     hs.push_back(Key(hgt + (prologue[head] ? kPrologueBoost : 0ull), tie_reverse ? head : ~head));
+                    std::push_heap(hs.begin(), hs.end());
+                    return;
+                }
+                if (hc == C_SCAN && scan_is_sel(g.nodes[i].op)) {  // a selection's two nodes name different operands: ready when both are
+                    const uint32_t o = (g.nodes[i].op & SCAN_OP_ACC) ? scan_partner[i] : i;
+                    if (placed[o] || sel_queued[o] || indeg[o] != 0 || indeg[scan_partner[o]] != 0) return;
+                    sel_queued[o] = 1;
+                    auto& hs = heap[(int)C_SCAN + (int)C_COUNT * (17 + scan_key_index(scan_key_of(o)))];
+                    hs.push_back(Key(std::max(height[o], height[scan_partner[o]]) + (prologue[o] ? kPrologueBoost : 0ull), tie_reverse ? o : ~o));
                     std::push_heap(hs.begin(), hs.end());
                     return;
                 }
@@ -693,6 +706,14 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 const int cl = sync_flags ? (int)C_SYNC : request ? (int)C_DIVREQ : collect && divider ? (int)C_DIVGET : coop == 2 ? (int)C_MULF : coop ? (int)C_MULQ : nodes.empty() ? (int)C_LIN : class_of(g.nodes[nodes[0]]);
                 if ((unsigned)cl < (unsigned)C_COUNT) ss.class_bundles[cl]++;
                 (void)b;
+                if (record && getenv("CWC_DEBUG_SCHED") && b < (uint32_t)atoi(getenv("CWC_DEBUG_SCHED"))) {  // diagnostic: the first bundles, node by node
+                    fprintf(stderr, "bundle %u class %d:", b, cl);
+                    for (size_t q = 0; q < nodes.size() && q < 6; ++q) {
+                        const Node& dn = g.nodes[nodes[q]];
+                        fprintf(stderr, " [%u k%d op%d (%u,%u,%u) h%llu]", nodes[q], dn.kind, dn.op, dn.a, dn.b, dn.c, (unsigned long long)height[nodes[q]]);
+                    }
+                    fprintf(stderr, "%s\n", nodes.size() > 6 ? " ..." : "");
+                }
                 for (uint32_t i : nodes) {
                     if (prologue[i] && !request) --prologue_left;
                     if (request) {
@@ -948,6 +969,13 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 for (int q = 0; q < arity_of(n); ++q) m = std::max(m, cp[ops[q]]);
                 cp[i] = m + node_cycles(class_of(n));
                 prologue[i] = cp[i] <= theta;
+                // (a selection step's two nodes name different operands and sit in one bundle: the later one brings both to the longer chain --
+                // one of them in the prologue and the other in a stream of its own would tear the bundle apart)
+                if (n.kind == N_SCAN && scan_is_sel(n.op) && scan_partner[i] < i) {
+                    const uint32_t o = scan_partner[i];
+                    cp[i] = cp[o] = std::max(cp[i], cp[o]);
+                    prologue[i] = prologue[o] = cp[i] <= theta;
+                }
             }
             for (size_t i = 0; i < N; ++i) {
                 if (!is_op((uint32_t)i) || prologue[i]) continue;
@@ -1088,7 +1116,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 case N_TRES: return "Tern";
                 case N_FUSED: return "fused";
                 case N_CONV: return "conv";
-                case N_SCAN: return std::string((n.op & SCAN_OP_LEX) ? "lex" : (n.op & SCAN_OP_BORROW) ? "borrow" : (n.op & SCAN_OP_DIV) ? "sdiv" : "carry") + ((n.op & SCAN_OP_ACC) ? ".acc" : ".out");
+                case N_SCAN: return std::string(scan_is_sel(n.op) ? "sel" : (n.op & SCAN_OP_LEX) ? "lex" : (n.op & SCAN_OP_BORROW) ? "borrow" : (n.op & SCAN_OP_DIV) ? "sdiv" : "carry") + ((n.op & SCAN_OP_ACC) ? ".acc" : ".out");
                 default: return n.op < sizeof kOps / sizeof *kOps ? kOps[n.op] : "?";
             }
         };
@@ -1349,7 +1377,8 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         return false;
                     }
                     const uint32_t pair = js / 2;
-                    const bool start = pair == 0 || (n.op & SCAN_OP_NOACC) || (order[k0 + 2 * pair - 1] & ~REQ_FLAG) != n.b;
+                    const bool is_sel = scan_is_sel(n.op);
+                    const bool start = pair == 0 || is_sel || (n.op & SCAN_OP_NOACC) || (order[k0 + 2 * pair - 1] & ~REQ_FLAG) != n.b;
                     ctrl |= (is_acc ? SCAN_ROLE_ACC : 0u) | (start ? SCAN_START : 0u);
                     if (!is_acc) {
                         if (!(n.op & SCAN_OP_NOX)) enc_operand(n.a, 0);  // (a chain end without this operand reads 0: the record's default)
@@ -1358,6 +1387,9 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                         scan_longest = std::max(scan_longest, scan_run);
                         scan_bits = (is_div ? HDR_SCAN_DIV : 0u) | ((n.op & SCAN_OP_BORROW) ? HDR_SCAN_BORROW : 0u) | ((n.op & SCAN_OP_LEX) ? HDR_SCAN_LEX : 0u) |
                                     ((n.op & SCAN_OP_KG) ? HDR_SCAN_KG : 0u) | ((n.op & SCAN_OP_KL) ? HDR_SCAN_KL : 0u) | (scan_shift_of_node(i) << HDR_SCAN_SHIFT_SHIFT);
+                    } else if (is_sel) {  // the ACC record: the selection's arms p, q
+                        enc_operand(n.a, 0);
+                        enc_operand(n.b, 1);
                     } else if (is_div) {
                         enc_to(n.c, 2, off[0], lds[0]);
                         off[1] = (uint32_t)mem_off(scan_imm[i]);

@@ -82,7 +82,7 @@ static inline uint64_t fused_cost50(uint8_t op) {
     return 12u + 15u + (fused_op2(op) == FOP_MUL ? 15u : fused_op2(op) ? 6u : 0u) + (fused_op3(op) ? 6u : 0u);
 }
 // a step of a scan bundle: its share of the bundle's front end and one round of the loop (cycles / 50; kCyclesScan* below)
-static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 10u : (op & (SCAN_OP_BORROW | SCAN_OP_LEX)) ? 1u : 4u; }  // (the one-bit recurrences run all steps at once)
+static inline uint64_t scan_cost50(uint8_t op) { return (op & SCAN_OP_DIV) ? 10u : scan_is_sel(op) ? 38u : (op & (SCAN_OP_BORROW | SCAN_OP_LEX)) ? 1u : 4u; }  // (the one-bit recurrences run all steps at once; a selection stands alone)
 static inline uint64_t node_cost(const uint32_t* table, const Node& n) {
     return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : n.kind == N_CONV ? 70u : cost_of(table, class_of(n));  // (a convolution bundle: ~3.5 k cycles)
 }

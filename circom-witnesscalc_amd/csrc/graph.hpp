@@ -36,7 +36,15 @@ enum NodeKind : uint8_t { N_INPUT = 0, N_CONST = 1, N_UNO = 2, N_DUO = 3, N_TRES
 //   BORROW  the borrow chain of a register-wise subtraction: OUT = x - y - bin (+ 2^n when that is negative), ACC = the borrow going out
 //   LEX     a most-significant-difference comparison: ACC = x > y ? KG : x < y ? KL : the bit coming in (KG, KL: the two op bits); OUT unused
 enum ScanOp : uint8_t { SCAN_OP_ACC = 1, SCAN_OP_DIV = 2, SCAN_OP_NOACC = 4, SCAN_OP_NOX = 8, SCAN_OP_BORROW = 16, SCAN_OP_LEX = 32, SCAN_OP_KG = 64, SCAN_OP_KL = 128 };
-static inline bool scan_has_third(uint8_t op) { return (op & (SCAN_OP_DIV | SCAN_OP_BORROW | SCAN_OP_LEX)) != 0; }  // (a divisor / a subtrahend / the other comparand)
+//   SEL     (round 5; BORROW and LEX bits both set: not a recurrence, every step stands alone) a selection through the pair's two records,
+//           with its comparison when that is an ordered one read by nothing else: OUT node a = cond (or the comparison's operands a, b),
+//           ACC node a = p, b = q; OUT = the comparison's boolean, ACC = cond ? p : q.  scan_imm: the comparison (SelCode, program_dev.h) | 8 when the
+//           boolean is wanted in Montgomery form.  The two nodes of a step name DIFFERENT operands (the scheduler waits for both).
+static const uint8_t SCAN_OP_SEL = SCAN_OP_BORROW | SCAN_OP_LEX;
+static inline bool scan_is_sel(uint8_t op) { return (op & SCAN_OP_SEL) == SCAN_OP_SEL; }
+static inline bool scan_is_borrow(uint8_t op) { return (op & SCAN_OP_SEL) == SCAN_OP_BORROW; }
+static inline bool scan_is_lex(uint8_t op) { return (op & SCAN_OP_SEL) == SCAN_OP_LEX; }
+static inline bool scan_has_third(uint8_t op) { return (op & SCAN_OP_DIV) || scan_is_borrow(op) || scan_is_lex(op); }  // (a divisor / a subtrahend / the other comparand)
 static inline uint32_t scan_kind_bits(uint8_t op) { return op & (SCAN_OP_DIV | SCAN_OP_BORROW | SCAN_OP_LEX | SCAN_OP_KG | SCAN_OP_KL); }  // (what the steps of one bundle share, with the shift)
 
 // graph::Node (reference src/graph.rs:236-245).  N_INPUT: a = input index.  N_CONST: a = index into

@@ -650,22 +650,43 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             const bool an = less(fr_half(), a), bn = less(fr_half(), b);
                             return an == bn ? less(a, b) : an;
                         };
-                        if (h & HDR_SCAN_LEX) {
+                        // lt / gt of two canonical integers with the reference's signed comparison (graph.rs:723-755); registers below 2^128 everywhere
+                        // in the wave are non-negative: one four-word subtraction decides
+                        auto compare = [&](const Fr& a, const Fr& b, bool& lt, bool& gt) {
+                            if (!wave_any(active && (a.v[4] | a.v[5] | a.v[6] | a.v[7] | b.v[4] | b.v[5] | b.v[6] | b.v[7]) != 0u)) {
+                                uint32_t d[4], bw = 0;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) d[k] = sbb32(a.v[k], b.v[k], bw);
+                                lt = bw != 0u;
+                                gt = bw == 0u && (d[0] | d[1] | d[2] | d[3]) != 0u;
+                            } else {
+                                lt = signed_lt(a, b);
+                                gt = signed_lt(b, a);
+                            }
+                        };
+                        if ((h & (HDR_SCAN_BORROW | HDR_SCAN_LEX)) == (HDR_SCAN_BORROW | HDR_SCAN_LEX)) {
+                            // selections (program_dev.h SelCode): OUT record {a, b} = x, acc0: the comparison; ACC record {p, q} = y, and the second
+                            // operand of the ACC record: the arms.  out = a <cmp> b (SEL_NEZ: a != 0), acc = out ? p : q (graph.rs:130-133, 221-225)
+                            const Fr q_arm = fr_quad_perm<QP_ACC>(b_op);
+                            const uint32_t code = sh & 7u;
+                            bool cond;
+                            if (code == SEL_NEZ) {
+                                cond = !u256_is_zero(x);
+                            } else {
+                                bool lt, gt;
+                                compare(x, acc0, lt, gt);
+                                cond = code == SEL_LT ? lt : code == SEL_GT ? gt : code == SEL_LEQ ? !gt : !lt;
+                            }
+                            if (role_acc) r = u256_select(cond, y, q_arm);
+                            else r = u256_select(cond, (sh & SEL_OUT_MONT) ? fr_one() : Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, fr_zero());
+                        } else if (h & HDR_SCAN_LEX) {
                             // acc' = x > y ? KG : x < y ? KL : acc (graph.rs:130-131, 221-225): generate = the registers differ and the winner's
                             // constant is 1, propagate = they are equal
                             const uint32_t kg = (h & HDR_SCAN_KG) ? 1u : 0u, kl = (h & HDR_SCAN_KL) ? 1u : 0u;
                             bool lt, gt;
-                            if (!wave_any(active && (x.v[4] | x.v[5] | x.v[6] | x.v[7] | y.v[4] | y.v[5] | y.v[6] | y.v[7]) != 0u)) {
-                                // registers below 2^128 everywhere in the wave: non-negative, one four-word subtraction decides
-                                uint32_t d[4], bw = 0;
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) d[k] = sbb32(x.v[k], y.v[k], bw);
-                                lt = active && bw != 0u;
-                                gt = active && bw == 0u && (d[0] | d[1] | d[2] | d[3]) != 0u;
-                            } else {
-                                lt = active && signed_lt(x, y);
-                                gt = active && signed_lt(y, x);
-                            }
+                            compare(x, y, lt, gt);
+                            lt = lt && active;
+                            gt = gt && active;
                             const bool gen = (gt && kg) || (lt && kl), prop = active && !gt && !lt;
                             const uint32_t cin = scan_bit_lookahead<T>(seg, gen || (seg && prop && a0), prop, lane);
                             const uint32_t bin = seg ? a0 : cin;

@@ -256,6 +256,37 @@ void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
         v = g.const_values[out[idx].a];
         return true;
     };
+    // Values that are 0 or 1 by construction: the constants 0 / 1, every comparison and logical operation (graph.rs:122-135 produce
+    // Fr::zero() / Fr::one()), a selection between two such values.  For them `b == 1` and `b != 0` ARE b (round 5: the predicated
+    // `if (long_gt(..) == 1)` of big-integer circuits -- an equality test and a bundle on the critical chain per use).  Memoised per new node.
+    std::vector<int8_t> bool_memo;
+    auto is_boolean = [&](uint32_t idx) -> bool {
+        if (bool_memo.size() < out.size()) bool_memo.resize(out.size(), -1);
+        if (bool_memo[idx] >= 0) return bool_memo[idx] != 0;
+        // (selections chain: an explicit stack instead of recursion)
+        std::vector<uint32_t> stack{idx};
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            if (bool_memo[i] >= 0) { stack.pop_back(); continue; }
+            const Node& n = out[i];
+            if (n.kind == N_CONST) {
+                const Fr& v = g.const_values[n.a];
+                bool small = v.v[0] <= 1u;
+                for (int w = 1; w < 8; ++w) small = small && v.v[w] == 0u;
+                bool_memo[i] = small ? 1 : 0;
+            } else if (n.kind == N_DUO) {
+                bool_memo[i] = (n.op >= OP_EQ && n.op <= OP_LOR) ? 1 : 0;
+            } else if (n.kind == N_TRES) {
+                if (bool_memo[n.b] < 0) { stack.push_back(n.b); continue; }
+                if (bool_memo[n.c] < 0) { stack.push_back(n.c); continue; }
+                bool_memo[i] = (bool_memo[n.b] == 1 && bool_memo[n.c] == 1) ? 1 : 0;
+            } else {
+                bool_memo[i] = 0;
+            }
+            stack.pop_back();
+        }
+        return bool_memo[idx] != 0;
+    };
     // Constants of the file sit in front of their users or (appended by earlier rewrites) behind them: number them first.
     for (size_t i = 0; i < N; ++i)
         if (g.nodes[i].kind == N_CONST) {
@@ -333,6 +364,12 @@ void optimize_loaded_graph(Graph& g, OptimizeStats* stats) {
                 st.folded++;
             } else if (op == OP_DIV && cb && u256_eq(vb, one_canon())) {
                 repl = c.a;
+                st.folded++;
+            } else if (op == OP_EQ && ((cb && u256_eq(vb, one_canon()) && is_boolean(c.a)) || (ca && u256_eq(va, one_canon()) && is_boolean(c.b)))) {
+                repl = cb ? c.a : c.b;  // b == 1 for b in {0, 1}: b (graph.rs:122-125 gives Fr::one() / Fr::zero(), the same field elements)
+                st.folded++;
+            } else if (op == OP_NEQ && ((cb && is_zero(vb) && is_boolean(c.a)) || (ca && is_zero(va) && is_boolean(c.b)))) {
+                repl = cb ? c.a : c.b;  // b != 0 for b in {0, 1}: b (graph.rs:126-129)
                 st.folded++;
             }
         }

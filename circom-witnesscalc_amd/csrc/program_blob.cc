@@ -60,7 +60,9 @@ bool validate_program(const Program& p, std::string& err) {
             } else {
                 // one kind per bundle: carry chain, long division by one limb, borrow chain, comparison (the last with its two result bits; its shift field: 1 = the chain's bits in Montgomery form)
                 const uint32_t kinds = h & (HDR_SCAN_DIV | HDR_SCAN_BORROW | HDR_SCAN_LEX);
-                const bool kind_ok = (kinds & (kinds - 1u)) == 0 && (!(h & (HDR_SCAN_KG | HDR_SCAN_KL)) || (h & HDR_SCAN_LEX)) && (!(h & HDR_SCAN_LEX) || sh <= 1u);
+                const bool sel = kinds == (HDR_SCAN_BORROW | HDR_SCAN_LEX);  // a bundle of selections: the comparison's code in the shift field
+                const bool kind_ok = sel ? (!(h & (HDR_SCAN_KG | HDR_SCAN_KL)) && (sh & 7u) >= SEL_LT && (sh & 7u) <= SEL_NEZ && sh < 16u && iters == 1u)
+                                         : ((kinds & (kinds - 1u)) == 0 && (!(h & (HDR_SCAN_KG | HDR_SCAN_KL)) || (h & HDR_SCAN_LEX)) && (!(h & HDR_SCAN_LEX) || sh <= 1u));
                 if (T > SCAN_MAX_T || (cnt & 1u) || cnt == 0 || iters > cnt / 2 || sh >= 254u || (h & 0x61000u) || !kind_ok) return bad("bundle " + std::to_string(b) + ": scan bundle");
             }
         }
@@ -161,7 +163,7 @@ void program_blob_write(const Program& p, uint8_t* dst) {
     BlobHeader h;
     memset(&h, 0, sizeof h);
     h.magic = kBlobMagic;
-    h.version = 19;  // (19: scan bundles of one-bit recurrences (HDR_SCAN_BORROW / HDR_SCAN_LEX).  18: convolution bundles (C_SCAN with HDR_SCAN_CONV), one more statistics word.  17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
+    h.version = 20;  // (20: selection bundles (C_SCAN with both HDR_SCAN_BORROW and HDR_SCAN_LEX).  19: scan bundles of one-bit recurrences (HDR_SCAN_BORROW / HDR_SCAN_LEX).  18: convolution bundles (C_SCAN with HDR_SCAN_CONV), one more statistics word.  17: results without a slot go nowhere (OFF_NOWHERE) instead of a trash slot.  16: scan bundles, class 14, in place of round 3's macro bundles; one more statistics word.  15: blob_checksum in the image's trailer)
     h.T = p.T; h.G = p.G; h.n_bundles = p.n_bundles; h.n_slots = p.n_slots; h.n_const = p.n_const;
     h.n_inputs = p.n_inputs; h.n_witness = p.n_witness;
     h.divider = p.divider; h.n_div_requests = p.n_div_requests;
@@ -192,7 +194,7 @@ bool program_from_blob(const uint8_t* data, size_t len, Program& p, std::string&
     BlobHeader h;
     if (len < sizeof h) { err = "program blob too short"; return false; }
     memcpy(&h, data, sizeof h);
-    if (h.magic != kBlobMagic || h.version != 19 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
+    if (h.magic != kBlobMagic || h.version != 20 || h.T == 0 || h.T > 64 || h.G != 64 / h.T || (h.divider != 0 && h.divider != 1 && h.divider != 3 && h.divider != 4)) { err = "bad program blob header"; return false; }
     p = Program();
     p.T = h.T; p.G = h.G; p.n_bundles = h.n_bundles; p.n_slots = h.n_slots; p.n_const = h.n_const;
     p.n_inputs = h.n_inputs; p.n_witness = h.n_witness; p.stats = h.stats;

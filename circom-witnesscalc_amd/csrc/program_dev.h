@@ -73,6 +73,10 @@ enum BundleClass : uint32_t {
 static const uint32_t COOP_LANES = 4, COOP_MAX_T = 4, COOP_FUSE_MAX_T = 2, SCAN_MAX_T = 2;
 static const uint32_t HDR_SCAN_DIV = 1u << 11, HDR_SCAN_CONV = 1u << 12;
 // one-bit recurrences (round 5): bit 13 BORROW, bit 14 LEX with its two result bits KG (bit 15), KL (bit 16)
+// selection bundles (round 5): both of the bits below set; the shift field holds the comparison -- SelCode, + SEL_OUT_MONT when the OUT value
+// (the comparison's boolean) is wanted as a Montgomery-form boolean.  OUT record {a, b}: the comparison's operands (SEL_NEZ: a alone, the
+// condition); ACC record {p, q}: the arms; out = a <cmp> b (graph.rs:130-133; SEL_NEZ: a != 0), acc = out ? p : q (graph.rs:221-225).
+enum SelCode : uint32_t { SEL_LT = 1, SEL_GT = 2, SEL_LEQ = 3, SEL_GEQ = 4, SEL_NEZ = 5, SEL_OUT_MONT = 8 };
 static const uint32_t HDR_SCAN_BORROW = 1u << 13, HDR_SCAN_LEX = 1u << 14, HDR_SCAN_KG = 1u << 15, HDR_SCAN_KL = 1u << 16;
 static const int HDR_SCAN_SHIFT_SHIFT = 19, HDR_SCAN_ITER_SHIFT = 27;
 static const uint32_t SCAN_ROLE_ACC = 1u, SCAN_START = 2u;  // sub-op bits of a scan record

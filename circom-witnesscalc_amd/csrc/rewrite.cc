@@ -1018,9 +1018,38 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
             }
         }
     }
+    // ---- selections (SCAN_OP_SEL), in programs that hold the kinds above anyway (they run in the MODE 3 interpreter instances): a
+    // TernCond whose condition is an ordered comparison that nothing else reads goes through a pair of records with it -- the comparison's
+    // operands in the OUT record, the arms in the ACC record, all four staged like any operand: one bundle instead of a comparison bundle
+    // and a selection bundle with its two dependent global loads for the third operand.  (CWC_SEL_NEZ=1: every other TernCond as well,
+    // its condition tested against zero.)
+    // Exact: the same comparison (graph.rs:130-133, 723-769) and the same selection (:221-225) on the same values.
+    struct Sel { uint32_t out, acc, a, b, p, q, imm; bool nez; };
+    std::vector<Sel> sels;
+    if (!steps.empty() && !getenv("CWC_NO_SEL_SCANS")) {
+        for (size_t j = 0; j < N; ++j) {
+            const Node& n = g.nodes[j];
+            if (n.kind != N_TRES || taken[j]) continue;
+            const Node& C = g.nodes[n.a];
+            const bool ordered = C.kind == N_DUO && (C.op == OP_LT || C.op == OP_GT || C.op == OP_LEQ || C.op == OP_GEQ);
+            const uint8_t want = VF_A_CANON | VF_B_CANON;
+            if (ordered && !getenv("CWC_NO_SEL_CMP") && uses[n.a] == 1 && !wit_uses[n.a] && !taken[n.a] && (vflags[n.a] & want) == want && canon(C.a) && canon(C.b)) {
+                const uint32_t code = C.op == OP_LT ? SEL_LT : C.op == OP_GT ? SEL_GT : C.op == OP_LEQ ? SEL_LEQ : SEL_GEQ;
+                sels.push_back(Sel{n.a, (uint32_t)j, C.a, C.b, n.b, n.c, code, false});
+                taken[n.a] = taken[j] = 1;
+            } else if (getenv("CWC_SEL_NEZ")) {
+                // (opt-in: on the RSA-class graph the list scheduler then starts the next digits' low registers ahead in one-node bundles --
+                // 562 bundles per multiplication against 495 with the comparisons' selections alone, 513 with none; profiles/r05_rsa_steps.txt)
+                // any other condition: its value is tested against zero; the step's OUT node is a new node behind the graph's last one (operands still precede their users)
+                sels.push_back(Sel{NONE, (uint32_t)j, n.a, n.a, n.b, n.c, SEL_NEZ, true});
+                taken[j] = 1;
+            }
+        }
+    }
     if (getenv("CWC_DEBUG_SCAN")) {
         size_t nb = 0;
         for (const Step& st : steps) nb += (st.op & SCAN_OP_BORROW) != 0;
+        fprintf(stderr, "selections with their comparison: %zu\n", sels.size());
         fprintf(stderr, "bit scans: %zu borrow candidates, %zu comparison candidates; steps: %zu borrow, %zu comparison\n", cand_borrow, cand_lex, nb, steps.size() - nb);
     }
     if (steps.empty()) return;
@@ -1033,17 +1062,35 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
         scan_partner[st.acc] = st.out;
     }
     n_steps += steps.size();
+    for (Sel& st : sels) {
+        if (st.nez) {
+            st.out = (uint32_t)g.nodes.size();
+            g.nodes.push_back(Node{N_SCAN, (uint8_t)(SCAN_OP_SEL | SCAN_OP_NOACC), st.a, st.a, st.a});
+            rep.push_back(REP_C);
+            vflags.push_back(0);
+            scan_imm.push_back(0);
+            scan_partner.push_back(NONE);
+        }
+        g.nodes[st.out] = Node{N_SCAN, (uint8_t)(SCAN_OP_SEL | (st.nez ? SCAN_OP_NOACC : 0)), st.a, st.b, st.a};
+        g.nodes[st.acc] = Node{N_SCAN, (uint8_t)(SCAN_OP_SEL | SCAN_OP_ACC), st.p, st.q, st.p};
+        vflags[st.out] = vflags[st.acc] = 0;
+        scan_imm[st.out] = scan_imm[st.acc] = st.imm;
+        scan_partner[st.out] = st.acc;
+        scan_partner[st.acc] = st.out;
+    }
+    n_steps += sels.size();
     // sweep: pure nodes that nothing reads any more (the arms, the conditions, the sums under them); a step's nodes stay as a pair
-    std::vector<uint32_t> live_uses(N, 0);
-    for (size_t i = 0; i < N; ++i) {
+    const size_t N2 = g.nodes.size();  // (with the OUT nodes of the plain selections)
+    std::vector<uint32_t> live_uses(N2, 0);
+    for (size_t i = 0; i < N2; ++i) {
         const Node& n = g.nodes[i];
         const uint32_t ops[3] = {n.a, n.b, n.c};
         for (int q = 0; q < arity_of(n); ++q) live_uses[ops[q]]++;
     }
     for (uint32_t w : g.witness_signals) live_uses[w]++;
-    std::vector<uint8_t> dead(N, 0);
+    std::vector<uint8_t> dead(N2, 0);
     bool any_dead = false;
-    for (size_t i = N; i-- > 0;) {
+    for (size_t i = N2; i-- > 0;) {
         const Node& n = g.nodes[i];
         if (live_uses[i]) continue;
         bool pure = false;

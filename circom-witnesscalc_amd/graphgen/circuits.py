@@ -1173,4 +1173,16 @@ def build_bit_recurrence_variants(seed):
                     b.signal(res)
             b.signal(b.tern(b.op("Eq", res, one), xs[0], ys[0]))
             b.signal(res)
+    # selections on an ordered comparison that nothing else reads (clamps, minima, maxima: one selection bundle with the comparison inside),
+    # and some whose comparison is read again or is a witness element (left alone)
+    for i in range(min(k, rnd.randrange(1, 6))):
+        cmp_op = rnd.choice(["Lt", "Gt", "Leq", "Geq"])
+        lhs, rhs = rnd.choice([xs[i], ys[i]]), rnd.choice([ys[i], mask, b.const(rnd.getrandbits(min(n, 250))), xs[(i + 1) % k]])
+        c = b.op(cmp_op, lhs, rhs)
+        arms = [rnd.choice([lhs, rhs, mask, zero, one, xs[0]]) for _ in range(2)]
+        sel = b.signal(b.tern(c, arms[0], arms[1]))
+        if rnd.random() < 0.2:
+            b.signal(c)
+        if rnd.random() < 0.3:
+            b.signal(b.add(sel, c) if rnd.random() < 0.5 else b.op("Band", sel, mask))
     return b

@@ -214,12 +214,32 @@ def run(blob: Blob, inputs_row):
                 assert all(v < model.M for v in xs + ys)
                 for c in range(cnt):
                     results.append((dsts[c], sum(xs[i] * ys[c - i] for i in range(k) if 0 <= c - i < k) % model.M))
-            is_borrow, is_lex = bool(h & HDR_SCAN_BORROW), bool(h & HDR_SCAN_LEX)
+            is_sel = (h & (HDR_SCAN_BORROW | HDR_SCAN_LEX)) == (HDR_SCAN_BORROW | HDR_SCAN_LEX)  # selections: the comparison's code in the shift field
+            is_borrow, is_lex = bool(h & HDR_SCAN_BORROW) and not is_sel, bool(h & HDR_SCAN_LEX) and not is_sel
+            if is_sel:
+                assert not is_div and not is_conv and iters == 1 and 1 <= (sh & 7) <= 5 and sh < 16 and not (h & (HDR_SCAN_KG | HDR_SCAN_KL))
+                for pr in range(cnt // 2):
+                    ro = blob.recs[(b * G + 2 * pr) * 4:(b * G + 2 * pr) * 4 + 4]
+                    ra = blob.recs[(b * G + 2 * pr + 1) * 4:(b * G + 2 * pr + 1) * 4 + 4]
+                    co, ca = ro[2] & CTRL_MASK, ra[2] & CTRL_MASK
+                    assert co & CTRL_ACTIVE and ca & CTRL_ACTIVE and not (co & SCAN_ROLE_ACC) and (ca & SCAN_ROLE_ACC) and (co & SCAN_START) and (ca & SCAN_START)
+                    xa = fetch(ro[0], ro[3] & 0xFFFF, 0, 2 * pr)
+                    pa, qa = fetch(ra[0], ra[3] & 0xFFFF, 0, 2 * pr + 1), fetch(ra[1], ra[3] >> 16, 1, 2 * pr + 1)
+                    code = sh & 7
+                    if code == 5:   # the condition's stored word against zero (either form)
+                        assert ro[1] == zero_off
+                        cond = xa != 0
+                    else:           # an ordered comparison of canonical integers (graph.rs:130-133)
+                        xb = fetch(ro[1], ro[3] >> 16, 1, 2 * pr)
+                        assert xa < model.M and xb < model.M
+                        cond = bool(model.eval_duo(["Lt", "Gt", "Leq", "Geq"][code - 1], xa, xb))
+                    results.append((ro[2] & ~CTRL_MASK, (R_MONT if sh & 8 else 1) if cond else 0))
+                    results.append((ra[2] & ~CTRL_MASK, pa if cond else qa))
             assert is_conv or (cnt % 2 == 0 and (h & 0x61000) == 0 and sh < 254 and is_div + is_borrow + is_lex <= 1)
             assert is_lex or not (h & (HDR_SCAN_KG | HDR_SCAN_KL))
             assert not is_lex or sh <= 1  # (1: the chain's bits are Montgomery-form booleans)
             acc, seg, longest = None, 0, 0
-            for pr in range(0 if is_conv else cnt // 2):
+            for pr in range(0 if is_conv or is_sel else cnt // 2):
                 ro = blob.recs[(b * G + 2 * pr) * 4:(b * G + 2 * pr) * 4 + 4]
                 ra = blob.recs[(b * G + 2 * pr + 1) * 4:(b * G + 2 * pr + 1) * 4 + 4]
                 co, ca = ro[2] & CTRL_MASK, ra[2] & CTRL_MASK
@@ -258,7 +278,7 @@ def run(blob: Blob, inputs_row):
                     out = 0
                 results.append((ro[2] & ~CTRL_MASK, out))
                 results.append((ra[2] & ~CTRL_MASK, acc))
-            assert is_conv or iters == longest, "the iteration count is the longest chain segment"
+            assert is_conv or is_sel or iters == longest, "the iteration count is the longest chain segment"
             for pos in range(cnt, G):
                 a_off, b_off, dctl, lds = blob.recs[(b * G + pos) * 4:(b * G + pos) * 4 + 4]
                 assert not (dctl & CTRL_ACTIVE) and (dctl & ~CTRL_MASK) == trash and a_off == zero_off and b_off == zero_off
