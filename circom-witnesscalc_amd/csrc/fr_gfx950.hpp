@@ -930,4 +930,93 @@ FRD void u128_divrem_64_recip(uint64_t th, uint64_t tl, uint64_t d, uint32_t s, 
     rem = rn >> s;
 }
 
+// ---- division by a two-word divisor (round 5: the quotient-digit estimates of multi-register long division, a 2n-bit value by an n-bit
+// register with 64 < n <= 128: zk-email's 121-bit registers) ------------------------------------------------------------------------
+// Moeller & Granlund, "Improved division by invariant integers" (IEEE TC 2011): Algorithm 6 refines the one-word reciprocal of d1 into the
+// reciprocal v of the normalised two-word divisor (d1:d0), v = floor((2^192 - 1) / (d1:d0)) - 2^64; Algorithm 5 divides three words by
+// two with it: (u2:u1:u0) / (d1:d0) with (u2:u1) < (d1:d0) -> one quotient word and a two-word remainder, two multiplications.
+FRD uint64_t recip64_3by2(uint64_t d1, uint64_t d0) {  // d1 normalised (top bit set)
+    uint64_t v = recip64(d1);
+    uint64_t p = d1 * v + d0;
+    if (p < d0) {
+        --v;
+        if (p >= d1) {
+            --v;
+            p -= d1;
+        }
+        p -= d1;
+    }
+    const uint64_t t1 = mulhi64(v, d0), t0 = v * d0;
+    p += t1;
+    if (p < t1) {
+        --v;
+        if (p > d1 || (p == d1 && t0 >= d0)) --v;
+    }
+    return v;
+}
+FRD void div3by2(uint64_t u2, uint64_t u1, uint64_t u0, uint64_t d1, uint64_t d0, uint64_t v, uint64_t& q, uint64_t& r1, uint64_t& r0) {
+    uint64_t q0 = v * u2, q1 = mulhi64(v, u2);
+    q0 += u1;
+    q1 += u2 + (q0 < u1 ? 1ull : 0ull);
+    uint64_t a1 = u1 - q1 * d1;
+    const uint64_t t1 = mulhi64(d0, q1), t0 = d0 * q1;
+    // (a1:a0) = (a1:u0) - (t1:t0) - (d1:d0)  (mod 2^128)
+    uint64_t a0 = u0 - t0;
+    a1 -= t1 + (u0 < t0 ? 1ull : 0ull);
+    const uint64_t b0 = a0 - d0;
+    a1 -= d1 + (a0 < d0 ? 1ull : 0ull);
+    a0 = b0;
+    ++q1;
+    if (a1 >= q0) {
+        --q1;
+        const uint64_t c0 = a0 + d0;
+        a1 += d1 + (c0 < a0 ? 1ull : 0ull);
+        a0 = c0;
+    }
+    if (a1 > d1 || (a1 == d1 && a0 >= d0)) {
+        ++q1;
+        const uint64_t c0 = a0 - d0;
+        a1 -= d1 + (a0 < d0 ? 1ull : 0ull);
+        a0 = c0;
+    }
+    q = q1;
+    r1 = a1;
+    r0 = a0;
+}
+// q = floor(a / b), rem = a mod b for any a < 2^256 and 2^64 <= b < 2^128 (graph.rs:112-121 on such operands): three quotient words.
+FRD void u256_divrem_128(Fr& q, Fr& rem, const Fr& a, const Fr& b) {
+    const uint64_t bh = ((uint64_t)b.v[3] << 32) | b.v[2], bl = ((uint64_t)b.v[1] << 32) | b.v[0];
+    const uint32_t s = clz64_nonzero(bh);  // bh != 0
+    const uint64_t d1 = (bh << s) | ((bl >> 1) >> (63u - s)), d0 = bl << s;
+    const uint64_t v = recip64_3by2(d1, d0);
+    uint64_t aw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aw[k] = ((uint64_t)a.v[2 * k + 1] << 32) | a.v[2 * k];
+    uint64_t u[5];  // a << s
+    u[0] = aw[0] << s;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) u[k] = (aw[k] << s) | ((aw[k - 1] >> 1) >> (63u - s));
+    u[4] = (aw[3] >> 1) >> (63u - s);
+    uint64_t qw[3];
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+        uint64_t r1, r0;
+        div3by2(u[j + 2], u[j + 1], u[j], d1, d0, v, qw[j], r1, r0);
+        u[j + 1] = r1;
+        u[j] = r0;
+    }
+    q = fr_zero();
+    rem = fr_zero();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        q.v[2 * j] = (uint32_t)qw[j];
+        q.v[2 * j + 1] = (uint32_t)(qw[j] >> 32);
+    }
+    const uint64_t rl = (u[0] >> s) | ((u[1] << 1) << (63u - s)), rh = u[1] >> s;
+    rem.v[0] = (uint32_t)rl;
+    rem.v[1] = (uint32_t)(rl >> 32);
+    rem.v[2] = (uint32_t)rh;
+    rem.v[3] = (uint32_t)(rh >> 32);
+}
+
 }  // namespace cwc

@@ -1044,8 +1044,23 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 Fr ys = y;
                 ys.v[0] |= yz ? 1u : 0u;
                 Fr q, rem;
+                // (round 5, MODE 3) divisors of two 64-bit words everywhere in the wave (or zero: the result is forced below): the quotient-digit
+                // estimate of a multi-register long division, a 2n-bit value by an n-bit register (zk-email: n = 121) -- three-by-two division
+                // with a reciprocal instead of 32-bit digits (6.3 k -> ~2 k cycles per bundle)
+                bool two_words = false;
+                if constexpr (WIDE) two_words = !wave_any(active && !yz && ((ys.v[2] | ys.v[3]) == 0u || (ys.v[4] | ys.v[5] | ys.v[6] | ys.v[7]) != 0u));
                 if (!wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | ys.v[2] | ys.v[3] | ys.v[4] | ys.v[5] | ys.v[6] | ys.v[7]) != 0u)) {
                     u128_divrem_64(q, rem, x, ys);  // limb-sized operands everywhere in the wave (x < 2^128, y < 2^64): short division
+                } else if (WIDE && two_words) {
+                    const bool sub = yz || !active;  // (a lane without a two-word divisor of its own divides by 2^64: its result is unused)
+                    Fr yy = ys;
+                    yy.v[0] = sub ? 0u : ys.v[0];
+                    yy.v[1] = sub ? 0u : ys.v[1];
+                    yy.v[2] = sub ? 1u : ys.v[2];
+                    yy.v[3] = sub ? 0u : ys.v[3];
+#pragma unroll
+                    for (int k = 4; k < 8; ++k) yy.v[k] = 0u;
+                    u256_divrem_128(q, rem, x, yy);
                 } else {
                     // quotient digits (32 bits each) of the longest quotient in the wave: bitlen(x) - bitlen(y) + 1 bits
                     const uint32_t lx = u256_bitlen(x), ly = u256_bitlen(ys);

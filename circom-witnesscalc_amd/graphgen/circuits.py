@@ -1173,6 +1173,12 @@ def build_bit_recurrence_variants(seed):
                     b.signal(res)
             b.signal(b.tern(b.op("Eq", res, one), xs[0], ys[0]))
             b.signal(res)
+    # integer divisions by registers (the quotient-digit estimates of multi-register long division: a product of two registers, or the
+    # field element an input is, by a register -- divisors of one, two and more 64-bit words, zero among them)
+    for i in range(min(k, rnd.randrange(0, 5))):
+        num = rnd.choice([b.mul(xs[i], ys[i]), b.add(b.mul(xs[i], base), ys[i]), xs_in[i], xs[i]])
+        den = rnd.choice([ys[i], ys[i], xs[(i + 1) % k], b.op("Band", ys_in[i], b.const((1 << rnd.choice([64, 65, 100, 121, 128])) - 1)), zero])
+        b.signal(b.op(rnd.choice(["Idiv", "Mod"]), num, den))
     # selections on an ordered comparison that nothing else reads (clamps, minima, maxima: one selection bundle with the comparison inside),
     # and some whose comparison is read again or is a witness element (left alone)
     for i in range(min(k, rnd.randrange(1, 6))):

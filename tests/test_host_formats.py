@@ -1050,7 +1050,7 @@ def test_loader_and_compiler_under_sanitizers(tmp_path):
 
 
 @pytest.mark.parametrize("perturb", [None, 1, -1])
-@pytest.mark.parametrize("which", ["div_digits_test", "div_short_test", "div_recip_test"])
+@pytest.mark.parametrize("which", ["div_digits_test", "div_short_test", "div_recip_test", "div_3by2_test"])
 def test_digitwise_division_on_host(tmp_path, perturb, which):
     """u256_divrem_digits and u128_divrem_64 (Idiv / Mod bundles) == the bit-serial division, also when the
     floating-point quotient-digit estimate is off by one in either direction; the division by an invariant limb of the
