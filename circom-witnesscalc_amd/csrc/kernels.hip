@@ -780,9 +780,9 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             xp[7] |= cy << 31;  // (x + acc at or above 2^256: outside every parallel form)
                         }
                         // registers of any width up to 126 bits (round 5): x (+ the accumulator coming in) below min(2^(3n), 2^252) everywhere in the wave
-                        // (instances for widths of 32 .. 63 and 96 .. 126 bits -- 55-bit and 100 / 121-bit registers of big-integer libraries; other widths
-                        // take the serial rounds below)
-                        bool wide_ok = WIDE && sh != 64u && ((sh >= 32u && sh <= 63u) || (sh >= 96u && sh <= 126u)) && iters > 2u;
+                        // (instances for widths of 32 .. 126 bits but 64 -- the 55-, 86-, 100-, 121-bit registers of big-integer libraries; narrower
+                        // registers take the serial rounds below)
+                        bool wide_ok = WIDE && sh != 64u && sh >= 32u && sh <= 126u && iters > 2u;
                         if (wide_ok) {
                             const Fr xpf = Fr{{xp[0], xp[1], xp[2], xp[3], xp[4], xp[5], xp[6], xp[7]}};
                             if (3u * sh >= 252u) {  // (registers of 84 bits and more: the bound is 2^252)
@@ -798,6 +798,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                                 Fr limb, carry;
                                 // (the word part of the width as a template parameter: shifts with fixed register positions)
                                 if (sh >= 96u) scan_carry_parallel_wide<T, 3>(seg, lane, sh, xpf, limb, carry);
+                                else if (sh >= 64u) scan_carry_parallel_wide<T, 2>(seg, lane, sh, xpf, limb, carry);
                                 else scan_carry_parallel_wide<T, 1>(seg, lane, sh, xpf, limb, carry);
                                 r = u256_select(role_acc, carry, limb);
                             }

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence of one code state on one MI355X box (run through gpurun from the repository root):
-#   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r04'
-# then, back in the container:  python tools/profile_summary.py r04  and  bash tools/copy_evidence.sh r04  (the logs named in profiles/README.md).
+#   gpurun --timeout 3600 -- 'bash tools/collect_evidence.sh r05'
+# then, back in the container:  python tools/profile_summary.py r05  and  bash tools/copy_evidence.sh r05  (the logs named in profiles/README.md).
 # Each rocprofv3 pass is its own command with the program directly behind `--`; counter passes carry no trace domains.
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
@@ -25,15 +25,18 @@ python tools/pmc_cache_summary.py $R > $O/cache_counters_$R.log 2>&1
 PROBE_T=258,2,4 python tools/gpu_classprof.py > $O/classprof_$R.log 2>&1
 PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 PROBE_GRAPH=bigint PROBE_B=32 PROBE_T=1,2 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
+PROBE_GRAPH=rsa RSA_MULS=4 PROBE_B=32 PROBE_T=1,2 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 python tools/gpu_sweep.py > $O/sweep_$R.log 2>&1
 python tools/gpu_autopick.py > $O/autopick_$R.log 2>&1
 python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
 (cd tools/ubench && ./coop_mul) > $O/coop_mul_$R.log 2>&1
 (cd tools/ubench && timeout 120 ./scan_par_test) > $O/scan_par_$R.log 2>&1
+(cd tools/ubench && timeout 120 ./inv_coop_bench) > $O/inv_coop_$R.log 2>&1
 (cd tools/ubench && for v in r02 cxx sh32 blk; do echo "== inv_bench_$v"; timeout 120 ./inv_bench_$v; done) > $O/inv_bench_$R.log 2>&1
 python tools/gpu_e2e.py > $O/e2e_$R.log 2>&1
 CWC_FUSE=1001 SOAK_SEEDS=2000 SOAK_BASE=20261004 python tools/gpu_soak.py > $O/soak_fused_$R.log 2>&1
 SOAK_KINDS=limb SOAK_SEEDS=3000 SOAK_BASE=20261104 python tools/gpu_soak.py > $O/soak_scan_$R.log 2>&1
+SOAK_KINDS=limb SOAK_WIDE_SHARE=1.0 SOAK_SEEDS=3000 SOAK_BASE=20261105 python tools/gpu_soak.py > $O/soak_wide_$R.log 2>&1
 CWC_FUSE=11 PROBE_B=256 PROBE_T=4353 python tools/gpu_classprof.py > $O/classprof_fused_$R.log 2>&1
 python bench.py --config 3 --cpu-sample 128 > $O/bench_config3_$R.json 2> $O/bench_config3_$R.err
 python bench.py --config 4 --cpu-sample 0 > $O/bench_config4_$R.json 2> $O/bench_config4_$R.err
@@ -47,7 +50,9 @@ CWC_PROGRAM_CACHE=/tmp/cwc_cache_$R CWC_DEBUG_CACHE=1 SHOTS=6 python tools/gpu_s
 echo "---- third process, no cache, where the first call's time goes" >> $O/single_shot_$R.log
 CWC_PROGRAM_CACHE=0 CWC_DEBUG_SINGLE=1 SHOTS=2 python tools/gpu_single_shot.py >> $O/single_shot_$R.log 2>&1
 BIGINT_ROUNDS=4000 PROBE_T=0 python tools/gpu_bigint.py > $O/config5_$R.log 2>&1
+RSA_MULS=310 PROBE_T=0,1,2 RSA_CHECK=32 python tools/gpu_rsa.py > $O/config5_rsa_$R.log 2>&1
 python bench.py --config 5 --cpu-sample 32 > $O/bench_config5_$R.json 2> $O/bench_config5_$R.err
+python bench.py --config 5 --config5-graph bigint --cpu-sample 32 > $O/bench_config5_bigint_$R.json 2> $O/bench_config5_bigint_$R.err
 python tools/gpu_streams.py > $O/streams_$R.log 2>&1
 SOAK_SEEDS=20000 SOAK_BASE=20261003 python tools/gpu_soak.py > $O/soak_$R.log 2>&1
 bash tools/gpu_policies.sh "X=0 --" "CWC_NO_COOP_MUL=1 --" "CWC_COOP_FILL=32 CWC_COOP_SLACK=4000000000 --" "CWC_COOP_FILL=16 CWC_COOP_SLACK=2 --" \
