@@ -670,6 +670,24 @@ def test_wide_register_scan_algorithms_on_plain_integers():
         assert serial_lex(kg, kl, xf, yf, starts, b0) == par_lex(kg, kl, xf, yf, starts, b0), (n, trial)
 
 
+def test_native_generators_write_the_python_generators_bytes(pkg):
+    """gwb_graphgen_bigint_class / gwb_graphgen_rsa_long_div_class (csrc/graphgen.cc: what the bench uses for BASELINE config 5's two
+    ten-million-node graphs) emit the same nodes in the same order through the same layout rules as the Python generator library,
+    their specification: the `.bin` bytes are equal over register widths, register counts, chain lengths, with and without range
+    checks; the histogram of a loaded handle equals the Python builder's statistics."""
+    for n, k, muls, rc in [(121, 17, 2, True), (64, 4, 18, True), (55, 5, 3, False), (12, 3, 2, True), (11, 2, 2, True), (126, 1, 2, True)]:
+        assert C.build_rsa_long_div_class(n=n, k=k, muls=muls, range_checks=rc).to_bin() == pkg.graphgen_native("rsa", n=n, k=k, muls=muls, range_checks=rc), (n, k, muls, rc)
+    for k, nb, rounds in [(8, 64, 4), (32, 64, 2), (3, 100, 2), (1, 16, 2)]:
+        assert C.build_bigint_class(k=k, n_bits=nb, rounds=rounds).to_bin() == pkg.graphgen_native("bigint", k=k, n_bits=nb, rounds=rounds), (k, nb, rounds)
+    b = C.build_rsa_long_div_class(n=64, k=4, muls=2)
+    nodes, wit, _ = b.finalize()
+    st = pkg.graphgen.builder.graph_stats(nodes, wit)
+    g = pkg.Graph(pkg.graphgen_native("rsa", n=64, k=4, muls=2))
+    assert g.op_histogram() == st["hist"] and g.n_nodes == st["N"] and g.depth == st["depth"]
+    with pytest.raises(pkg.WitnessCalcError):
+        pkg.graphgen_native("rsa", n=200, k=4, muls=1)
+
+
 def test_rsa_long_div_class_generator_against_plain_integers(pkg):
     """graphgen.circuits.build_rsa_long_div_class restates circom-bigint's witness hints (schoolbook product with carries, long_div
     by a k-register divisor: short_div estimate, long_scalar_mult, long_gt, long_sub) node by node.  Outside anchor: for every
