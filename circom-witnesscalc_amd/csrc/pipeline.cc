@@ -55,6 +55,7 @@ std::string upload_program(DeviceProgram& dp) {
     // their parallel form, 128-bit canonical products) live in interpreter instances of their own (MODE 3): a program with a borrow /
     // comparison bundle, or a carry-chain bundle of another width than 64 bits, runs there; every other limb program in the MODE 2
     // instances, whose code these kinds would only push apart (kernels.hip).
+    if (dp.dev.has_fused == 2u && getenv("CWC_FORCE_MODE3")) dp.dev.has_fused = 3u;  // (layout experiments: any limb program in the MODE 3 instances)
     if (dp.dev.has_fused == 2u)
         for (uint32_t h : p.hdr)
             if ((h & HDR_CLASS_MASK) == C_SCAN && !(h & HDR_SCAN_CONV) &&
