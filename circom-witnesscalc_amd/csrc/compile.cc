@@ -514,11 +514,24 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 users[o].push_back((uint32_t)i);
             }
         }
+        // (a selection step's ACC value depends on the operands of its OUT node -- the condition, the comparison's operands -- though it does not
+        // name them: the OUT node is as urgent as the ACC node, or whatever computes the condition would be scheduled as if nothing waited for it)
+        const bool any_sel = !scan_partner.empty();
         for (size_t i = N; i-- > 0;) {
             if (g.nodes[i].kind == N_CONST) continue;
             uint64_t h = 0;
             for (uint32_t u : users[i]) h = std::max(h, height[u]);
+            const bool sel = any_sel && g.nodes[i].kind == N_SCAN && scan_is_sel(g.nodes[i].op);
+            if (sel && !(g.nodes[i].op & SCAN_OP_ACC)) h = std::max(h, height[i]);  // (OUT in front of its ACC node: pre-set below)
             height[i] = h + node_cost(class_cost, g.nodes[i]);
+            if (sel && (g.nodes[i].op & SCAN_OP_ACC)) {
+                const uint32_t o = scan_partner[i];
+                if (o > i) {  // the OUT node was visited already (a plain selection's: behind the graph's last node); its operands come later
+                    height[o] = std::max(height[o], height[i]);
+                } else {
+                    height[o] = std::max(height[o], h);  // picked up when the loop reaches it
+                }
+            }
         }
         if (getenv("CWC_DEBUG_CRITICAL_PATH")) {  // diagnostic: class composition of the cost-weighted critical path
             uint32_t cur = 0xffffffffu;
@@ -971,10 +984,26 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                 prologue[i] = cp[i] <= theta;
                 // (a selection step's two nodes name different operands and sit in one bundle: the later one brings both to the longer chain --
                 // one of them in the prologue and the other in a stream of its own would tear the bundle apart)
-                if (n.kind == N_SCAN && scan_is_sel(n.op) && scan_partner[i] < i) {
+                if (n.kind == N_SCAN && scan_is_sel(n.op)) {
                     const uint32_t o = scan_partner[i];
-                    cp[i] = cp[o] = std::max(cp[i], cp[o]);
-                    prologue[i] = prologue[o] = cp[i] <= theta;
+                    if (n.op & SCAN_OP_ACC) {
+                        // the ACC node decides for both: ITS users come behind it in node order and take their chain from it, so it must know
+                        // the condition's chain now -- the OUT node's operands all precede this node (they were the selection's, or its
+                        // comparison's, operands), whether the OUT node itself sits in front of it or behind the graph's last node
+                        const Node& on = g.nodes[o];
+                        const uint32_t oops[3] = {on.a, on.b, on.c};
+                        double mo = 0;
+                        for (int q = 0; q < arity_of(on); ++q) mo = std::max(mo, cp[oops[q]]);
+                        cp[i] = std::max(cp[i], mo + node_cycles(class_of(n)));
+                        prologue[i] = cp[i] <= theta;
+                        if (o < i) {
+                            cp[o] = cp[i];
+                            prologue[o] = prologue[i];
+                        }
+                    } else if (o < i) {  // (an OUT node behind its ACC node)
+                        cp[i] = cp[o];
+                        prologue[i] = prologue[o];
+                    }
                 }
             }
             for (size_t i = 0; i < N; ++i) {

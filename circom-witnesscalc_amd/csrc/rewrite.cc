@@ -715,6 +715,28 @@ void detect_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>& vfl
             }
         }
     }
+    // Carry-chain tails (round 5): the last step of a chain whose outgoing carry nothing reads has lost its Shr node to the load-time
+    // optimiser's sweep -- only limb = (x + carry) & (2^n - 1) is there (the top register of a long_scalar_mult whose carry is dropped).
+    // The sum, read by nothing else, becomes the step's ACC node (its value, the carry, is read by nothing): the step joins its chain's
+    // bundle instead of costing an Add bundle and a Band bundle on the chain's critical path.
+    if (!getenv("CWC_NO_SCAN_ENDS")) {
+        std::vector<uint32_t> acc_of_regular(N, NONE);
+        for (size_t k = 0; k < steps.size(); ++k)
+            if (!steps[k].div) acc_of_regular[steps[k].acc] = (uint32_t)k;
+        for (size_t t = 0; t < N; ++t) {
+            const uint32_t o = user_out[t];
+            if (o >= NONE - 1 || user_acc[t] != NONE || uses[t] != 1 || rep[t] != REP_C) continue;
+            const Node& T_ = g.nodes[t];
+            const Node& O = g.nodes[o];
+            if (O.op != OP_BAND || !canon(T_.a) || !canon(T_.b)) continue;
+            const int n = mask_of(O.b);
+            // (one operand must be the carry of a regular step of the same width: a lone masked sum is left alone)
+            const uint32_t la = acc_of_regular[T_.a], lb = acc_of_regular[T_.b];
+            const bool a_is = la != NONE && (int)steps[la].imm == n, b_is = lb != NONE && (int)steps[lb].imm == n;
+            if (n < 1 || (!a_is && !b_is)) continue;
+            steps.push_back(Step{NONE, o, (uint32_t)t, b_is ? T_.a : T_.b, b_is ? T_.b : T_.a, 0, (uint32_t)n, false});
+        }
+    }
     if (getenv("CWC_DEBUG_SCAN")) {
         size_t n_band = 0, n_shr = 0, pairs = 0, uses_ok = 0, rep_ok = 0, canon_ok = 0;
         for (size_t t = 0; t < N; ++t) {
@@ -1021,8 +1043,8 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
     // ---- selections (SCAN_OP_SEL), in programs that hold the kinds above anyway (they run in the MODE 3 interpreter instances): a
     // TernCond whose condition is an ordered comparison that nothing else reads goes through a pair of records with it -- the comparison's
     // operands in the OUT record, the arms in the ACC record, all four staged like any operand: one bundle instead of a comparison bundle
-    // and a selection bundle with its two dependent global loads for the third operand.  (CWC_SEL_NEZ=1: every other TernCond as well,
-    // its condition tested against zero.)
+    // and a selection bundle with its two dependent global loads for the third operand.  Every other TernCond as well, its condition tested
+    // against zero (CWC_NO_SEL_NEZ=1 leaves those to the TernCond class).
     // Exact: the same comparison (graph.rs:130-133, 723-769) and the same selection (:221-225) on the same values.
     struct Sel { uint32_t out, acc, a, b, p, q, imm; bool nez; };
     std::vector<Sel> sels;
@@ -1037,9 +1059,10 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
                 const uint32_t code = C.op == OP_LT ? SEL_LT : C.op == OP_GT ? SEL_GT : C.op == OP_LEQ ? SEL_LEQ : SEL_GEQ;
                 sels.push_back(Sel{n.a, (uint32_t)j, C.a, C.b, n.b, n.c, code, false});
                 taken[n.a] = taken[j] = 1;
-            } else if (getenv("CWC_SEL_NEZ")) {
-                // (opt-in: on the RSA-class graph the list scheduler then starts the next digits' low registers ahead in one-node bundles --
-                // 562 bundles per multiplication against 495 with the comparisons' selections alone, 513 with none; profiles/r05_rsa_steps.txt)
+            } else if (!getenv("CWC_NO_SEL_NEZ")) {
+                // (the scheduler's priorities must know that the step's ACC value waits for the OUT node's operands -- compile.cc, the heights
+                // of a selection pair -- or whatever computes the condition is scheduled as if nothing waited for it: 562 bundles per
+                // multiplication of the RSA-class graph instead of 495)
                 // any other condition: its value is tested against zero; the step's OUT node is a new node behind the graph's last one (operands still precede their users)
                 sels.push_back(Sel{NONE, (uint32_t)j, n.a, n.a, n.b, n.c, SEL_NEZ, true});
                 taken[j] = 1;

@@ -736,15 +736,20 @@ def test_bit_recurrence_scans_are_exact(pkg, monkeypatch):
         return (sum(1 for h in scan if h & pe.HDR_SCAN_BORROW), sum(1 for h in scan if h & pe.HDR_SCAN_LEX),
                 sum(1 for h in scan if not h & (pe.HDR_SCAN_BORROW | pe.HDR_SCAN_LEX | pe.HDR_SCAN_DIV | pe.HDR_SCAN_CONV)))
 
-    for n, k, muls in [(121, 17, 1), (64, 4, 2), (33, 6, 1)]:
+    for n, k, muls in [(121, 17, 1), (64, 4, 2), (33, 6, 1), (121, 3, 2), (100, 6, 2)]:
         b = C.build_rsa_long_div_class(n=n, k=k, muls=muls, range_checks=(k < 17))
         nodes, wit, _ = b.finalize()
         g = pkg.Graph(b.to_bin())
         rows = [[1] + [rnd.randrange(model.M) if s == 0 else rnd.choice([0, 1, (1 << n) - 1, rnd.randrange(1 << n)]) for _ in range(2 * k)] for s in range(2)]
-        for tw in (1, 2, 4):
-            blob = pe.Blob(g.export_blob(tw))
+        for tw in (1, 2, 4, 1 | STREAMS4, 2 | DIVIDER | STREAMS4):
+            try:
+                blob = pe.Blob(g.export_blob(tw))
+            except Exception as e:  # (the graph is one independent part: no stream program -- a plain selection whose ACC node sat in the prologue
+                if "one independent part" in str(e):  # while its condition did not once made a bogus partition of it, found by the soak)
+                    continue
+                raise
             nb, nl, nc = kinds(blob)
-            assert (nb > 0 and nl > 0 and nc > 0) == (tw <= 2), (tw, nb, nl, nc)
+            assert (nb > 0 and nl > 0 and nc > 0) == ((tw & 0xff) <= 2), (tw, nb, nl, nc)
             for row in rows:
                 got, st = pe.run(blob, row)
                 assert st == 0 and got == model.evaluate(nodes, row, wit)
