@@ -636,20 +636,17 @@ FRD Fr fr_inv(const Fr& a) {
 
 // logical right shift of a 256-bit value by n in [0, 255]
 FRD Fr u256_shr(const Fr& x, uint32_t n) {
+    // (word moves as selections, not branches: n differs between the lanes of a wave wherever a graph shifts by a value, and a
+    // divergent branch inside the interpreter's uniform class paths makes the structurizer rewrite those -- DESIGN 5)
     Fr a = x;
-    uint32_t w = n >> 5, s = n & 31;
-    if (w & 4) {
+    const uint32_t w = n >> 5, s = n & 31;
+    const bool w4 = (w & 4u) != 0u, w2 = (w & 2u) != 0u, w1 = (w & 1u) != 0u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a.v[i] = (i + 4 < 8) ? a.v[i + 4] : 0;
-    }
-    if (w & 2) {
+    for (int i = 0; i < 8; ++i) a.v[i] = w4 ? ((i + 4 < 8) ? a.v[i + 4 < 8 ? i + 4 : 0] : 0u) : a.v[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a.v[i] = (i + 2 < 8) ? a.v[i + 2] : 0;
-    }
-    if (w & 1) {
+    for (int i = 0; i < 8; ++i) a.v[i] = w2 ? ((i + 2 < 8) ? a.v[i + 2 < 8 ? i + 2 : 0] : 0u) : a.v[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a.v[i] = (i + 1 < 8) ? a.v[i + 1] : 0;
-    }
+    for (int i = 0; i < 8; ++i) a.v[i] = w1 ? ((i + 1 < 8) ? a.v[i + 1 < 8 ? i + 1 : 0] : 0u) : a.v[i];
     Fr r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -661,19 +658,14 @@ FRD Fr u256_shr(const Fr& x, uint32_t n) {
 // left shift by n in [0, 255], bits past 2^256 dropped (ark-ff BigInt::muln)
 FRD Fr u256_shl(const Fr& x, uint32_t n) {
     Fr a = x;
-    uint32_t w = n >> 5, s = n & 31;
-    if (w & 4) {
+    const uint32_t w = n >> 5, s = n & 31;
+    const bool w4 = (w & 4u) != 0u, w2 = (w & 2u) != 0u, w1 = (w & 1u) != 0u;
 #pragma unroll
-        for (int i = 7; i >= 0; --i) a.v[i] = (i - 4 >= 0) ? a.v[i - 4] : 0;
-    }
-    if (w & 2) {
+    for (int i = 7; i >= 0; --i) a.v[i] = w4 ? ((i - 4 >= 0) ? a.v[i - 4 >= 0 ? i - 4 : 0] : 0u) : a.v[i];
 #pragma unroll
-        for (int i = 7; i >= 0; --i) a.v[i] = (i - 2 >= 0) ? a.v[i - 2] : 0;
-    }
-    if (w & 1) {
+    for (int i = 7; i >= 0; --i) a.v[i] = w2 ? ((i - 2 >= 0) ? a.v[i - 2 >= 0 ? i - 2 : 0] : 0u) : a.v[i];
 #pragma unroll
-        for (int i = 7; i >= 0; --i) a.v[i] = (i - 1 >= 0) ? a.v[i - 1] : 0;
-    }
+    for (int i = 7; i >= 0; --i) a.v[i] = w1 ? ((i - 1 >= 0) ? a.v[i - 1 >= 0 ? i - 1 : 0] : 0u) : a.v[i];
     Fr r;
 #pragma unroll
     for (int i = 7; i >= 0; --i) {
@@ -841,12 +833,12 @@ FRD void u256_divrem(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t top) {
 FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t digits, uint32_t bitlen_b = 0) {
     const uint32_t L = bitlen_b ? bitlen_b : u256_bitlen(b);   // 1..256 (callers pass b != 0)
     const uint32_t sh = 256u - L;        // divisor shifted left by sh has its top bit set
-    const Fr bn = sh ? u256_shl(b, sh) : b;
+    const Fr bn = u256_shl(b, sh);  // (a shift by 0 is the value: no branch around the shifts)
     // a << sh as 512 bits: hi:lo (sh = 0: hi = 0)
-    Fr lo = sh ? u256_shl(a, sh) : a;
+    Fr lo = u256_shl(a, sh);
     uint32_t R[9];
     {
-        const Fr hi = sh ? u256_shr(a, L) : fr_zero();  // < 2^(256-L) <= bn
+        const Fr hi = u256_select(sh != 0u, u256_shr(a, L & 255u), fr_zero());  // < 2^(256-L) <= bn
 #pragma unroll
         for (int i = 0; i < 8; ++i) R[i] = hi.v[i];
         R[8] = 0;
@@ -906,7 +898,7 @@ FRD void u256_divrem_digits(Fr& q, Fr& rem, const Fr& a, const Fr& b, uint32_t d
     Fr r8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r8.v[i] = R[i];
-    rem = sh ? u256_shr(r8, sh) : r8;
+    rem = u256_shr(r8, sh);
 }
 
 // Short division: a < 2^128 by b < 2^64 (b != 0) -- the operand sizes of limb-wise big-integer circuits (64-bit limbs:
@@ -987,7 +979,8 @@ FRD uint64_t mulhi64(uint64_t a, uint64_t b) {
 }
 FRD uint32_t clz64_nonzero(uint64_t x) {  // x != 0
     const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-    return hi ? (uint32_t)__builtin_clz(hi) : 32u + (uint32_t)__builtin_clz(lo | 1u);
+    const uint32_t c_hi = (uint32_t)__builtin_clz(hi | 1u), c_lo = 32u + (uint32_t)__builtin_clz(lo | 1u);  // (both computed: a selection, no branch)
+    return hi ? c_hi : c_lo;
 }
 FRD uint64_t recip64(uint64_t dn) {  // floor((2^128 - 1) / dn) - 2^64 for a normalised dn (top bit set); once per divisor
     // Moller & Granlund, "Improved division by invariant integers" (IEEE TC 2011), Algorithm 3: an 11-bit start value (their table

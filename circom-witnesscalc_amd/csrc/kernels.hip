@@ -29,6 +29,10 @@ __device__ __forceinline__ Fr fr_from_u4(const uint4& lo, const uint4& hi) {
 
 // wave-wide OR-reduction of a predicate ("does any lane need the slow path")
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+// a && b without the short circuit: no branch around b (a divergent branch inside a region of uniform branches makes the structurizer
+// rewrite the uniform ones into flag registers and chains of s_cbranch_vcc*: DESIGN 5, layout sensitivity)
+__device__ __forceinline__ bool both(bool a, bool b) { return ((uint32_t)a & (uint32_t)b) != 0u; }
+__device__ __forceinline__ bool either(bool a, bool b) { return ((uint32_t)a | (uint32_t)b) != 0u; }
 
 // PROF = true is a diagnostic build (gwb_profile_classes): one s_memtime per bundle, summed per bundle class by
 // lane 0 of every 64th tile (prof[class*4 + {0: cycles, 3: bundles}]), and for MUL and LIN bundles five sections of
@@ -624,7 +628,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     if (h & HDR_SCAN_CONV) {  // the columns of a k x k limb product (program_dev.h): out_c = sum_{i + j = c} x_i y_j; graph.rs:105, 110
                         const uint32_t k = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
                         const bool holds_y = active && lane < k * (uint32_t)T;  // (the columns k and above name a factor only to name one)
-                        if (!wave_any(active && (a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u)) {
+                        if (!wave_any(both(active, (a_op.v[2] | a_op.v[3] | a_op.v[4] | a_op.v[5] | a_op.v[6] | a_op.v[7] | b_op.v[2] | b_op.v[3] | b_op.v[4] | b_op.v[5] | b_op.v[6] | b_op.v[7]) != 0u))) {
                             uint32_t col[5];
                             conv_limb_columns<T>(k, lane, ((uint64_t)a_op.v[1] << 32) | a_op.v[0], holds_y ? (((uint64_t)b_op.v[1] << 32) | b_op.v[0]) : 0ull, col);
 #pragma unroll
@@ -662,7 +666,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                         // ---- one-bit recurrences (round 5), all steps of the bundle at once: c_out = gen | (prop & c_in), scan_bit_lookahead
                         const Fr y = fr_quad_perm<QP_ACC>(a_op);
                         const bool seg = start || !active;
-                        const uint32_t a0 = (start && active && !u256_is_zero(acc0)) ? 1u : 0u;  // the bit coming into a segment (a chain end without one reads 0; a comparison chain's may be a Montgomery-form boolean)
+                        const uint32_t a0 = both(both(start, active), !u256_is_zero(acc0)) ? 1u : 0u;  // the bit coming into a segment (a chain end without one reads 0; a comparison chain's may be a Montgomery-form boolean)
                         auto less = [](const Fr& a, const Fr& b) {  // a < b as the borrow of a - b, the difference kept alive (see C_CMPS below)
                             Fr t;
                             const uint32_t borrow = u256_sub(t, a, b);
@@ -670,13 +674,13 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             return borrow != 0;
                         };
                         auto signed_lt = [&](const Fr& a, const Fr& b) {  // graph.rs:723-755: negative = above (r - 1) / 2
-                            const bool an = less(fr_half(), a), bn = less(fr_half(), b);
-                            return an == bn ? less(a, b) : an;
+                            const bool an = less(fr_half(), a), bn = less(fr_half(), b), ab = less(a, b);  // (all three computed: no branch around the third)
+                            return an == bn ? ab : an;
                         };
                         // lt / gt of two canonical integers with the reference's signed comparison (graph.rs:723-755); registers below 2^128 everywhere
                         // in the wave are non-negative: one four-word subtraction decides
                         auto compare = [&](const Fr& a, const Fr& b, bool& lt, bool& gt) {
-                            if (!wave_any(active && (a.v[4] | a.v[5] | a.v[6] | a.v[7] | b.v[4] | b.v[5] | b.v[6] | b.v[7]) != 0u)) {
+                            if (!wave_any(both(active, (a.v[4] | a.v[5] | a.v[6] | a.v[7] | b.v[4] | b.v[5] | b.v[6] | b.v[7]) != 0u))) {
                                 uint32_t d[4], bw = 0;
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) d[k] = sbb32(a.v[k], b.v[k], bw);
@@ -700,36 +704,36 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                                 compare(x, acc0, lt, gt);
                                 cond = code == SEL_LT ? lt : code == SEL_GT ? gt : code == SEL_LEQ ? !gt : !lt;
                             }
-                            if (role_acc) r = u256_select(cond, y, q_arm);
-                            else r = u256_select(cond, (sh & SEL_OUT_MONT) ? fr_one() : Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, fr_zero());
+                            const Fr one_out = (sh & SEL_OUT_MONT) ? fr_one() : Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
+                            r = u256_select(cond, u256_select(role_acc, y, one_out), u256_select(role_acc, q_arm, fr_zero()));
                         } else if (h & HDR_SCAN_LEX) {
                             // acc' = x > y ? KG : x < y ? KL : acc (graph.rs:130-131, 221-225): generate = the registers differ and the winner's
                             // constant is 1, propagate = they are equal
                             const uint32_t kg = (h & HDR_SCAN_KG) ? 1u : 0u, kl = (h & HDR_SCAN_KL) ? 1u : 0u;
                             bool lt, gt;
                             compare(x, y, lt, gt);
-                            lt = lt && active;
-                            gt = gt && active;
-                            const bool gen = (gt && kg) || (lt && kl), prop = active && !gt && !lt;
-                            const uint32_t cin = scan_bit_lookahead<T>(seg, gen || (seg && prop && a0), prop, lane);
+                            lt = both(lt, active);
+                            gt = both(gt, active);
+                            const bool gen = either(both(gt, kg != 0u), both(lt, kl != 0u)), prop = both(active, !either(gt, lt));
+                            const uint32_t cin = scan_bit_lookahead<T>(seg, either(gen, both(both(seg, prop), a0 != 0u)), prop, lane);
                             const uint32_t bin = seg ? a0 : cin;
-                            const bool res = role_acc ? (gen || (prop && bin)) : bin != 0u;  // (the OUT value is read by nothing)
+                            const bool res = role_acc ? either(gen, both(prop, bin != 0u)) : bin != 0u;  // (the OUT value is read by nothing)
                             r = u256_select(res, sh ? fr_one() : Fr{{1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, fr_zero());  // (shift field 1: Montgomery-form booleans)
                         } else {
                             // borrow chain: s = y + bin; c = x >= s; out = c ? x - y - bin : x - y - bin + 2^n; acc' = c ? 0 : 1 (graph.rs:110-111, 133, 221-225)
                             const uint32_t m[4] = {mask_word(sh, 0), mask_word(sh, 1), mask_word(sh, 2), mask_word(sh, 3)};
                             const uint32_t above = (x.v[0] & ~m[0]) | (x.v[1] & ~m[1]) | (x.v[2] & ~m[2]) | (x.v[3] & ~m[3]) | x.v[4] | x.v[5] | x.v[6] | x.v[7] |
                                                    (y.v[0] & ~m[0]) | (y.v[1] & ~m[1]) | (y.v[2] & ~m[2]) | (y.v[3] & ~m[3]) | y.v[4] | y.v[5] | y.v[6] | y.v[7];
-                            if (sh <= 126u && !wave_any(active && above != 0u)) {
+                            if (sh <= 126u && !wave_any(both(active, above != 0u))) {
                                 // registers below 2^n everywhere in the wave: everything is a small non-negative integer, the comparison unsigned;
                                 // generate = x < y, propagate = x == y
                                 uint32_t d[4], bw = 0;
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) d[k] = sbb32(x.v[k], y.v[k], bw);
-                                const bool gen = active && bw != 0u, prop = active && (d[0] | d[1] | d[2] | d[3]) == 0u;
-                                const uint32_t cin = scan_bit_lookahead<T>(seg, gen || (seg && prop && a0), prop, lane);
+                                const bool gen = both(active, bw != 0u), prop = both(active, (d[0] | d[1] | d[2] | d[3]) == 0u);
+                                const uint32_t cin = scan_bit_lookahead<T>(seg, either(gen, both(both(seg, prop), a0 != 0u)), prop, lane);
                                 const uint32_t bin = seg ? a0 : cin;
-                                const bool bout = gen || (prop && bin);
+                                const bool bout = either(gen, both(prop, bin != 0u));
                                 // x - y - bin, + 2^n when a borrow leaves (mod 2^128: the result is in [0, 2^n))
                                 uint32_t e[4], b2 = 0;
                                 e[0] = sbb32(d[0], bin, b2);
@@ -760,11 +764,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                                     diff = u256_select(c, d0, fr_add_wave(d0, pw, pv));
                                     bo = c ? 0u : 1u;
                                 }
-                                r = diff;
-                                if (role_acc) {
-                                    r = fr_zero();
-                                    r.v[0] = bo;
-                                }
+                                r = u256_select(role_acc, Fr{{bo, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, diff);
                             }
                         }
                     } else if (!(h & HDR_SCAN_DIV)) {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             // one divisor per segment, every incoming remainder below it: all segments at once (scan_div_parallel)
                             const bool seg = start || !active;
                             const uint64_t d_prev = ((uint64_t)wave_shr_lanes<D>((uint32_t)(dv >> 32)) << 32) | wave_shr_lanes<D>((uint32_t)dv);
-                            if (sh == 64u && iters > 2u && !wave_any(active && (dz || (start ? a0 >= dv : dv != d_prev)))) {
+                            if (sh == 64u && iters > 2u && !wave_any(both(active, either(dz, start ? a0 >= dv : dv != d_prev)))) {
                                 scan_div_parallel<T>(seg, lane, iters, active ? dv : 1ull, active ? xl : 0ull, active ? a0 : 0ull, ql, r64);
                             } else if (sh == 64u) {
                                 // t = rem : x -- the low word is the lane's own x for all rounds: its normalised parts are made once

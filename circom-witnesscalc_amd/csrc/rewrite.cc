@@ -1048,7 +1048,8 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
     // Exact: the same comparison (graph.rs:130-133, 723-769) and the same selection (:221-225) on the same values.
     struct Sel { uint32_t out, acc, a, b, p, q, imm; bool nez; };
     std::vector<Sel> sels;
-    if (!steps.empty() && !getenv("CWC_NO_SEL_SCANS")) {
+    static const bool sel_always = getenv("CWC_SEL_ALWAYS") && atoi(getenv("CWC_SEL_ALWAYS")) != 0;
+    if ((!steps.empty() || sel_always) && !getenv("CWC_NO_SEL_SCANS")) {
         for (size_t j = 0; j < N; ++j) {
             const Node& n = g.nodes[j];
             if (n.kind != N_TRES || taken[j]) continue;
@@ -1075,7 +1076,7 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
         fprintf(stderr, "selections with their comparison: %zu\n", sels.size());
         fprintf(stderr, "bit scans: %zu borrow candidates, %zu comparison candidates; steps: %zu borrow, %zu comparison\n", cand_borrow, cand_lex, nb, steps.size() - nb);
     }
-    if (steps.empty()) return;
+    if (steps.empty() && sels.empty()) return;
     for (const Step& st : steps) {
         g.nodes[st.out] = Node{N_SCAN, st.op, st.x, st.acc_in, st.y};
         g.nodes[st.acc] = Node{N_SCAN, (uint8_t)(st.op | SCAN_OP_ACC), st.x, st.acc_in, st.y};
