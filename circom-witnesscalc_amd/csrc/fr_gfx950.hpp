@@ -41,6 +41,12 @@ FRD Fr fr_r2() { return Fr{{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 
 FRD Fr fr_half() { return Fr{{0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u}}; }
 FRD Fr fr_zero() { return Fr{{0, 0, 0, 0, 0, 0, 0, 0}}; }
 
+// a && b / a || b without the short circuit: no branch around b.  (On the GPU a divergent branch inside a region of uniform branches makes
+// StructurizeCFG rewrite the uniform ones into flag registers and chains of s_cbranch_vcc*, and the interpreter's class paths lose their
+// own back edges: DESIGN 5, layout sensitivity.  Inside the interpreter loop and everything it calls, per-lane conditions are selections.)
+FRD bool both(bool a, bool b) { return ((uint32_t)a & (uint32_t)b) != 0u; }
+FRD bool either(bool a, bool b) { return ((uint32_t)a | (uint32_t)b) != 0u; }
+
 FRD bool u256_is_zero(const Fr& a) {
     uint32_t o = 0;
 #pragma unroll
@@ -1042,20 +1048,15 @@ FRD void u128_divrem_64_recip(uint64_t th, uint64_t tl, uint64_t d, uint32_t s, 
 FRD uint64_t recip64_3by2(uint64_t d1, uint64_t d0) {  // d1 normalised (top bit set)
     uint64_t v = recip64(d1);
     uint64_t p = d1 * v + d0;
-    if (p < d0) {
-        --v;
-        if (p >= d1) {
-            --v;
-            p -= d1;
-        }
-        p -= d1;
-    }
+    // (the algorithm's conditional corrections as selections: no per-lane branch)
+    const bool c1 = p < d0, c2 = both(c1, p >= d1);
+    v -= (c1 ? 1ull : 0ull) + (c2 ? 1ull : 0ull);
+    p -= (c2 ? d1 : 0ull);
+    p -= (c1 ? d1 : 0ull);
     const uint64_t t1 = mulhi64(v, d0), t0 = v * d0;
     p += t1;
-    if (p < t1) {
-        --v;
-        if (p > d1 || (p == d1 && t0 >= d0)) --v;
-    }
+    const bool c3 = p < t1, c4 = both(c3, either(p > d1, both(p == d1, t0 >= d0)));
+    v -= (c3 ? 1ull : 0ull) + (c4 ? 1ull : 0ull);
     return v;
 }
 FRD void div3by2(uint64_t u2, uint64_t u1, uint64_t u0, uint64_t d1, uint64_t d0, uint64_t v, uint64_t& q, uint64_t& r1, uint64_t& r0) {
@@ -1071,17 +1072,19 @@ FRD void div3by2(uint64_t u2, uint64_t u1, uint64_t u0, uint64_t d1, uint64_t d0
     a1 -= d1 + (a0 < d0 ? 1ull : 0ull);
     a0 = b0;
     ++q1;
-    if (a1 >= q0) {
-        --q1;
-        const uint64_t c0 = a0 + d0;
-        a1 += d1 + (c0 < a0 ? 1ull : 0ull);
-        a0 = c0;
+    {
+        const bool f = a1 >= q0;
+        q1 -= f ? 1ull : 0ull;
+        const uint64_t c0 = a0 + d0, c1 = a1 + d1 + (c0 < a0 ? 1ull : 0ull);
+        a1 = f ? c1 : a1;
+        a0 = f ? c0 : a0;
     }
-    if (a1 > d1 || (a1 == d1 && a0 >= d0)) {
-        ++q1;
-        const uint64_t c0 = a0 - d0;
-        a1 -= d1 + (a0 < d0 ? 1ull : 0ull);
-        a0 = c0;
+    {
+        const bool f = either(a1 > d1, both(a1 == d1, a0 >= d0));
+        q1 += f ? 1ull : 0ull;
+        const uint64_t c0 = a0 - d0, c1 = a1 - (d1 + (a0 < d0 ? 1ull : 0ull));
+        a1 = f ? c1 : a1;
+        a0 = f ? c0 : a0;
     }
     q = q1;
     r1 = a1;

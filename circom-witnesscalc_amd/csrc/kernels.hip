@@ -29,10 +29,6 @@ __device__ __forceinline__ Fr fr_from_u4(const uint4& lo, const uint4& hi) {
 
 // wave-wide OR-reduction of a predicate ("does any lane need the slow path")
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-// a && b without the short circuit: no branch around b (a divergent branch inside a region of uniform branches makes the structurizer
-// rewrite the uniform ones into flag registers and chains of s_cbranch_vcc*: DESIGN 5, layout sensitivity)
-__device__ __forceinline__ bool both(bool a, bool b) { return ((uint32_t)a & (uint32_t)b) != 0u; }
-__device__ __forceinline__ bool either(bool a, bool b) { return ((uint32_t)a | (uint32_t)b) != 0u; }
 
 // PROF = true is a diagnostic build (gwb_profile_classes): one s_memtime per bundle, summed per bundle class by
 // lane 0 of every 64th tile (prof[class*4 + {0: cycles, 3: bundles}]), and for MUL and LIN bundles five sections of
@@ -594,7 +590,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                             const Fr z = limb_product(ma, mb);
                             Fr nz;
                             (void)u256_sub(nz, fr_p(), z);
-                            r = u256_select((a_neg != b_neg) && !u256_is_zero(z), nz, z);
+                            r = u256_select(both(a_neg != b_neg, !u256_is_zero(z)), nz, z);
                         } else {  // any operands: a into Montgomery form, then Montgomery x canonical = the canonical product
                             r = fr_mul_wave(fr_mul_wave(a_op, fr_r2(), pv), b_op, pv);
                         }
@@ -971,7 +967,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             }
             case C_CMPZ: {  // graph.rs:122-129 Eq/Neq, :134-135 Land/Lor
                 const bool az = u256_is_zero(a_op), cz = u256_is_zero(b_op), eq = u256_eq(a_op, b_op);
-                const bool v = sub == SUB_EQ ? eq : sub == SUB_NEQ ? !eq : sub == SUB_LAND ? (!az && !cz) : (!az || !cz);
+                const bool v = either(either(both(sub == SUB_EQ, eq), both(sub == SUB_NEQ, !eq)), either(both(sub == SUB_LAND, !either(az, cz)), both(both(sub != SUB_EQ, both(sub != SUB_NEQ, sub != SUB_LAND)), !both(az, cz))));
                 r = u256_select(v, one_out(), fr_zero());
                 break;
             }
@@ -988,10 +984,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     return borrow != 0;
                 };
                 const bool xn = less(fr_half(), x), yn = less(fr_half(), y);
-                const bool same = xn == yn;
-                const bool lt = same ? less(x, y) : xn;
-                const bool gt = same ? less(y, x) : yn;
-                const bool v = sub == SUB_LT ? lt : sub == SUB_GT ? gt : sub == SUB_LEQ ? !gt : !lt;
+                const bool same = xn == yn, xy = less(x, y), yx = less(y, x);  // (both computed: selections, no branch around either -- a divergent branch in a class body makes the structurizer rewrite its uniform ones)
+                const bool lt = same ? xy : xn;
+                const bool gt = same ? yx : yn;
+                const bool v = either(either(both(sub == SUB_LT, lt), both(sub == SUB_GT, gt)), either(both(sub == SUB_LEQ, !gt), both(both(sub != SUB_LT, both(sub != SUB_GT, sub != SUB_LEQ)), !lt)));
                 r = u256_select(v, one_out(), fr_zero());
                 break;
             }
@@ -1010,7 +1006,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 // the canonical result d in the form the users read: canonical, or Montgomery (booleans without a product)
                 auto bit_result = [&](const Fr& d) -> Fr {
                     if (h & HDR_OUT_CANON) return d;
-                    const bool small = (d.v[0] < 2u) && ((d.v[1] | d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) == 0u);
+                    const bool small = both(d.v[0] < 2u, (d.v[1] | d.v[2] | d.v[3] | d.v[4] | d.v[5] | d.v[6] | d.v[7]) == 0u);
                     if (wave_any(!small)) return fr_mul_wave(d, fr_r2(), pv);
                     return u256_select(d.v[0] != 0u, fr_one(), fr_zero());
                 };
@@ -1021,7 +1017,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
 #pragma unroll
                     for (int i = 0; i < 8; ++i) d.v[i] = x.v[i] & y.v[i];
                     if (h & HDR_BIT_ALL_SHR) {  // (some or all of them shift)
-                        const bool big = (y.v[1] | y.v[2] | y.v[3] | y.v[4] | y.v[5] | y.v[6] | y.v[7]) != 0u || y.v[0] >= 254u;
+                        const bool big = either((y.v[1] | y.v[2] | y.v[3] | y.v[4] | y.v[5] | y.v[6] | y.v[7]) != 0u, y.v[0] >= 254u);
                         const Fr sh = u256_select(big, fr_zero(), u256_shr(x, big ? 0u : y.v[0]));
                         d = u256_select(sub == SUB_SHR, sh, d);
                     }
@@ -1031,32 +1027,35 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 uint32_t hi_or = 0;
 #pragma unroll
                 for (int i = 1; i < 8; ++i) hi_or |= y.v[i];
-                const bool big = hi_or != 0 || y.v[0] >= 254u;  // b >= MODULUS_BIT_SIZE -> 0
+                const bool big = either(hi_or != 0u, y.v[0] >= 254u);  // b >= MODULUS_BIT_SIZE -> 0
                 const uint32_t n = is_x ? kx : big ? 0u : y.v[0];
-                Fr d;
-                if (sub == SUB_SHL || sub == SUB_SHR || is_x) {
-                    d = u256_shr(x, n);
-                    if (wave_any(sub == SUB_SHL)) d = u256_select(sub == SUB_SHL, u256_shl(x, n), d);  // (left shifts are rare)
-                    d = u256_select(big && !is_x, fr_zero(), d);
-                    if (is_x) {
-                        d.v[0] &= 1u;
+                // (mixed bundles: every lane computes the shift and the bitwise forms and selects -- no per-lane branch: DESIGN 5, layout sensitivity)
+                const bool shifts = either(either(sub == SUB_SHL, sub == SUB_SHR), is_x);
+                Fr d = u256_shr(x, n);
+                if (wave_any(sub == SUB_SHL)) d = u256_select(sub == SUB_SHL, u256_shl(x, n), d);  // (left shifts are rare)
+                d = u256_select(both(big, !is_x), fr_zero(), d);
+                d.v[0] &= is_x ? 1u : 0xffffffffu;
 #pragma unroll
-                        for (int i = 1; i < 8; ++i) d.v[i] = 0;
-                    }
-                    if (sub == SUB_SHL && !u256_lt(d, fr_p())) {  // graph.rs:634 unwrap on None
-                        if (active) err_bits |= ST_SHL_OVERFLOW;
-                        d = fr_zero();
-                    }
-                } else {
+                for (int i = 1; i < 8; ++i) d.v[i] = is_x ? 0u : d.v[i];
+                {
+                    const bool over = both(sub == SUB_SHL, !u256_lt(d, fr_p()));  // graph.rs:634 unwrap on None
+                    err_bits |= both(over, active) ? ST_SHL_OVERFLOW : 0u;
+                    d = u256_select(over, fr_zero(), d);
+                }
+                {
+                    // and / or / xor = (x | y) & ~(x & y) through masks of the lane's operation
+                    const uint32_t m_and = sub == SUB_BAND ? 0xffffffffu : 0u, m_or = sub == SUB_BAND ? 0u : 0xffffffffu, m_xor = (sub == SUB_BAND || sub == SUB_BOR) ? 0u : 0xffffffffu;
+                    Fr e;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        d.v[i] = sub == SUB_BAND ? (x.v[i] & y.v[i]) : sub == SUB_BOR ? (x.v[i] | y.v[i]) : (x.v[i] ^ y.v[i]);
-                    Fr dm;
-                    const uint32_t br = u256_sub(dm, d, fr_p());  // br == 1 iff d < r
-                    if (br == 0) {                                // d >= r: one subtraction (d < 2^254 < 2r)
-                        if (u256_is_zero(dm) && active) err_bits |= ST_BITOP_EQ_R;  // d == r: reference panics
-                        d = dm;
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t a = x.v[i] & y.v[i], o = x.v[i] | y.v[i];
+                        e.v[i] = (a & m_and) | ((o & m_or) & ~(a & m_xor));
                     }
+                    Fr em;
+                    const uint32_t br = u256_sub(em, e, fr_p());  // br == 1 iff e < r; e >= r: one subtraction (e < 2^254 < 2r)
+                    err_bits |= both(both(br == 0u, u256_is_zero(em)), both(active, !shifts)) ? ST_BITOP_EQ_R : 0u;  // e == r: reference panics
+                    e = u256_select(br == 0u, em, e);
+                    d = u256_select(shifts, d, e);
                 }
                 // boolean-valued results (Num2Bits-style Band(x,1)) skip the Montgomery multiplication
                 r = bit_result(d);
@@ -1072,11 +1071,11 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                 // estimate of a multi-register long division, a 2n-bit value by an n-bit register (zk-email: n = 121) -- three-by-two division
                 // with a reciprocal instead of 32-bit digits (6.3 k -> ~2 k cycles per bundle)
                 bool two_words = false;
-                if constexpr (WIDE) two_words = !wave_any(active && !yz && ((ys.v[2] | ys.v[3]) == 0u || (ys.v[4] | ys.v[5] | ys.v[6] | ys.v[7]) != 0u));
+                if constexpr (WIDE) two_words = !wave_any(both(both(active, !yz), either((ys.v[2] | ys.v[3]) == 0u, (ys.v[4] | ys.v[5] | ys.v[6] | ys.v[7]) != 0u)));
                 if (!wave_any((x.v[4] | x.v[5] | x.v[6] | x.v[7] | ys.v[2] | ys.v[3] | ys.v[4] | ys.v[5] | ys.v[6] | ys.v[7]) != 0u)) {
                     u128_divrem_64(q, rem, x, ys);  // limb-sized operands everywhere in the wave (x < 2^128, y < 2^64): short division
                 } else if (WIDE && two_words) {
-                    const bool sub = yz || !active;  // (a lane without a two-word divisor of its own divides by 2^64: its result is unused)
+                    const bool sub = either(yz, !active);  // (a lane without a two-word divisor of its own divides by 2^64: its result is unused)
                     Fr yy = ys;
                     yy.v[0] = sub ? 0u : ys.v[0];
                     yy.v[1] = sub ? 0u : ys.v[1];
