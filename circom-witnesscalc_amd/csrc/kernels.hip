@@ -383,10 +383,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             if (cls_q == C_MULF) {  // fused narrow bundle: (a * b) op2 x2 op3 x3 in the registers of the node's four lanes (program_dev.h)
                 // lane l holds record l / T: the group's main record (even positions) and extra record (odd positions) by DPP
                 constexpr int QP_MAIN = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x00 /* [0,0,0,0] */, QP_EXTRA = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xAA /* [2,2,2,2] */;
-                const uint32_t mx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.x, QP_MAIN, 0xf, 0xf, false);
-                const uint32_t my = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.y, QP_MAIN, 0xf, 0xf, false);
-                const uint32_t xx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.x, QP_EXTRA, 0xf, 0xf, false);
-                const uint32_t xy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rec_hi.y, QP_EXTRA, 0xf, 0xf, false);
+                const uint32_t mx = (uint32_t)__builtin_amdgcn_mov_dpp((int)rec_hi.x, QP_MAIN, 0xf, 0xf, false);
+                const uint32_t my = (uint32_t)__builtin_amdgcn_mov_dpp((int)rec_hi.y, QP_MAIN, 0xf, 0xf, false);
+                const uint32_t xx = (uint32_t)__builtin_amdgcn_mov_dpp((int)rec_hi.x, QP_EXTRA, 0xf, 0xf, false);
+                const uint32_t xy = (uint32_t)__builtin_amdgcn_mov_dpp((int)rec_hi.y, QP_EXTRA, 0xf, 0xf, false);
                 const uint32_t la = my + (t16c | (t16c << 16)), lx = xy + (t16c | (t16c << 16));
                 const Fr a_op = ld_lds(la & 0xffffu);
                 const uint2 bq = *reinterpret_cast<const uint2*>(ldsb + (la >> 16) + coop_chunk);

@@ -20,7 +20,7 @@ template <int QP>
 __device__ __forceinline__ Fr fr_quad_perm(const Fr& a) {
     Fr r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], QP, 0xf, 0xf, false);
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], QP, 0xf, 0xf, false);
     return r;
 }
 // word k of 2^n - 1 (wave-uniform n)
@@ -217,11 +217,11 @@ __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32
     constexpr int QP_OUT = T == 1 ? 0xA0 /* [0,0,2,2] */ : 0x44 /* [0,1,0,1] */, QP_ACC = T == 1 ? 0xF5 /* [1,1,3,3] */ : 0xEE /* [2,3,2,3] */;
     const bool acc_lane = ((lane / (uint32_t)T) & 1u) != 0;
     auto from_out = [&](uint64_t v) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, QP_OUT, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), QP_OUT, 0xf, 0xf, false);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, QP_OUT, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), QP_OUT, 0xf, 0xf, false);
         return ((uint64_t)hi << 32) | lo;
     };
     auto from_acc = [&](uint64_t v) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, QP_ACC, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), QP_ACC, 0xf, 0xf, false);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, QP_ACC, 0xf, 0xf, false), hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), QP_ACC, 0xf, 0xf, false);
         return ((uint64_t)hi << 32) | lo;
     };
     const uint32_t s = clz64_nonzero(dv);
