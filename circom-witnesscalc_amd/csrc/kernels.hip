@@ -333,8 +333,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             uint32_t cls_q = h & HDR_CLASS_MASK;
             asm volatile("" : "+s"(cls_q));
             static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_SCAN == 14 && C_COUNT == 15, "one compare (class >= C_MULQ) leads to the narrow classes");
-            if (cls_q >= C_MULQ) {
-            if (cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
+            // (limb and bit graphs hold few narrow bundles, if any: their instances keep the other classes on the fall-through path)
+            const bool narrow_cls = MODE == 1 ? cls_q >= C_MULQ : cls_q == C_MULQ;  // (one compare; C_MULF exists in the MODE 1 instances only)
+            if (M2 ? __builtin_expect(narrow_cls, 0) : narrow_cls) {
+            if (MODE != 1 || cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
                 // (laid out behind the loop's main line: a taken branch costs a lone wave ~50 cycles, and two of three bundles are not narrow)
                 const uint32_t la = rec_hi.y + (t16c | (t16c << 16));
                 const Fr a_op = ld_lds(la & 0xffffu);
@@ -545,7 +547,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             continue;
         }
         wait_and_stage();
-        if (__builtin_expect(cls_hot == C_MUL, 1)) {  // graph.rs:105
+        if (__builtin_expect(cls_hot == C_MUL, WIDE ? 0 : 1)) {  // graph.rs:105 (MODE 3: wide-register graphs are scan bundles first, the scan class keeps the fall-through path)
             if constexpr (M2) {
                 if (h & HDR_MUL_CC) {  // canonical x canonical -> canonical: limb-sized factors (below 2^64 everywhere in the wave) multiply as integers
                     auto limb_product = [&](const Fr& x, const Fr& y) -> Fr {  // x, y < 2^64
@@ -618,7 +620,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         if constexpr (M2 && (uint32_t)T <= SCAN_MAX_T) {
             uint32_t cls_scan = cls;
             asm volatile("" : "+s"(cls_scan));
-            if (cls_scan == C_SCAN) {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
+            if (WIDE ? __builtin_expect(cls_scan == C_SCAN, 1) : (cls_scan == C_SCAN)) {  // the steps of serial limb recurrences, pair after pair (program_dev.h); graph.rs:105, 110-121, 637-687
                 r = fr_zero();
                 if constexpr (M2 && (uint32_t)T <= SCAN_MAX_T) {
                     if (h & HDR_SCAN_CONV) {  // the columns of a k x k limb product (program_dev.h): out_c = sum_{i + j = c} x_i y_j; graph.rs:105, 110
