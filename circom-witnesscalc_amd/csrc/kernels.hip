@@ -335,7 +335,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
             static_assert(C_MULQ == 11 && C_SYNC == 12 && C_MULF == 13 && C_SCAN == 14 && C_COUNT == 15, "one compare (class >= C_MULQ) leads to the narrow classes");
             // (limb and bit graphs hold few narrow bundles, if any: their instances keep the other classes on the fall-through path)
             const bool narrow_cls = MODE == 1 ? cls_q >= C_MULQ : cls_q == C_MULQ;  // (one compare; C_MULF exists in the MODE 1 instances only)
-            if (M2 ? __builtin_expect(narrow_cls, 0) : narrow_cls) {
+            if (M2 ? __builtin_expect(narrow_cls, 0) : narrow_cls) {  // (plain instances: the narrow class stays the fall-through path -- out of line it cost the headline 1.3 %, same box)
             if (MODE != 1 || cls_q == C_MULQ) {  // graph.rs:105, four lanes per product: the iteration of the other classes with its own lane mapping
                 // (laid out behind the loop's main line: a taken branch costs a lone wave ~50 cycles, and two of three bundles are not narrow)
                 const uint32_t la = rec_hi.y + (t16c | (t16c << 16));
@@ -658,8 +658,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     const uint32_t sh = (h >> HDR_SCAN_SHIFT_SHIFT) & 0xffu, iters = (h >> HDR_SCAN_ITER_SHIFT) + 1u;
                     const bool start = (sub & SCAN_START) != 0, role_acc = (sub & SCAN_ROLE_ACC) != 0;
                     const Fr x = fr_quad_perm<QP_OUT>(a_op), acc0 = fr_quad_perm<QP_OUT>(b_op);
-                    // (MODE 3: compiled into the MODE 2 instances the round-5 kinds cost BASELINE config 5's first graph 10 % -- same box, same program,
-                    // same register count; laid out behind the older paths with `unlikely`, 13 %: a lone wave pays for the code it has to fetch)
+                    // (MODE 3.  Everything below is free of per-lane branches -- both() / either() for && / ||, both arms computed in front of a ?:,
+                    // role and kind selections as u256_select: this if / else-if chain is a region of uniform tests, and ONE divergent branch anywhere
+                    // below it makes StructurizeCFG rewrite all of them into flag registers and chains of s_cbranch_vcc* -- the 64-bit carry and division
+                    // paths included, which is what the round-5 kinds cost programs that never ran them: DESIGN 5, profiles/r05_structurizer_ab.txt.)
                     if (WIDE && (h & (HDR_SCAN_BORROW | HDR_SCAN_LEX))) {
                         // ---- one-bit recurrences (round 5), all steps of the bundle at once: c_out = gen | (prop & c_in), scan_bit_lookahead
                         const Fr y = fr_quad_perm<QP_ACC>(a_op);

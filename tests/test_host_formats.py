@@ -906,6 +906,31 @@ def test_kernel_isa_uses_the_hidden_header_register_only_as_written(pkg, tmp_pat
     assert n_move >= 100 and n_load >= n_move
 
 
+def test_kernel_isa_has_no_per_lane_branches_in_the_interpreter_loop(pkg, tmp_path):
+    """Inside the bundle loop every per-lane condition is a selection: one divergent branch in a class body makes StructurizeCFG rewrite
+    the uniform branches around it into flag registers (profiles/r05_structurizer_ab.txt: the same program 10-15 % slower for code it
+    never executed).  Checked on the kernels as built: an interpreter instance without divider waves holds a handful of
+    s_*_saveexec (the one-lane stores of the sync / error words), its bundle loop keeps a back edge per class path, and the limb
+    instances stay within reach of short branches."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_report
+    obj = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc", "build", "kernels.o")
+    if not (os.path.exists(os.path.join(isa_report.LLVM, "llvm-objdump")) and os.path.exists(obj)):
+        pytest.skip("no llvm-objdump / no kernels.o in the tree")
+    st = isa_report.instance_stats(isa_report.disassemble(obj, str(tmp_path)))
+    assert len(st) >= 40
+    for (T, prof, W, pack, mode), c in st.items():
+        if prof:
+            continue
+        name = "interp_kernel<%d,%d,%d,%d,%d>" % (T, prof, W, pack, mode)
+        if W == 0:
+            assert c["divergent_branches"] <= 8, name + ": %d divergent branches (a per-lane `if`, `a && b` or `c ? f() : y` in the bundle loop?)" % c["divergent_branches"]
+            assert c["flag_branches"] <= 12, name + ": %d flag branches (a structurized region in the bundle loop?)" % c["flag_branches"]
+        else:  # (+ the divider wave's request loop, which is per-lane by nature)
+            assert c["divergent_branches"] <= 60, name + ": %d divergent branches" % c["divergent_branches"]
+        assert c["bytes"] < (128 << 10), name + ": %d bytes of code, beyond the reach of s_branch" % c["bytes"]
+
+
 def test_slot_reuse_keeps_workspace_small(pkg):
     b = C.build_poseidon(2)
     g = pkg.Graph(b.to_bin())
