@@ -288,8 +288,11 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{r_prev.v[4], r_prev.v[5], r_prev.v[6], r_prev.v[7]}, rsrc, (int)doff_prev + (int)HI, 0, 0)
     // CWC_NEXT_HEADER: right behind the wait for the LDS reads -- the header of bundle b + 2 out of its landing register
     // (CWC_HDR_LANDING below), the fetch of bundle b + 3's in the same statement.
+// ("=&s": the move writes its destination BEFORE the load reads the header pointer and the offset -- without the early-clobber mark the register
+// allocator may give the destination one of their registers, and did in one stamped MODE 3 instance: the load then read from header word : pointer high
+// half, a memory fault found by the class profile of the RSA-class graph; tests/test_host_formats.py checks the built kernels for it)
 #define CWC_NEXT_HEADER(var)                                                                                                                 \
-    asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=s"(var) : "s"(hdr), "s"(hdr_off_n2) : "memory"); \
+    asm volatile("s_mov_b32 %0, xnack_mask_lo\n\ts_load_dword xnack_mask_lo, %1, %2" : "=&s"(var) : "s"(hdr), "s"(hdr_off_n2) : "memory"); \
     hdr_off_n2 += 4u
 
     // Software pipeline, everything through LDS.  While bundle b computes: its operands sit in STAGE[b mod 2] / the

@@ -868,15 +868,16 @@ def test_library_kernels_match_the_sources(pkg):
     assert pkg.kernel_source_hash() == now, "libcircom_witnesscalc_amd.so holds kernels of other sources: run make"
 
 
-def test_kernel_isa_uses_the_hidden_header_register_only_as_written(pkg, tmp_path):
+@pytest.mark.parametrize("objname", ["kernels.o", "kernels_diag.o"])
+def test_kernel_isa_uses_the_hidden_header_register_only_as_written(pkg, tmp_path, objname):
     """The interpreter's header fetch lands in XNACK_MASK_LO, a register the compiler does not know it is using
     (kernels.hip CWC_HDR_LANDING).  That is safe only while (1) nothing but the hand-written statements touches the register
     and (2) every move out of it sits right behind a full wait for scalar loads.  Checked on the ISA of the kernels as built:
     the gfx950 code object is taken out of build/kernels.o and disassembled -- a compiler bump that breaks either rule fails here."""
     llvm = "/opt/rocm/lib/llvm/bin"
-    obj = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc", "build", "kernels.o")
+    obj = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc", "build", objname)  # (the diagnostic object exists once `make diag` has run: its stamped instances are compiled from the same statements)
     if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(obj)):
-        pytest.skip("no llvm-objdump / no kernels.o in the tree")
+        pytest.skip("no llvm-objdump / no %s in the tree" % objname)
     fat, co = str(tmp_path / "fatbin.bin"), str(tmp_path / "kernels_gfx950.co")
     subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj])
     subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
@@ -885,15 +886,27 @@ def test_kernel_isa_uses_the_hidden_header_register_only_as_written(pkg, tmp_pat
     assert sum("interp_kernel" in ln and ln.rstrip().endswith(">:") for ln in asm) >= 40, "interpreter instances in the disassembly"
     load = re.compile(r"\bs_load_dword xnack_mask_lo, s\[\d+:\d+\], (s\d+|0x[0-9a-f]+|\d+)\s")
     move = re.compile(r"\bs_mov_b32 s\d+, xnack_mask_lo\s")
-    n_load = n_move = 0
+    n_load = n_move = n_pair = 0
     for i, ln in enumerate(asm):
         if "xnack_mask" not in ln:
             continue
-        if load.search(ln):
+        m_load = load.search(ln)
+        if m_load:
             n_load += 1
+            # the fetch of the next header follows the move of the landed one in the same statement: the move's destination must be none of
+            # the registers the load still reads (header pointer pair, offset) -- an asm output without the early-clobber mark may share them
+            prev = asm[i - 1]
+            mv = re.search(r"\bs_mov_b32 s(\d+), xnack_mask_lo\s", prev)
+            if mv:
+                base = re.search(r"xnack_mask_lo, s\[(\d+):(\d+)\], (s(\d+))?", ln)
+                used = {int(base.group(1)), int(base.group(2))} | ({int(base.group(4))} if base.group(4) else set())
+                assert int(mv.group(1)) not in used, "the landed header is moved into a register the next fetch reads: " + prev.strip() + " / " + ln.strip()
+                n_pair += 1
             continue
         assert move.search(ln), "the compiler (or a new statement) uses xnack_mask: " + ln.strip()
         n_move += 1
+        if objname != "kernels.o":  # (the stamped instances put their time stamps between the wait and the move: the product object carries rule 2)
+            continue
         # walking back from the move: the wait comes before any other use of the register and before any branch
         for back in range(1, 4):
             prev = asm[i - back]
@@ -903,7 +916,7 @@ def test_kernel_isa_uses_the_hidden_header_register_only_as_written(pkg, tmp_pat
                 "a move out of xnack_mask_lo without the wait in front of it: " + ln.strip()
         else:
             raise AssertionError("no s_waitcnt lgkmcnt(0) within three instructions in front of: " + ln.strip())
-    assert n_move >= 100 and n_load >= n_move
+    assert n_move >= 100 and n_load >= n_move and n_pair >= 100
 
 
 def test_kernel_isa_has_no_per_lane_branches_in_the_interpreter_loop(pkg, tmp_path):
