@@ -237,7 +237,9 @@ __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32
     const uint64_t t0v = from_out(t0), t0m = from_acc(t0);
     uint64_t v = t0v, m = st ? 0ull : t0m;
     bool f = st;
-    for (uint32_t dl = 1; dl < rounds_cover; dl <<= 1) {
+    // (rounds written out: the compiler does not unroll a loop of cross-lane operations by a run-time count, and a lone wave pays ~70 cycles
+    // for every taken branch, the loop's back edge included -- five rounds cover a bundle's 32 steps, more stay a loop)
+    auto round = [&](uint32_t dl) {
         const int src = (int)((lane - dl * (uint32_t)D) << 2);
         const uint64_t mine = acc_lane ? m : v;  // (the partner pair's lane of the same role holds the same v and m)
         const uint64_t theirs = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(mine >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)mine);
@@ -250,7 +252,13 @@ __device__ __forceinline__ void scan_div_parallel(bool st, uint32_t lane, uint32
         v = f ? v : nv;
         m = f ? m : nm;
         f = f || pf;
-    }
+    };
+    if (1u < rounds_cover) round(1u);
+    if (2u < rounds_cover) round(2u);
+    if (4u < rounds_cover) round(4u);
+    if (8u < rounds_cover) round(8u);
+    if (16u < rounds_cover) round(16u);
+    for (uint32_t dl = 32; dl < rounds_cover; dl <<= 1) round(dl);
     const uint32_t r0 = wave_shr_lanes<D>((uint32_t)v), r1 = wave_shr_lanes<D>((uint32_t)(v >> 32));
     const uint64_t rin = st ? a0 : (((uint64_t)r1 << 32) | r0);
     (void)divrem(rin, x, quo);
@@ -275,7 +283,7 @@ __device__ __forceinline__ void conv_limb_columns(uint32_t k, uint32_t lane, uin
         asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(sum), "=s"(cy) : "s"(xs), "v"(yv));
         asm volatile("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(overflows), "=s"(unused) : "s"(cy));
     };
-    for (uint32_t i = 0; i < k; ++i) {
+    auto round = [&](uint32_t i) {
         uint32_t b0, b1;
         if constexpr (T == 1) {
             b0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)i);
@@ -301,7 +309,26 @@ __device__ __forceinline__ void conv_limb_columns(uint32_t k, uint32_t lane, uin
         }
         y0 = wave_shr_lanes<T>(y0);
         y1 = wave_shr_lanes<T>(y1);
+    };
+    uint32_t i = 0;
+    for (; i + 8u <= k; i += 8u) {  // (eight rounds per back edge: written out, see scan_div_parallel)
+        round(i);
+        round(i + 1u);
+        round(i + 2u);
+        round(i + 3u);
+        round(i + 4u);
+        round(i + 5u);
+        round(i + 6u);
+        round(i + 7u);
     }
+    if (i + 4u <= k) {
+        round(i);
+        round(i + 1u);
+        round(i + 2u);
+        round(i + 3u);
+        i += 4u;
+    }
+    for (; i < k; ++i) round(i);
     // total = s_lo + c_lo 2^64 + s_mid 2^32 + c_mid 2^96 + s_hi 2^64 + c_hi 2^128  (< 2^134)
     out[0] = (uint32_t)s_lo;
     const uint64_t t1 = (s_lo >> 32) + (uint32_t)s_mid;
