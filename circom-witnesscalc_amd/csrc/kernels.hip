@@ -990,10 +990,24 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     if constexpr (M2) asm volatile("" ::"v"(t.v[7]));
                     return borrow != 0;
                 };
-                const bool xn = less(fr_half(), x), yn = less(fr_half(), y);
-                const bool same = xn == yn, xy = less(x, y), yx = less(y, x);  // (both computed: selections, no branch around either -- a divergent branch in a class body makes the structurizer rewrite its uniform ones)
-                const bool lt = same ? xy : xn;
-                const bool gt = same ? yx : yn;
+                bool lt, gt;
+                // limb graphs compare registers: below 2^128 everywhere in the wave nothing is negative (graph.rs:723-755: negative = above (r - 1) / 2)
+                // and one four-word subtraction decides -- the two comparisons with the constant (r - 1) / 2 are what the compiler lowers to
+                // compare / and / or chains through scalar registers, ~1 200 of the bundle's 2 200 cycles on a lone wave
+                bool limb_sized = false;
+                if constexpr (M2) limb_sized = !wave_any(both(active, (x.v[4] | x.v[5] | x.v[6] | x.v[7] | y.v[4] | y.v[5] | y.v[6] | y.v[7]) != 0u));
+                if (M2 && limb_sized) {
+                    uint32_t d[4], bw = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = sbb32(x.v[k], y.v[k], bw);
+                    lt = bw != 0u;
+                    gt = both(bw == 0u, (d[0] | d[1] | d[2] | d[3]) != 0u);
+                } else {
+                    const bool xn = less(fr_half(), x), yn = less(fr_half(), y);
+                    const bool same = xn == yn, xy = less(x, y), yx = less(y, x);  // (both computed: selections, no branch around either -- a divergent branch in a class body makes the structurizer rewrite its uniform ones)
+                    lt = same ? xy : xn;
+                    gt = same ? yx : yn;
+                }
                 const bool v = either(either(both(sub == SUB_LT, lt), both(sub == SUB_GT, gt)), either(both(sub == SUB_LEQ, !gt), both(both(sub != SUB_LT, both(sub != SUB_GT, sub != SUB_LEQ)), !lt)));
                 r = u256_select(v, one_out(), fr_zero());
                 break;
