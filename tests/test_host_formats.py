@@ -919,6 +919,38 @@ def test_kernel_isa_uses_the_hidden_header_register_only_as_written(pkg, tmp_pat
     assert n_move >= 100 and n_load >= n_move and n_pair >= 100
 
 
+def test_multi_instruction_asm_statements_mark_their_outputs_early_clobber():
+    """An asm statement of several instructions whose output is written before its last input is read needs the early-clobber mark ("=&s" /
+    "=&v"), or the register allocator may give the output an input's register -- what the header fetch's statement did in one stamped instance
+    (profiles/r05_header_fetch_fault.txt).  Source-level guard beside the ISA test: in the kernel sources every statement with more than one
+    instruction, outputs and inputs marks every write-only output; statements of one instruction are exempt (the hardware reads before it writes)."""
+    csrc = os.path.join(ROOT, "circom-witnesscalc_amd", "csrc")
+    names = [n for n in os.listdir(csrc) if n.endswith((".hip", ".hpp", ".inc"))]
+    checked = 0
+    for name in names:
+        src = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'asm\s+(?:volatile\s*)?\(', src):
+            # the statement's text up to its closing parenthesis at depth 0
+            i, depth = m.end(), 1
+            while depth and i < len(src):
+                depth += {"(": 1, ")": -1}.get(src[i], 0)
+                i += 1
+            stmt = src[m.end():i - 1]
+            parts = re.split(r'"\s*:\s*(?=[\[":]|$)', stmt, maxsplit=1)  # template | constraints
+            template = parts[0]
+            if template.count("\\n") == 0:
+                continue  # one instruction
+            sections = re.split(r'(?<!:):(?!:)', stmt[len(template):])
+            outputs = sections[1] if len(sections) > 1 else ""
+            inputs = sections[2] if len(sections) > 2 else ""
+            if not re.search(r'"[^"]*"\s*\(', inputs):
+                continue  # no inputs to collide with
+            for c in re.findall(r'"(=[^"]*)"\s*\(', outputs):
+                checked += 1
+                assert c.startswith("=&"), "%s: a multi-instruction asm statement with inputs has the output constraint \"%s\" without the early-clobber mark: %s" % (name, c, template[:80])
+    assert checked >= 50  # (the generated multiplier / adder blocks and the header fetch)
+
+
 def test_kernel_isa_has_no_per_lane_branches_in_the_interpreter_loop(pkg, tmp_path):
     """Inside the bundle loop every per-lane condition is a selection: one divergent branch in a class body makes StructurizeCFG rewrite
     the uniform branches around it into flag registers (profiles/r05_structurizer_ab.txt: the same program 10-15 % slower for code it
