@@ -482,12 +482,57 @@ def main():
         if rank == 0 and isinstance(out.get("config4"), dict) and "matches_single_gpu_digest" in out["config4"]:
             out["matches_single_gpu_digest"] = out["config4"]["matches_single_gpu_digest"]
     if rank == 0:
+        flatten_roofline(out)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+SCHEMA = 6  # (advisor, round 5) 5: roofline.bound / frac = the VALU-issue ceiling, `--config 5` = the RSA-class graph; 6: + the flat scalars below
+
+
+def flatten_roofline(out):
+    """The driver's record keeps only the SCALARS of `roofline`: SURVEY 8(d)'s own number (algorithmic bytes / interpreter time / 8 TB/s) and
+    the other figures a reader needs therefore also sit there as flat keys, next to the nested blocks they come from (tools/design_table.py
+    reads these keys)."""
+    rf = out.get("roofline")
+    if not isinstance(rf, dict):
+        return
+    out["schema"] = SCHEMA
+    hbm, chain, comp = rf.get("hbm", {}), rf.get("chain", {}), rf.get("compute", {})
+    rf["hbm_frac"] = hbm.get("frac")                      # SURVEY 8(d): algorithmic bytes per launch / the interpreter's launch time / 8 TB/s
+    rf["hbm_frac_step"] = hbm.get("frac_step")            # ... over the whole step (interpreter + pack)
+    rf["hbm_achieved_gbs"] = hbm.get("achieved")
+    rf["hbm_measured_frac"] = hbm.get("hbm_measured_frac")  # counter traffic / launch time / 8 TB/s
+    rf["traffic_over_algorithmic"] = (rf["traffic"] / hbm["algorithmic_bytes_per_launch"]) if rf.get("traffic") and hbm.get("algorithmic_bytes_per_launch") else None
+    rf["chain_achieved_over_floor"] = chain.get("achieved_over_floor")
+    rf["chain_floor_ms"] = chain.get("floor_ms")
+    pmc = PMC_CHECK.get("interp")
+    eq = comp.get("modmul_equivalents_per_set")
+    batch = out.get("config", {}).get("batch_per_gpu")
+    # of the vector instructions the counters saw per launch (divider waves included), the share the arithmetic alone needs: one 322-slot
+    # product per 64 lane-products
+    rf["valu_useful_issue_frac"] = (eq * batch / 64.0 * 322.0 / pmc["sq_insts_valu_per_launch"]) if pmc and eq and batch and pmc.get("sq_insts_valu_per_launch") else None
+    rf["sq_wait_any_frac"] = (pmc["sq_wait_any_per_launch"] / pmc["sq_wave_cycles_per_launch"]) if pmc and pmc.get("sq_wave_cycles_per_launch") else None
+    for name in ("config3", "config4_per_gpu", "config5", "config5_rsa"):
+        sub = out.get(name)
+        if not isinstance(sub, dict) or "value" not in sub:
+            continue
+        rf[name + "_value"] = sub["value"]
+        rf[name + "_ms_per_step"] = sub.get("ms_per_step")
+        c = sub.get("compute")
+        rf[name + "_compute_frac"] = c.get("frac") if isinstance(c, dict) else None
+        rf[name + "_hbm_frac"] = sub.get("roofline_frac")
+        if sub.get("traffic") is not None:
+            rf[name + "_traffic"] = sub["traffic"]
+            rf[name + "_traffic_over_algorithmic"] = sub.get("traffic_over_algorithmic")
+    ss = out.get("single_shot")
+    if isinstance(ss, dict):
+        rf["single_shot_warm_ms"] = ss.get("warm_call_ms_median_of_last_5")
+        rf["single_shot_first_call_ms"] = ss.get("first_call_ms")
 
 
 def extras(pkg, cdist, wl, g, cfg, rows, d_out, dev, rank, world, distributed, out):
@@ -711,6 +756,8 @@ def config3_point(pkg, dev, batch=4096, cpu_sample=256):
             "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms, "tile_width": tm["tile_width"],
             "n_op": g.n_op, "n_witness": g.n_witness, "bundles": tm["n_bundles"],
             "sets_with_error_status": int((d_st != 0).sum().item()),
+            "roofline_frac": g.algorithmic_bytes_per_set * batch / (interp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            **sub_traffic(pkg, "sha256", batch, tm["tile_width"], g.algorithmic_bytes_per_set * batch, interp_ms),
             "matches_hashlib": bool(ok == batch), "sets_checked_against_hashlib": batch,
             "matches_oracle": bool(np.array_equal(d_out[:8].cpu().numpy(), want) and not st.any()), "sets_checked_against_oracle": 8}
 
@@ -734,6 +781,7 @@ def config4_per_gpu_point(pkg, wl, dev, batch=8192):
             "unit": "witnesses/s", "ms_per_step": dt * 1e3, "interp_kernel_ms": interp_ms, "pack_kernel_ms": pack_ms,
             "tile_width": tm["tile_width"], "interpreter_waves_per_divider_wave": tm["divider"], "launches": tm["n_launches"],
             "roofline_frac": achieved / HBM_PEAK_GBS, "compute": compute_block(wl.stats_from(g)["hist"], g.n_witness, batch, interp_ms),
+            **sub_traffic(pkg, wl.kind, batch, tm["tile_width"], g.algorithmic_bytes_per_set * batch, interp_ms),
             "sets_with_error_status": int((d_st != 0).sum().item()),
             "matches_oracle": bool(np.array_equal(got, want) and not st.any()), "sets_checked_against_oracle": len(sample)}
 
@@ -780,6 +828,13 @@ def config5_point(pkg, dev, kind="bigint", batch=32, steps=3, cpu_sample=4, batc
                        "tile_width": tm2["tile_width"], "bundles": tm2["n_bundles"], "sets_with_error_status": int((d_st != 0).sum().item()),
                        "step_time_over_32_set_step": dt2 / dt, "compute": compute_block(wl.stats["hist"], g.n_witness, batch_one_gpu, interp2),
                        "note": "all 256 sets of BASELINE config 5 on one GPU: %.2f x the 32-set step's time for 8 x the sets" % (dt2 / dt)}
+            if CPU_SAMPLE > 0:  # (advisor, round 5) sets beyond the first 32 -- which only this run evaluates -- against the oracle as whole witnesses
+                from oracle import cbind
+                sample = [batch + 8, batch_one_gpu - 1]
+                want, wst = cbind.Graph(wl.data).evaluate_batch(rows[sample])
+                got = d_out[torch.tensor(sample, device=dev)].cpu().numpy()
+                one_gpu["matches_oracle"] = bool(np.array_equal(got, want) and not wst.any())
+                one_gpu["sets_checked_against_oracle"] = sample
         except Exception as e:  # (a sub-record: its failure is reported, not fatal)
             one_gpu = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"workload": "%s, %d nodes, %d input sets on one GPU (BASELINE config 5: 256 sets over 8 GPUs)" % (wl.name, g.n_nodes, batch),
@@ -790,6 +845,8 @@ def config5_point(pkg, dev, kind="bigint", batch=32, steps=3, cpu_sample=4, batc
             "field_ops_per_sec": batch / dt * g.n_op, "nodes_per_sec": batch / dt * g.n_nodes, "sets_with_error_status": bad,
             "compute": compute_block(wl.stats["hist"], g.n_witness, batch, interp_ms),
             "hbm_model_frac": g.algorithmic_bytes_per_set * batch / (interp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_frac": g.algorithmic_bytes_per_set * batch / (interp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            **sub_traffic(pkg, kind, batch, tm["tile_width"], g.algorithmic_bytes_per_set * batch, interp_ms),
             "all_256_sets_on_one_gpu": one_gpu,
             "cpu_baseline": cpu, "matches_oracle": (cpu or {}).get("matches_gpu"), "sets_checked_against_oracle": min(cpu_sample, batch) if cpu else 0}
 
@@ -857,30 +914,57 @@ def config4_job(pkg, cdist, wl, dev, rank, world, distributed, per_gpu=8192):
     return rec
 
 
-def committed_traffic(graph_kind, batch, tile_width, kernel_hash=None):
-    """HBM bytes per interpreter launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json, collected
-    on this same command line by tools/collect_evidence.sh) -- a cross-reference, not measured in this run -- or None when
-    no committed profile matches this configuration."""
+def find_pmc_summary(graph_kind, batch, tile_width):
+    """(summary, path) of the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary*.json, tools/profile_summary.py) whose
+    configuration is this graph / batch / tile width, or (None, None)"""
     import glob
-    best, src = None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json"))):
         try:
             j = json.load(open(f))
         except (OSError, ValueError):
             continue
         c = j.get("config", {})
         if c.get("graph") == graph_kind and c.get("batch_per_gpu") == batch and c.get("tile_width") == tile_width:
-            best = j["kernels"]["interp"]["hbm_bytes_per_launch_corrected"]
-            src = "committed rocprofv3 --pmc passes of this command line (%s), FETCH_SIZE x2 gfx950 correction; not re-measured in this run" % os.path.relpath(f, ROOT)
-            profiled = j.get("kernel_source_hash")
-            same = None if not profiled or not kernel_hash else profiled == kernel_hash
-            src += "; profiled kernels = this library's" if same else "; the profile is of OTHER kernel sources than this library's" if same is False else "; kernel sources of the profile not recorded"
-            PMC_CHECK["same_kernels"] = same
-    return best, src or "none: no committed PMC profile matches this graph / batch / tile width"
+            best = (j, f)
+    return best
+
+
+def committed_traffic(graph_kind, batch, tile_width, kernel_hash=None):
+    """HBM bytes per interpreter launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json, collected
+    on this same command line by tools/collect_evidence.sh) -- a cross-reference, not measured in this run -- or None when
+    no committed profile matches this configuration."""
+    j, f = find_pmc_summary(graph_kind, batch, tile_width)
+    if j is None:
+        return None, "none: no committed PMC profile matches this graph / batch / tile width"
+    best = j["kernels"]["interp"]["hbm_bytes_per_launch_corrected"]
+    PMC_CHECK["interp"] = j["kernels"]["interp"]
+    src = "committed rocprofv3 --pmc passes of this command line (%s), FETCH_SIZE x2 gfx950 correction; not re-measured in this run" % os.path.relpath(f, ROOT)
+    profiled = j.get("kernel_source_hash")
+    same = None if not profiled or not kernel_hash else profiled == kernel_hash
+    src += "; profiled kernels = this library's" if same else "; the profile is of OTHER kernel sources than this library's" if same is False else "; kernel sources of the profile not recorded"
+    PMC_CHECK["same_kernels"] = same
+    return best, src
+
+
+def sub_traffic(pkg, graph_kind, batch, tile_width, alg_bytes_per_launch, interp_ms):
+    """the counter traffic of a sub-record's interpreter launch from its own committed PMC summary (tools/collect_evidence.sh runs the
+    passes on `bench.py --config N`): keys to merge into the sub-record"""
+    j, f = find_pmc_summary(graph_kind, batch, tile_width)
+    if j is None:
+        return {"traffic": None, "traffic_source": "none: no committed PMC profile matches this graph / batch / tile width"}
+    k = j["kernels"]["interp"]
+    t = k["hbm_bytes_per_launch_corrected"]
+    profiled = j.get("kernel_source_hash")
+    return {"traffic": t, "traffic_over_algorithmic": t / alg_bytes_per_launch if alg_bytes_per_launch else None,
+            "hbm_measured_frac": t / (interp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_source": os.path.relpath(f, ROOT),
+            "traffic_kernel_hash_matches": (profiled == pkg.kernel_source_hash()) if profiled else None,
+            "profiled_avg_launch_ms": k.get("avg_duration_ms"),
+            "sq_wait_any_frac": (k["sq_wait_any_per_launch"] / k["sq_wave_cycles_per_launch"]) if k.get("sq_wave_cycles_per_launch") else None}
 
 
 PEAK = {"modmul_per_s": None}  # chip-wide one-lane Montgomery products per second measured in this run (main): the denominator of every `compute` block
-PMC_CHECK = {"same_kernels": None}  # --pmc-selfcheck: the committed PMC summary must be of the kernels this library was built from
+PMC_CHECK = {"same_kernels": None, "interp": None}  # --pmc-selfcheck: the committed PMC summary must be of the kernels this library was built from
 
 
 def cpu_baseline(graph_data, rows, d_out, n, parse_reps=3, all_cores_sets=None):

@@ -457,6 +457,8 @@ class Graph:
         res["SCAN"] = tuple(int(x) for x in out[68:72])
         res["_scan_kinds"] = {k: tuple(int(x) for x in out[72 + 4 * i:76 + 4 * i]) for i, k in enumerate(("carry", "division", "convolution", "borrow", "comparison"))}
         res["_sections"] = {"MUL": tuple(int(x) for x in out[48:54]), "LIN": tuple(int(x) for x in out[56:62])}
+        # the issue part of section 1 (reads, record refill, previous stores ISSUED; the rest of the section is the wait for the LDS reads)
+        res["_issue_part"] = {"MUL": int(out[92]), "LIN": int(out[93])}
         n = int(out[63])
         res["_waves"] = {"n": n, "max_cycles": int(out[54]), "min_cycles": (1 << 40) - int(out[55]) if n else 0,
                          "mean_cycles": int(out[62]) // n if n else 0}

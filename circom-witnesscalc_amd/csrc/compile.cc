@@ -56,12 +56,17 @@ bool compile_program(const Graph& g, uint32_t T, uint32_t divider, Program& out,
         // A fused form that cannot be scheduled must not fail the graph: the scan / convolution rewrites group nodes into one
         // bundle, and a grouping the detection should have rejected (a member that depends on another member) shows up as a
         // scheduler without ready nodes.  The program without convolution bundles, then without any scan chains, is always there.
-        if (err.find("no ready node") == std::string::npos) return false;
+        // (the scheduler's deadlock is named by ONE constant, kErrSchedulerDeadlock, here and where it is raised: rewording the message
+        // cannot turn the fallback off; when every attempt fails the LAST attempt's error is what the caller sees)
+        if (err != kErrSchedulerDeadlock) return false;
         base.no_conv = true;
         std::string err2;
         if (!compile_variant(g, T, divider, true, base, out, err2, &cache, false, streams)) {
             base.no_scans = true;
-            if (!compile_variant(g, T, divider, true, base, out, err2, &cache, false, streams)) return false;
+            if (!compile_variant(g, T, divider, true, base, out, err2, &cache, false, streams)) {
+                err = err2;
+                return false;
+            }
         }
         err.clear();
     }
@@ -780,7 +785,7 @@ static bool compile_variant(const Graph& g_in, uint32_t T, uint32_t divider, boo
                     }
                 }
                 if (best < 0) {
-                    err = "internal error: scheduler found no ready node";
+                    err = kErrSchedulerDeadlock;
                     return false;
                 }
                 // An inversion bundle costs about thirty multiplication bundles however few of its lanes are used, and a

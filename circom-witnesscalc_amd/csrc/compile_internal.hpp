@@ -87,6 +87,10 @@ static inline uint64_t node_cost(const uint32_t* table, const Node& n) {
     return n.kind == N_FUSED ? fused_cost50(n.op) : n.kind == N_SCAN ? scan_cost50(n.op) : n.kind == N_CONV ? 70u : cost_of(table, class_of(n));  // (a convolution bundle: ~3.5 k cycles)
 }
 
+// the list scheduler's "nothing is ready although nodes remain": a grouping (scan chain, convolution block) whose members depend on each other;
+// compile_program falls back to the program without such groupings on exactly this error
+static const char kErrSchedulerDeadlock[] = "internal error: scheduler found no ready node";
+
 // ---- node forms (rewrite.cc infer_representations) ----
 static const uint8_t REP_M = 0, REP_C = 1;
 static const uint8_t VF_A_CANON = 1, VF_B_CANON = 2, VF_OUT_CANON = 4;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
     asm volatile("" : "+v"(nq0), "+v"(nq1));
     const uint32_t trash_doff = p.trash_off | t16;  // (OFF_NOWHERE: dropped by the buffer range check)
     constexpr int C_PROF = 12;  // (classes with counters in the diagnostic buffer: all but C_SYNC)
-    unsigned long long pf[C_PROF][2], psec[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
+    unsigned long long pf[C_PROF][2], psec[2][7] = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}};  // psec: MUL, LIN
     unsigned long long pf_fused[2] = {0, 0};  // C_MULF (prof[64], prof[67]) / C_SCAN (prof[68], prof[71])
     unsigned long long pf_scan[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};  // scan bundles by kind: carry, division, convolution, borrow, comparison (prof[72 + 4 k], prof[75 + 4 k])
     if (PROF) {
@@ -458,6 +458,10 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         // results of bundle b-1 -> tile (unconditional: values without a slot and inactive node slots go to the tile's
         // trash slot; a fixed number of vector-memory operations per bundle is what makes the counted wait possible)
         CWC_SHADOW_ISSUE();
+        // (diagnostic build: the time at which the reads, the record refill and the stores have been ISSUED -- an s_memtime that is not waited
+        // for here (its wait would be the wait for the reads): the lgkmcnt(0) below retires it, nothing reads the register before)
+        unsigned long long st_iss = 0;
+        if (PROF) st_iss = __builtin_amdgcn_s_memtime();
         uint32_t h_n2;  // header of bundle b + 2: fetched one iteration ago (CWC_HDR_LANDING above); the next iteration's fetch follows
         unsigned long long st2 = 0, st3 = 0;
         // the wait for the LDS reads and what must follow it: every read must have completed before the staging loads overwrite
@@ -525,6 +529,7 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     q[3] += st4 - st3;    // class dispatch + arithmetic
                     q[4] += t_now - st4;  // ring write
                     q[5] += 1;
+                    q[6] += st_iss - st1;  // the issue part of section 1 (the rest of it is the wait for the LDS reads)
                 }
             }
         };
@@ -1174,6 +1179,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int q = 0; q < 6; ++q) atomicAdd(&prof[48 + 8 * k + q], psec[k][q]);
+        atomicAdd(&prof[92], psec[0][6]);
+        atomicAdd(&prof[93], psec[1][6]);
     }
     if (err_bits && set < batch) atomicOr(&status[set], err_bits);
 }

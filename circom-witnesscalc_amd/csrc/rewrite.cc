@@ -1049,6 +1049,8 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
     struct Sel { uint32_t out, acc, a, b, p, q, imm; bool nez; };
     std::vector<Sel> sels;
     static const bool sel_always = getenv("CWC_SEL_ALWAYS") && atoi(getenv("CWC_SEL_ALWAYS")) != 0;
+    // (knobs read once, not per TernCond node: 1.6 M of them in the ten-million-node RSA graph, each getenv a scan of the environment)
+    const bool no_sel_cmp = getenv("CWC_NO_SEL_CMP") != nullptr, no_sel_nez = getenv("CWC_NO_SEL_NEZ") != nullptr;
     if ((!steps.empty() || sel_always) && !getenv("CWC_NO_SEL_SCANS")) {
         for (size_t j = 0; j < N; ++j) {
             const Node& n = g.nodes[j];
@@ -1056,11 +1058,11 @@ void detect_bit_scans(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_t>&
             const Node& C = g.nodes[n.a];
             const bool ordered = C.kind == N_DUO && (C.op == OP_LT || C.op == OP_GT || C.op == OP_LEQ || C.op == OP_GEQ);
             const uint8_t want = VF_A_CANON | VF_B_CANON;
-            if (ordered && !getenv("CWC_NO_SEL_CMP") && uses[n.a] == 1 && !wit_uses[n.a] && !taken[n.a] && (vflags[n.a] & want) == want && canon(C.a) && canon(C.b)) {
+            if (ordered && !no_sel_cmp && uses[n.a] == 1 && !wit_uses[n.a] && !taken[n.a] && (vflags[n.a] & want) == want && canon(C.a) && canon(C.b)) {
                 const uint32_t code = C.op == OP_LT ? SEL_LT : C.op == OP_GT ? SEL_GT : C.op == OP_LEQ ? SEL_LEQ : SEL_GEQ;
                 sels.push_back(Sel{n.a, (uint32_t)j, C.a, C.b, n.b, n.c, code, false});
                 taken[n.a] = taken[j] = 1;
-            } else if (!getenv("CWC_NO_SEL_NEZ")) {
+            } else if (!no_sel_nez) {
                 // (the scheduler's priorities must know that the step's ACC value waits for the OUT node's operands -- compile.cc, the heights
                 // of a selection pair -- or whatever computes the condition is scheduled as if nothing waited for it: 562 bundles per
                 // multiplication of the RSA-class graph instead of 495)
@@ -1221,6 +1223,10 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
     std::vector<uint8_t> dead(N, 0), taken(N, 0);
     bool any = false;
     const bool debug = getenv("CWC_DEBUG_CONV") != nullptr;
+    const bool skip_dependency_check = getenv("CWC_CONV_SKIP_DEPENDENCY_CHECK") != nullptr;  // (the knob: tests of compile_program's fallback)
+    std::vector<uint32_t> walk_epoch;  // the dependency walk's "seen in this block" marks
+    uint32_t walk_now = 0;
+    size_t n_dependent_blocks = 0;     // complete blocks left unfused because a factor depends on the block (CWC_DEBUG_CONV prints it)
     if (debug) {
         size_t np = 0, nroot = 0, nclean = 0, nseed = 0, ncc = 0, nmul = 0;
         for (size_t i = 0; i < N; ++i) {
@@ -1303,21 +1309,23 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
                 std::sort(block.begin(), block.end());
                 block.erase(std::unique(block.begin(), block.end()), block.end());
                 auto in_block = [&](uint32_t i) { return std::binary_search(block.begin(), block.end(), i); };
-                std::vector<uint32_t> seen;
                 for (uint32_t f : X) stack.push_back(f);
                 for (uint32_t f : Y) stack.push_back(f);
-                size_t visited = 0;
-                while (!stack.empty() && ok && !getenv("CWC_CONV_SKIP_DEPENDENCY_CHECK")) {  // (the knob: tests of compile_program's fallback)
+                // every node is visited once per block (an epoch array over the whole graph: no cap on the ancestry behind first_prod, no
+                // linear search -- a block with a long ancestry used to lose its bundle silently once 4 096 nodes had been remembered)
+                if (walk_epoch.empty()) walk_epoch.assign(N, 0);
+                ++walk_now;
+                while (!stack.empty() && ok && !skip_dependency_check) {
                     const uint32_t i = stack.back();
                     stack.pop_back();
-                    if (i < first_prod || g.nodes[i].kind == N_CONST) continue;
-                    if (in_block(i) || ++visited > 100000) { ok = false; break; }  // (a walk that does not end is treated like a dependency)
-                    if (std::find(seen.begin(), seen.end(), i) != seen.end()) continue;
-                    if (seen.size() < 4096) seen.push_back(i);
+                    if (i < first_prod || g.nodes[i].kind == N_CONST || walk_epoch[i] == walk_now) continue;
+                    walk_epoch[i] = walk_now;
+                    if (in_block(i)) { ok = false; break; }
                     const Node& fn = g.nodes[i];
                     const uint32_t fops[3] = {fn.a, fn.b, fn.c};
                     for (int q = 0; q < arity_of(fn); ++q) stack.push_back(fops[q]);
                 }
+                if (!ok) ++n_dependent_blocks;
             }
             if (!ok) continue;
             // rewrite: the roots become the column nodes, everything below them dies
@@ -1340,6 +1348,7 @@ void detect_convolutions(Graph& g, std::vector<uint8_t>& rep, std::vector<uint8_
             break;
         }
     }
+    if (debug && n_dependent_blocks) fprintf(stderr, "convolutions: %zu complete block(s) left unfused (a factor depends on the block)\n", n_dependent_blocks);
     if (any) compact_dead(g, dead, rep, vflags, scan_imm, scan_partner);
 }
 

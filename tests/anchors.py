@@ -79,3 +79,51 @@ def operand_pairs(seed, n):
         b = rnd.randrange(R) if k < 0.5 else rnd.randrange(300) if k < 0.7 else (R - a) % R if k < 0.75 else a ^ rnd.randrange(1 << 20) if k < 0.8 else rnd.randrange(1 << rnd.randrange(1, 254))
         pairs.append((a, b % R))
     return pairs
+
+
+# ---- Neg, TernCond and inputs at or above r (round 6): the three semantics that rested on the two restatements agreeing with each other ----
+def neg_plain(a):
+    """UnoOperation::Neg on a canonical field element (graph.rs:188-194): 0 stays 0, anything else is r - a"""
+    return 0 if a == 0 else R - a
+
+
+def tern_plain(a, b, c):
+    """TresOperation::TernCond (graph.rs:221-225): a == 0 ? c : b -- both arms are values, nothing is evaluated lazily"""
+    return c if a == 0 else b
+
+
+def input_plain(x):
+    """graph.rs:376 `Fr::new(inputs[i])`: any 256-bit input stands for x mod r (ark-ff's Montgomery `new` multiplies by R^2 and
+    reduces; lib.rs:195-247 checks no range), and leaves as the canonical residue (graph.rs:387 `into_bigint`)"""
+    return x % R
+
+
+def uno_tres_graph():
+    """.bin bytes (pywriter) of a graph over three inputs a, b, c whose witness is [1, a, b, c, Neg a, Neg b, TernCond(a, b, c),
+    TernCond(b, c, a), TernCond(Neg a, a, b), Neg TernCond(c, a, b)]: the Input nodes themselves are witness elements, so inputs at or
+    above r show their reduction, and a selector that is r (or 2r) as an input must select like 0."""
+    from tools.graphgen.pywriter import serialize_graph
+    nodes = [("Input", 0), ("Input", 1), ("Input", 2), ("Input", 3),
+             ("Uno", "Neg", 1), ("Uno", "Neg", 2), ("Tres", "TernCond", 1, 2, 3), ("Tres", "TernCond", 2, 3, 1),
+             ("Tres", "TernCond", 4, 1, 2), ("Tres", "TernCond", 3, 1, 2), ("Uno", "Neg", 9)]
+    return serialize_graph(nodes, [0, 1, 2, 3, 4, 5, 6, 7, 8, 10], {"a": (1, 1), "b": (2, 1), "c": (3, 1)})
+
+
+def uno_tres_plain(a, b, c):
+    """the witness of uno_tres_graph for RAW inputs a, b, c < 2^256, in plain integers"""
+    ra, rb, rc = input_plain(a), input_plain(b), input_plain(c)
+    return [1, ra, rb, rc, neg_plain(ra), neg_plain(rb), tern_plain(ra, rb, rc), tern_plain(rb, rc, ra),
+            tern_plain(neg_plain(ra), ra, rb), neg_plain(tern_plain(rc, ra, rb))]
+
+
+def uno_tres_inputs(seed, n):
+    """raw input triples: every combination of the values the semantics turn on (0, 1, r - 1, r, r + 1, r + 5, 2r, 2r + 1, 2^256 - 1,
+    multiples of r below 2^256) and random ones below r / below 2^256"""
+    rnd = random.Random(seed)
+    top = (1 << 256) - 1
+    edge = [0, 1, 2, R - 1, R, R + 1, R + 5, 2 * R, 2 * R + 1, 5 * R, 5 * R + 3, top, top - 1, (top // R) * R, HALF, HALF + 1, HALF + R]
+    rows = [(a, b, c) for a in edge for b in edge[:9] for c in (0, 7, R, top)]
+    while len(rows) < n:
+        pick = lambda: rnd.choice(edge) if rnd.random() < 0.3 else rnd.randrange(R) if rnd.random() < 0.5 else rnd.randrange(1 << 256)
+        rows.append((pick(), pick(), pick()))
+    return rows

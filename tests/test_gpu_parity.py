@@ -562,6 +562,48 @@ def test_gpu_against_plain_integers_and_published_poseidon(pkg):
             assert all(cbind.array_to_ints(got[k])[1] == C.poseidon_model(rows[k][1:], circomlib=True) for k in range(1, 64))
 
 
+def test_gpu_neg_and_terncond_against_plain_integers(pkg):
+    """Neg (graph.rs:188-194: 0 -> 0, else r - a) and TernCond (graph.rs:221-225: a == 0 ? c : b) on the kernels against plain Python
+    integers (tests/anchors.py: outside both restatements), through a graph written by the independent `.bin` writer, inputs below r,
+    four program keys."""
+    import anchors
+    data = anchors.uno_tres_graph()
+    rows = [(a % anchors.R, b % anchors.R, c % anchors.R) for a, b, c in anchors.uno_tres_inputs(6, 1200)]
+    g = pkg.Graph(data)
+    inp = cbind.ints_to_array([[1, a, b, c] for a, b, c in rows])
+    for tw in (1, 4, 64, 2 | DIVIDER):
+        g.set_tile_width(tw)
+        got, st = g.calc_witness_batch(inp)
+        assert not st.any()
+        for (a, b, c), row in zip(rows, got):
+            w = cbind.array_to_ints(row)
+            assert w[4] == (0 if a == 0 else anchors.R - a) and w[5] == (0 if b == 0 else anchors.R - b), (tw, a, b)
+            assert w[6] == (c if a == 0 else b) and w[7] == (a if b == 0 else c), (tw, a, b, c)
+            assert w == anchors.uno_tres_plain(a, b, c), (tw, a, b, c)
+
+
+def test_gpu_inputs_at_or_above_r_against_plain_integers(pkg):
+    """graph.rs:376 `Fr::new(inputs[i])` on the kernels: raw inputs r, r + 5, 2r, 2^256 - 1, multiples of r ... leave as x mod r, feed
+    Neg as x mod r and select like their residue (r as a selector = 0) -- against plain Python integers, four program keys; the
+    single-call symbol with the same values as decimal strings in the inputs JSON gives the same `.wtns` rows."""
+    import anchors
+    data = anchors.uno_tres_graph()
+    rows = anchors.uno_tres_inputs(7, 1200)
+    assert sum(1 for r in rows if max(r) >= anchors.R) > 400
+    g = pkg.Graph(data)
+    inp = cbind.ints_to_array([[1, a, b, c] for a, b, c in rows])
+    for tw in (1, 4, 64, 2 | DIVIDER):
+        g.set_tile_width(tw)
+        got, st = g.calc_witness_batch(inp)
+        assert not st.any()
+        for (a, b, c), row in zip(rows, got):
+            assert cbind.array_to_ints(row) == anchors.uno_tres_plain(a, b, c), (tw, a, b, c)
+    for a, b, c in [(anchors.R, 5, 9), (anchors.R + 5, anchors.R, (1 << 256) - 1), (2 * anchors.R, 2 * anchors.R + 1, 0)]:
+        wtns = pkg.calc_witness(json.dumps({"a": [str(a)], "b": str(b), "c": c if c < (1 << 64) else str(c)}), data)
+        body = wtns[76:]
+        assert [int.from_bytes(body[32 * k:32 * k + 32], "little") for k in range(len(body) // 32)] == anchors.uno_tres_plain(a, b, c)
+
+
 def test_scan_bundles_on_the_gpu(pkg):
     """Round 4, class C_SCAN: carry chains and remainder chains of limb arithmetic as loops inside one bundle (pairs of node
     slots, the accumulator moving up the wave by DPP).  Every shift / base width (word-aligned and not, up to 253), chains

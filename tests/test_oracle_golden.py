@@ -252,3 +252,28 @@ def test_oracles_against_plain_integer_semantics_and_published_poseidon():
         assert model.evaluate(nodes, [1] + list(ins), wit)[1] == want
         out, st = cbind.Graph(data).evaluate_batch(cbind.ints_to_array([[1] + list(ins)]))
         assert st[0] == 0 and cbind.array_to_ints(out[0])[1] == want
+
+
+def test_oracles_neg_terncond_and_inputs_above_r_against_plain_integers():
+    """The three semantics that had no anchor outside the two restatements (tests/anchors.py, round 6): Neg (graph.rs:188-194: 0 -> 0,
+    else r - a), TernCond (graph.rs:221-225: a == 0 ? c : b) and the reduction of inputs at or above r (graph.rs:376: r, r + 5, 2r,
+    2^256 - 1 ... stand for x mod r; a selector that arrives as r selects like 0) -- a graph written by the independent `.bin` writer,
+    raw input triples against plain Python integers, on both oracles."""
+    import anchors
+    from oracle import cbind
+    data = anchors.uno_tres_graph()
+    nodes, wit, _ = model.deserialize_witnesscalc_graph(data)
+    og = cbind.Graph(data)
+    rows = anchors.uno_tres_inputs(5, 1500)
+    assert any(a >= anchors.R for a, _, _ in rows) and any(a % anchors.R == 0 and a for a, _, _ in rows)
+    out, st = og.evaluate_batch(cbind.ints_to_array([[1, a, b, c] for a, b, c in rows]))
+    assert not st.any()
+    for (a, b, c), row in zip(rows, out):
+        want = anchors.uno_tres_plain(a, b, c)
+        assert cbind.array_to_ints(row) == want, (a, b, c)
+    for a, b, c in rows[::7]:
+        assert model.evaluate(nodes, [1, a, b, c], wit) == anchors.uno_tres_plain(a, b, c), (a, b, c)
+    # known answers spelled out (not through the helper): Neg 0 = 0, Neg 1 = r - 1; r as a selector takes the else arm; 2^256 - 1 mod r
+    assert anchors.uno_tres_plain(anchors.R, 5, 9)[1:8] == [0, 5, 9, 0, anchors.R - 5, 9, 9]
+    assert anchors.uno_tres_plain(1, 0, 9)[4:8] == [anchors.R - 1, 0, 0, 1]
+    assert anchors.input_plain((1 << 256) - 1) == 6350874878119819312338956282401532410528162663560392320966563075034087161850

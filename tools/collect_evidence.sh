@@ -19,6 +19,15 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$R -o runc -- $BENCH > $O/pmc_fetch_$
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$R -o runc -- $BENCH > $O/pmc_write_$R.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
     -d $O/pmc_sq_$R -o runc -- $BENCH > $O/pmc_sq_$R.log 2>&1
+# the other BASELINE configurations as the timed metric: kernel trace + the three counter passes each (tools/profile_summary.py --tag configN)
+for C in 3 4 5; do
+  CB="python3 bench.py --config $C --steps 5 --warmup 1 --cpu-sample 0 --extras 0"
+  rocprofv3 --kernel-trace --stats -d $O/prof_${R}_config$C -o runc -- $CB > $O/prof_${R}_config$C.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_${R}_config$C -o runc -- $CB > $O/pmc_fetch_${R}_config$C.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_${R}_config$C -o runc -- $CB > $O/pmc_write_${R}_config$C.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+      -d $O/pmc_sq_${R}_config$C -o runc -- $CB > $O/pmc_sq_${R}_config$C.log 2>&1
+done
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_icache_$R -o runc -- $BENCH > $O/pmc_icache_$R.log 2>&1
 rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ SQ_INSTS_SMEM -d $O/pmc_dcache_$R -o runc -- $BENCH > $O/pmc_dcache_$R.log 2>&1
 python tools/pmc_cache_summary.py $R > $O/cache_counters_$R.log 2>&1

@@ -39,6 +39,7 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
     tiles = (B + (tw & 0xff) - 1) // (tw & 0xff)
     nw = max(1, tiles // 64 + (1 if tiles % 64 else 0))
     sections = prof.pop("_sections")
+    issue_part = prof.pop("_issue_part", {})
     scan_kinds = prof.pop("_scan_kinds")
     wv = prof.pop("_waves")
     tot = sum(v[0] for v in prof.values())
@@ -54,3 +55,6 @@ for tw in [int(x) for x in os.environ.get("PROBE_T", "1,4,64").split(",")]:
         if v[5]:
             print("   %s sections (cycles/bundle, each includes one ~40-cycle stamp): top+vmcnt wait %.0f | LDS reads + previous stores %.0f | staging issue %.0f | arithmetic %.0f | ring write %.0f" % (
                 (k,) + tuple(x / v[5] for x in v[:5])))
+            if issue_part.get(k):
+                print("   %s section 2 split (one stamp in it, not waited for): reads + record refill + previous stores issued after %.0f cycles | wait for the LDS reads %.0f" % (
+                    k, issue_part[k] / v[5], (v[1] - issue_part[k]) / v[5]))

@@ -26,20 +26,24 @@ def main():
     ap.add_argument("round")
     ap.add_argument("--graph", default="authv2")
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--tag", default="", help="passes of another bench command line (tools/collect_evidence.sh: config3, config4, config5): reads gpurun_out/*_<round>_<tag>, "
+                                              "writes profiles/<round>_*_<tag>.*")
+    ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0")
     a = ap.parse_args()
     r = a.round
+    sfx = ("_" + a.tag) if a.tag else ""
     out = os.path.join(ROOT, "profiles")
     # ---- kernel trace + stats ----
-    con = db("prof_%s" % r)
+    con = db("prof_%s%s" % (r, sfx))
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    with open(os.path.join(out, "%s_bench_kernel_stats.csv" % r), "w", newline="") as f:
+    with open(os.path.join(out, "%s_bench_kernel_stats%s.csv" % (r, sfx)), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
         for n, c, t, avg, pct in rows:
             w.writerow([n, c, "%.3f" % t, "%.3f" % avg, "%.4f" % pct])
     disp = list(con.execute("select name, dispatch_id, start, end, duration, grid_x, grid_y, workgroup_x, workgroup_y, "
                             "lds_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels order by start"))
-    with open(os.path.join(out, "%s_bench_kernel_trace_cwc.csv" % r), "w", newline="") as f:
+    with open(os.path.join(out, "%s_bench_kernel_trace_cwc%s.csv" % (r, sfx)), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Kernel_Name", "Dispatch_Id", "Start_ns", "End_ns", "Duration_ns", "Grid_X", "Grid_Y", "Workgroup_X",
                     "Workgroup_Y", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"])
@@ -58,7 +62,7 @@ def main():
     summary = {"config": {"graph": a.graph, "batch_per_gpu": a.batch, "tile_width": tile, "interpreter_waves_per_divider_wave": divider},
                "kernel_source_hash": ksrc,
                "source": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* passes of "
-                         "`python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0`, one pass per command",
+                         "`%s`, one pass per command" % a.cmd,
                "kernels": {"interp": {"name": interp[0][0].split("(")[0], "launches": len(interp),
                                       "avg_duration_ms": sum(d[4] for d in interp) / len(interp) / 1e6,
                                       "vgpr": interp[0][10], "sgpr": interp[0][12], "lds_bytes": interp[0][9],
@@ -75,9 +79,9 @@ def main():
                 if ours(x[0]):
                     w.writerow([x[0].split("(")[0]] + list(x[1:]))
         return [x for x in rows if ours(x[0])]
-    fetch = counters("pmc_fetch_%s" % r, "%s_bench_pmc_fetch_size.csv" % r)
-    write = counters("pmc_write_%s" % r, "%s_bench_pmc_write_size.csv" % r)
-    sq = counters("pmc_sq_%s" % r, "%s_bench_pmc_sq.csv" % r)
+    fetch = counters("pmc_fetch_%s%s" % (r, sfx), "%s_bench_pmc_fetch_size%s.csv" % (r, sfx))
+    write = counters("pmc_write_%s%s" % (r, sfx), "%s_bench_pmc_write_size%s.csv" % (r, sfx))
+    sq = counters("pmc_sq_%s%s" % (r, sfx), "%s_bench_pmc_sq%s.csv" % (r, sfx))
 
     def per_launch(rows, kern, ctr):
         v = [x[3] for x in rows if kern in x[0] and x[2] == ctr]
@@ -90,7 +94,7 @@ def main():
         e["hbm_bytes_per_launch_corrected"] = (2.0 * f_kib + w_kib) * 1024.0  # FETCH_SIZE x2 on gfx950 (16 B/lane reads)
         for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
             e[c.lower() + "_per_launch"] = per_launch(sq, kern, c)
-    json.dump(summary, open(os.path.join(out, "%s_pmc_summary.json" % r), "w"), indent=1)
+    json.dump(summary, open(os.path.join(out, "%s_pmc_summary%s.json" % (r, sfx)), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
 
