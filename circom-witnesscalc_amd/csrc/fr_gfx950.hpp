@@ -682,114 +682,6 @@ FRD Fr u256_shl(const Fr& x, uint32_t n) {
 }
 
 #if defined(__HIPCC__)
-// Lane-cooperative inversion (round 5): SIXTEEN lanes -- a DPP row -- per inversion, for the requests of a divider wave that fill a
-// handful of its 64 lanes (the division ladder of a signature check: one or two divisions at a time, the critical path of small
-// batches and of the single call).  x is the same in the row's lanes; so is the result.  Lane l < 9 holds limb l (30 bits, signed)
-// of f, g, d, e.  A batch: the low limbs and the signs are broadcast (ds_bpermute from the row's lanes 0 and 8), every lane runs the
-// same 30 divsteps on them (the serial part: unchanged), then the matrix update is ONE product sum per lane and value instead of
-// nine -- 10 multiply-adds instead of 90 -- with a TWO-PASS LAZY carry between neighbour lanes (row_shl / row_shr): c = lo + hi 2^30,
-// new_l = hi_l + lo_(l+1) (the division by 2^30: lo_0 vanishes by construction), new = nlo + nhi 2^30, limb_l = nlo_l + nhi_(l-1);
-// limbs stay within (-8, 2^30 + 8) (products below 2^62), the low limb is exact (nothing comes in from below), the top limb keeps
-// its sign.  g = 0 is tested exactly (a gather and a carry from the bottom) from the fourteenth batch on; the result is gathered and
-// finished as in u256_inv_mod_r.  tests/native/inv_coop_test.cc runs the same statements with the lanes as array indices against
-// the one-lane function (20 k operands: identical results, no limb out of range, at most 19 batches).
-__device__ __forceinline__ Fr u256_inv_mod_r_coop16(const Fr& x) {
-    const int32_t M30 = 0x3fffffff;
-    const int32_t p30[9] = {0x30000001, 0x0f87d64f, 0x1b970914, 0x0cfa121e, 0x01585d28, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x3064};
-    const uint32_t pinv30 = 0x10000001u;
-    const uint32_t lane = threadIdx.x & 63u, l = lane & 15u;
-    const int row0 = (int)((lane & 48u) << 2), row8 = row0 + 32;  // byte addresses (lane * 4) of the row's lanes 0 and 8 for ds_bpermute
-    auto from_lane = [](int addr, int32_t v) -> int32_t { return __builtin_amdgcn_ds_bpermute(addr, v); };
-    int32_t pl = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) pl = l == (uint32_t)i ? p30[i] : pl;
-    int32_t dl = 0, el = l == 0u ? 1 : 0, fl = pl;
-    int32_t gl = l < 9u ? (int32_t)(u256_shr(x, 30u * (l < 9u ? l : 0u)).v[0] & (uint32_t)M30) : 0;
-    const bool top = l == 8u;
-    auto lazy = [&](int64_t c) -> int32_t {
-        const int32_t lo = (int32_t)((uint32_t)c & (uint32_t)M30);
-        const int32_t lo_next = __builtin_amdgcn_update_dpp(0, lo, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
-        const int64_t nw = sgcd_sar30(c) + (int64_t)lo_next;
-        const int32_t nlo = top ? 0 : (int32_t)((uint32_t)nw & (uint32_t)M30);
-        const int32_t nhi = top ? 0 : (int32_t)sgcd_sar30(nw);
-        const int32_t nhi_prev = __builtin_amdgcn_update_dpp(0, nhi, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-        return (top ? (int32_t)nw : nlo) + nhi_prev;
-    };
-    int32_t eta = -1;
-    for (int it = 0; it < 25; ++it) {
-        const uint32_t f0 = (uint32_t)from_lane(row0, fl), g0 = (uint32_t)from_lane(row0, gl);
-        const uint32_t d0 = (uint32_t)from_lane(row0, dl), e0 = (uint32_t)from_lane(row0, el);
-        const int32_t sd = from_lane(row8, dl) >> 31, se = from_lane(row8, el) >> 31;
-        Trans2x2 t;
-        eta = sgcd_divsteps_30_var(eta, f0, g0, t);
-        int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
-        md -= (int32_t)((pinv30 * ((uint32_t)t.u * d0 + (uint32_t)t.v * e0) + (uint32_t)md) & (uint32_t)M30);
-        me -= (int32_t)((pinv30 * ((uint32_t)t.q * d0 + (uint32_t)t.r * e0) + (uint32_t)me) & (uint32_t)M30);
-        const int64_t cf = mad_i64(t.u, fl, mad_i64(t.v, gl, 0)), cg = mad_i64(t.q, fl, mad_i64(t.r, gl, 0));
-        const int64_t cd = mad_i64(pl, md, mad_i64(t.u, dl, mad_i64(t.v, el, 0))), ce = mad_i64(pl, me, mad_i64(t.q, dl, mad_i64(t.r, el, 0)));
-        fl = lazy(cf);
-        gl = lazy(cg);
-        dl = lazy(cd);
-        el = lazy(ce);
-        if (it >= 13) {  // g == 0, exactly: every lane gathers the row's limbs and carries from the bottom
-            int64_t carry = 0;
-            bool zero = true;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int64_t v = (int64_t)from_lane(row0 + 4 * i, gl) + carry;
-                zero = zero && (i < 8 ? ((uint32_t)v & (uint32_t)M30) == 0u : v == 0);
-                carry = v >> 30;
-            }
-            if (__ballot(!zero) == 0ull) break;  // every row of the wave is done (extra batches are harmless: g = 0)
-        }
-    }
-    S30 d, f;
-    {
-        int64_t cd = 0, cf = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int64_t vd = (int64_t)from_lane(row0 + 4 * i, dl) + cd, vf = (int64_t)from_lane(row0 + 4 * i, fl) + cf;
-            d.v[i] = i < 8 ? (int32_t)((uint32_t)vd & (uint32_t)M30) : (int32_t)vd;
-            f.v[i] = i < 8 ? (int32_t)((uint32_t)vf & (uint32_t)M30) : (int32_t)vf;
-            cd = vd >> 30;
-            cf = vf >> 30;
-        }
-    }
-    const int32_t sign = f.v[8] >> 31;
-    int32_t cond_add = d.v[8] >> 31;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) d.v[i] += p30[i] & cond_add;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) d.v[i] = (d.v[i] ^ sign) - sign;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        d.v[i + 1] += d.v[i] >> 30;
-        d.v[i] &= M30;
-    }
-    cond_add = d.v[8] >> 31;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) d.v[i] += p30[i] & cond_add;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        d.v[i + 1] += d.v[i] >> 30;
-        d.v[i] &= M30;
-    }
-    Fr out;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int li = (32 * k) / 30, off = (32 * k) % 30;
-        uint64_t w = (uint64_t)(uint32_t)d.v[li] >> off;
-        w |= (uint64_t)(uint32_t)d.v[li + 1] << (30 - off);
-        if (li + 2 < 9) w |= (uint64_t)(uint32_t)d.v[li + 2] << (60 - off);
-        out.v[k] = (uint32_t)w;
-    }
-    return out;
-}
-// Montgomery in, Montgomery out, like fr_inv
-__device__ __forceinline__ Fr fr_inv_coop16(const Fr& a) {
-    const Fr r3 = Fr{{0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu}};
-    return fr_mul(u256_inv_mod_r_coop16(a), r3);
-}
 #endif
 
 FRD uint32_t u256_bitlen(const Fr& a) {

@@ -42,7 +42,6 @@ struct InterpDims {
     // streams: interpreter wave w of a workgroup evaluates bundles [stream_first[s], stream_first[s] + stream_count[s]),
     // s = w % n_streams, of tile w / n_streams (program.hpp); with divider waves, divider d serves interpreter wave d
     uint32_t n_streams, stream_first[MAX_STREAMS], stream_count[MAX_STREAMS], stream_div_requests[MAX_STREAMS], stream_cref_first[MAX_STREAMS];
-    uint32_t no_coop_inverse;  // 0 with CWC_COOP_INVERSE=1: requests of up to four divisions run the lane-cooperative inversion (off by default, see the divider wave)
 };
 static const uint32_t ST_DIVIDER_TIMEOUT = 0x80000000u;  // internal: a mailbox wait gave up (never expected)
 static const uint32_t ST_SYNC_TIMEOUT = 0x40000000u;     // internal: the wait for stream 0's post gave up (never expected)
@@ -164,28 +163,8 @@ __global__ __launch_bounds__((W > 0 ? (W + 1) * PACK : PACK) * 64) void interp_k
                     break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // (W = 1: the request's active lanes from the program as well -- a request of up to four divisions runs lane-cooperatively)
-                const uint32_t lanes_k = p.div_lanes[div_lanes_base + k];
+                const uint32_t lanes_k = p.div_lanes[div_lanes_base + k];  // (W = 1: from the program as well)
                 const uint32_t total = n_active * lanes_k;
-                if (total <= 4u && !p.no_coop_inverse) {
-                    // a handful of divisions (the ladder of a signature check: one or two at a time): a row of sixteen lanes per inversion
-                    // (fr_gfx950.hpp u256_inv_mod_r_coop16), ~0.75 of the one-lane inversion's time -- the critical path of small batches
-                    const uint32_t g = lane >> 4;
-                    const bool valid = g < total;
-                    const uint32_t w = valid ? g / lanes_k : 0u, i = valid ? g % lanes_k : 0u;
-                    char* mb = mbox_d + w * MB + 16u * i;
-                    const uint4* qa = reinterpret_cast<const uint4*>(mb);
-                    const uint4* qb = reinterpret_cast<const uint4*>(mb + 32u * ML);
-                    Fr a = fr_from_u4(qa[0], qa[ML]), b = fr_from_u4(qb[0], qb[ML]);
-                    if (!valid) b = fr_zero();
-                    const Fr inv = fr_inv_coop16(b);  // inv(0) = 0
-                    const Fr r = u256_select(u256_is_zero(b), fr_zero(), fr_mul(a, inv));
-                    if (valid && (lane & 15u) == 0u) {  // the quotient overwrites operand a
-                        uint4* qr = reinterpret_cast<uint4*>(mb);
-                        qr[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-                        qr[ML] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-                    }
-                } else
                 for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
                     const uint32_t g = g0 + lane;
                     const bool valid = g < total;
@@ -1314,11 +1293,7 @@ hipError_t launch_interp(uint32_t T, uint32_t W, uint32_t pack, uint32_t n_div_r
     const uint32_t tiles_per_wg = nw / ns;
     dim3 grid((tiles + tiles_per_wg - 1) / tiles_per_wg), block((W ? (W + 1) * pack : pack) * 64);
     const uint4* in = (const uint4*)inputs;
-    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, p.trash_off, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
-    // (off by default: 49.6 k against 52.9 k cycles per inversion on its own, and no reported number moves -- the divider waves are not
-    // waited for at 1024 sets, and below 512 the tile's slowest stream is the 64-level Merkle chain: profiles/r05_coop_inverse_ab.txt)
-    static const uint32_t no_coop = getenv("CWC_COOP_INVERSE") && atoi(getenv("CWC_COOP_INVERSE")) != 0 ? 0u : 1u;
-    dims.no_coop_inverse = no_coop;
+    InterpDims dims{p.n_bundles, p.n_slots, p.n_inputs, batch, p.n_const, n_div_requests, p.trash_off, div_lanes, ns, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (uint32_t s = 0; s < MAX_STREAMS; ++s) {
         dims.stream_first[s] = p.stream_first[s];
         dims.stream_count[s] = p.stream_count[s];

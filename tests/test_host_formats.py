@@ -1170,17 +1170,6 @@ def test_field_inversion_on_host(tmp_path, constant_time):
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout
 
 
-def test_lane_cooperative_inversion_emulated(tmp_path):
-    """The lane-cooperative inversion (fr_gfx950.hpp u256_inv_mod_r_coop16, opt-in on the GPU: CWC_COOP_INVERSE=1) with its lanes as
-    array indices on the host: identical to the one-lane inversion on 20 k operands, every limb of the lazy carry within 32 bits, the
-    exact zero test terminating within 19 batches."""
-    import subprocess
-    exe = str(tmp_path / "inv_coop_test")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "native", "inv_coop_test.cc")])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and " 0 mismatches" in out.stdout and " 0 range violations" in out.stdout, out.stdout
-
-
 def test_schedule_quality_guard(pkg):
     """The schedule of the bench workloads must not silently regress.  A wave's time is the sum of its bundles, priced per
     class with the cycles measured on MI355X (compile.cc kCycles): authV2-class at T = 2 with the divider wave 30.5 M

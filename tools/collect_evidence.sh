@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence of one code state on one MI355X box (run through gpurun from the repository root):
-#   gpurun --timeout 3600 -- 'bash tools/collect_evidence.sh r05'
+#   gpurun --timeout 3600 -- 'bash tools/collect_evidence.sh r06'
 # then, back in the container:  python tools/profile_summary.py r05  and  bash tools/copy_evidence.sh r05  (the logs named in profiles/README.md).
 # Each rocprofv3 pass is its own command with the program directly behind `--`; counter passes carry no trace domains.
-R=${1:-r05}
+R=${1:-r06}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
@@ -38,10 +38,11 @@ PROBE_GRAPH=rsa RSA_MULS=4 PROBE_B=32 PROBE_T=1,2 python tools/gpu_classprof.py 
 python tools/gpu_sweep.py > $O/sweep_$R.log 2>&1
 python tools/gpu_autopick.py > $O/autopick_$R.log 2>&1
 python tools/gpu_robustness.py > $O/robustness_$R.log 2>&1
-(cd tools/ubench && ./coop_mul) > $O/coop_mul_$R.log 2>&1
-(cd tools/ubench && timeout 120 ./scan_par_test) > $O/scan_par_$R.log 2>&1
-(cd tools/ubench && timeout 120 ./inv_coop_bench) > $O/inv_coop_$R.log 2>&1
-(cd tools/ubench && for v in r02 cxx sh32 blk; do echo "== inv_bench_$v"; timeout 120 ./inv_bench_$v; done) > $O/inv_bench_$R.log 2>&1
+# (the micro-benchmarks are built on the box, into /tmp: built binaries no longer travel with the repository)
+H="/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950"
+(cd tools/ubench && $H -o /tmp/coop_mul coop_mul.hip && /tmp/coop_mul) > $O/coop_mul_$R.log 2>&1
+(cd tools/ubench && $H -I../../circom-witnesscalc_amd/csrc -o /tmp/scan_par_test scan_par_test.hip && timeout 120 /tmp/scan_par_test) > $O/scan_par_$R.log 2>&1
+(cd tools/ubench && $H -o /tmp/inv_bench_blk inv_bench.hip && $H -DCWC_SGCD_CXX_UPDATE -o /tmp/inv_bench_cxx inv_bench.hip && for v in cxx blk; do echo "== inv_bench_$v"; timeout 120 /tmp/inv_bench_$v; done) > $O/inv_bench_$R.log 2>&1
 python tools/gpu_e2e.py > $O/e2e_$R.log 2>&1
 CWC_FUSE=1001 SOAK_SEEDS=2000 SOAK_BASE=20261004 python tools/gpu_soak.py > $O/soak_fused_$R.log 2>&1
 SOAK_KINDS=limb SOAK_SEEDS=3000 SOAK_BASE=20261104 python tools/gpu_soak.py > $O/soak_scan_$R.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/ (scratch) -> profiles/ (tracked): the logs of tools/collect_evidence.sh under their committed names
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out
 P=profiles
 cp $O/bench_$R.json $P/${R}_bench_line.json
@@ -23,7 +23,6 @@ cp $O/config5_$R.log $P/${R}_config5_10m_nodes.txt
 cp $O/config5_rsa_$R.log $P/${R}_config5_rsa_10m_nodes.txt
 cp $O/bench_config5_bigint_$R.json $P/${R}_bench_line_config5_bigint.json
 cp $O/soak_wide_$R.log $P/${R}_soak_wide.txt
-cp $O/inv_coop_$R.log $P/${R}_inv_coop_bench.txt
 cp $O/streams_$R.log $P/${R}_streams_ab.txt
 cp $O/soak_$R.log $P/${R}_soak.txt
 cp $O/soak_fused_$R.log $P/${R}_soak_fused.txt

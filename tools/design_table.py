@@ -1,8 +1,8 @@
 """Prints DESIGN.md section 5's table of current numbers from the round's committed evidence (profiles/rNN_*):
-    python tools/design_table.py r05
+    python tools/design_table.py r06
 Every row names the file its number comes from."""
 import json, os, re, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 def load(name):
     try:
@@ -21,6 +21,15 @@ if d:
     row("... SURVEY 8(d) algorithmic-byte model (`roofline.hbm`)", "%.0f GB/s of 8000 = %.3f (per step %.3f); counter traffic %.2f GB per launch = %.3f of peak, kernel hash matches: %s" % (h["achieved"], h["frac"], h["frac_step"], (rf["traffic"] or 0) / 1e9, h["hbm_measured_frac"] or 0, rf.get("traffic_kernel_hash_matches")), "bench_line.json, pmc_summary.json")
     c = rf["chain"]
     row("... floor of the execution model (`roofline.chain`)", "longest dependent chain %.2f M cycles = %.2f ms; achieved / floor **%.2f**" % (c["floor_cycles"] / 1e6, c["floor_ms"], c["achieved_over_floor"]), "bench_line.json")
+    if "hbm_frac" in rf:  # the flat scalars the driver's record keeps (round 6): the same numbers under the keys a reader of BENCH_rNN.json finds
+        row("... the same as flat keys of `roofline` (what the driver's record keeps)", "`hbm_frac` %.3f, `hbm_frac_step` %.3f, `hbm_measured_frac` %s, `traffic_over_algorithmic` %s, `chain_achieved_over_floor` %.3f, `valu_useful_issue_frac` %s, `sq_wait_any_frac` %s" % (
+            rf["hbm_frac"], rf["hbm_frac_step"], "%.3f" % rf["hbm_measured_frac"] if rf.get("hbm_measured_frac") else "-", "%.3f" % rf["traffic_over_algorithmic"] if rf.get("traffic_over_algorithmic") else "-",
+            rf["chain_achieved_over_floor"], "%.3f" % rf["valu_useful_issue_frac"] if rf.get("valu_useful_issue_frac") else "-", "%.3f" % rf["sq_wait_any_frac"] if rf.get("sq_wait_any_frac") else "-"), "bench_line.json")
+        for k in ("config3", "config4_per_gpu", "config5", "config5_rsa"):
+            if rf.get(k + "_value") is not None:
+                row("... `roofline.%s_*`" % k, "value %.1f /s, %.2f ms per step, compute_frac %s, hbm_frac %s, counter traffic / algorithmic %s" % (
+                    rf[k + "_value"], rf[k + "_ms_per_step"], "%.3f" % rf[k + "_compute_frac"] if rf.get(k + "_compute_frac") else "-", "%.3f" % rf[k + "_hbm_frac"] if rf.get(k + "_hbm_frac") else "-",
+                    "%.3f" % rf[k + "_traffic_over_algorithmic"] if rf.get(k + "_traffic_over_algorithmic") else "-"), "bench_line.json")
     cb = d.get("cpu_baseline") or {}
     if cb:
         row("... CPU baseline (C port of `evaluate()`, same sets, byte-equal)", "%.0f witnesses/s on one pinned core, %.0f on all %d" % (cb["value"], (cb.get("all_cores") or {}).get("value", 0), (cb.get("all_cores") or {}).get("cores", 0)), "bench_line.json")
@@ -51,5 +60,12 @@ for name, what in (("bench_line_config3.json", "config 3 as the timed metric"), 
     d2 = load(name)
     if d2:
         row(what, "%.1f %s, %.2f ms per step%s" % (d2["value"], d2["unit"], d2["ms_per_step"], (", rccl_ranks %s" % d2.get("rccl_ranks")) if "rccl" in name else ""), name)
+for tag, what in (("", "headline"), ("_config3", "config 3"), ("_config4", "config 4"), ("_config5", "config 5 (RSA class)")):
+    pm = load("pmc_summary%s.json" % tag)
+    if pm:
+        k = pm["kernels"]["interp"]
+        row("rocprofv3 passes, %s: `%s`" % (what, k["name"].replace("void cwc::", "")), "avg %.3f ms over %d launches; FETCH_SIZE x2 + WRITE_SIZE = %.2f GB per launch; SQ_WAIT_ANY / SQ_WAVE_CYCLES %.3f; VALU wave-instructions %.3g; kernel sources %s" % (
+            k["avg_duration_ms"], k["launches"], k["hbm_bytes_per_launch_corrected"] / 1e9, (k.get("sq_wait_any_per_launch") or 0) / max(1.0, k.get("sq_wave_cycles_per_launch") or 1.0), k.get("sq_insts_valu_per_launch") or 0,
+            (pm.get("kernel_source_hash") or "?")[:8]), "pmc_summary%s.json, bench_kernel_stats%s.csv" % (tag, tag))
 print("| what | number | evidence (profiles/) |\n|---|---|---|")
 print("\n".join(rows))
