@@ -482,7 +482,7 @@ def main():
         if rank == 0 and isinstance(out.get("config4"), dict) and "matches_single_gpu_digest" in out["config4"]:
             out["matches_single_gpu_digest"] = out["config4"]["matches_single_gpu_digest"]
     if rank == 0:
-        flatten_roofline(out)
+        flatten_roofline(out, cfg)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
@@ -494,7 +494,7 @@ def main():
 SCHEMA = 6  # (advisor, round 5) 5: roofline.bound / frac = the VALU-issue ceiling, `--config 5` = the RSA-class graph; 6: + the flat scalars below
 
 
-def flatten_roofline(out):
+def flatten_roofline(out, cfg=2):
     """The driver's record keeps only the SCALARS of `roofline`: SURVEY 8(d)'s own number (algorithmic bytes / interpreter time / 8 TB/s) and
     the other figures a reader needs therefore also sit there as flat keys, next to the nested blocks they come from (tools/design_table.py
     reads these keys)."""
@@ -515,7 +515,8 @@ def flatten_roofline(out):
     batch = out.get("config", {}).get("batch_per_gpu")
     # of the vector instructions the counters saw per launch (divider waves included), the share the arithmetic alone needs: one 322-slot
     # product per 64 lane-products
-    rf["valu_useful_issue_frac"] = (eq * batch / 64.0 * 322.0 / pmc["sq_insts_valu_per_launch"]) if pmc and eq and batch and pmc.get("sq_insts_valu_per_launch") else None
+    # (configurations 2 and 4: field products are 322-slot Montgomery products there; bit and limb graphs multiply small integers)
+    rf["valu_useful_issue_frac"] = (eq * batch / 64.0 * 322.0 / pmc["sq_insts_valu_per_launch"]) if cfg in (2, 4) and pmc and eq and batch and pmc.get("sq_insts_valu_per_launch") else None
     rf["sq_wait_any_frac"] = (pmc["sq_wait_any_per_launch"] / pmc["sq_wave_cycles_per_launch"]) if pmc and pmc.get("sq_wave_cycles_per_launch") else None
     for name in ("config3", "config4_per_gpu", "config5", "config5_rsa"):
         sub = out.get(name)

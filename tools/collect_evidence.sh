@@ -14,23 +14,32 @@ echo "$have" > $O/ksrc_$R.txt   # (tools/profile_summary.py stamps the PMC summa
 BENCH="python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0"
 python -m pytest tests -q -m gpu > $O/gputest_$R.log 2>&1; tail -1 $O/gputest_$R.log
 python bench.py > $O/bench_$R.json 2> $O/bench_$R.err
-rocprofv3 --kernel-trace --stats -d $O/prof_$R -o runc -- $BENCH > $O/prof_$R.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$R -o runc -- $BENCH > $O/pmc_fetch_$R.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$R -o runc -- $BENCH > $O/pmc_write_$R.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-    -d $O/pmc_sq_$R -o runc -- $BENCH > $O/pmc_sq_$R.log 2>&1
-# the other BASELINE configurations as the timed metric: kernel trace + the three counter passes each (tools/profile_summary.py --tag configN)
-for C in 3 4 5; do
-  CB="python3 bench.py --config $C --steps 5 --warmup 1 --cpu-sample 0 --extras 0"
-  rocprofv3 --kernel-trace --stats -d $O/prof_${R}_config$C -o runc -- $CB > $O/prof_${R}_config$C.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_${R}_config$C -o runc -- $CB > $O/pmc_fetch_${R}_config$C.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_${R}_config$C -o runc -- $CB > $O/pmc_write_${R}_config$C.log 2>&1
+# rocprofv3 passes: each its own command with the program directly behind `--`; counter passes carry no trace domains.  The rocpd databases are
+# summarised HERE (tools/profile_summary.py -> $O/summary_$R/, what gets committed under profiles/) and deleted: four configurations of them do not
+# fit the 64 MiB a lease copies back.
+S=$O/summary_$R
+mkdir -p $S
+passes() {  # $1 = tag suffix ("" or _configN), $2.. = the bench command
+  local sfx=$1; shift
+  rocprofv3 --kernel-trace --stats -d $O/prof_${R}$sfx -o runc -- "$@" > $O/prof_${R}$sfx.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_${R}$sfx -o runc -- "$@" > $O/pmc_fetch_${R}$sfx.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_${R}$sfx -o runc -- "$@" > $O/pmc_write_${R}$sfx.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-      -d $O/pmc_sq_${R}_config$C -o runc -- $CB > $O/pmc_sq_${R}_config$C.log 2>&1
-done
+      -d $O/pmc_sq_${R}$sfx -o runc -- "$@" > $O/pmc_sq_${R}$sfx.log 2>&1
+}
+passes "" $BENCH
+python tools/profile_summary.py $R --graph authv2 --batch 1024 --out $S > $O/profile_summary_$R.log 2>&1
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_icache_$R -o runc -- $BENCH > $O/pmc_icache_$R.log 2>&1
 rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ SQ_INSTS_SMEM -d $O/pmc_dcache_$R -o runc -- $BENCH > $O/pmc_dcache_$R.log 2>&1
 python tools/pmc_cache_summary.py $R > $O/cache_counters_$R.log 2>&1
+rm -rf $O/prof_$R $O/pmc_fetch_$R $O/pmc_write_$R $O/pmc_sq_$R $O/pmc_icache_$R $O/pmc_dcache_$R
+# the other BASELINE configurations as the timed metric (config 5 = the RSA-class graph, 32 sets)
+for C in 3 4 5; do
+  passes _config$C python3 bench.py --config $C --steps 5 --warmup 1 --cpu-sample 0 --extras 0
+  case $C in 3) GK="--graph sha256 --batch 4096";; 4) GK="--graph authv2 --batch 8192";; 5) GK="--graph rsa --batch 32";; esac
+  python tools/profile_summary.py $R --tag config$C $GK --cmd "python3 bench.py --config $C --steps 5 --warmup 1 --cpu-sample 0 --extras 0" --out $S > $O/profile_summary_${R}_config$C.log 2>&1
+  rm -rf $O/prof_${R}_config$C $O/pmc_fetch_${R}_config$C $O/pmc_write_${R}_config$C $O/pmc_sq_${R}_config$C
+done
 PROBE_T=258,2,4 python tools/gpu_classprof.py > $O/classprof_$R.log 2>&1
 PROBE_B=256 PROBE_T=257 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
 PROBE_GRAPH=bigint PROBE_B=32 PROBE_T=1,2 python tools/gpu_classprof.py >> $O/classprof_$R.log 2>&1
@@ -69,4 +78,4 @@ bash tools/gpu_policies.sh "X=0 --" "CWC_NO_COOP_MUL=1 --" "CWC_COOP_FILL=32 CWC
     "CWC_SCHED_MUL_COST=47 CWC_SCHED_LIN_COST=12 --" "CWC_SCHED_MUL_COST=26 CWC_SCHED_LIN_COST=14 --" "CWC_SCHED_MUL_COST=30 CWC_SCHED_LIN_COST=24 --" \
     "CWC_PACK=2 --" "CWC_PACK=2 -- --config 4" "X=0 -- --config 4" "CWC_WITNESS_SLOTS=1 -- --config 4" "X=0 -- --batch-per-gpu 256" "CWC_NO_COOP_MUL=1 -- --batch-per-gpu 256" \
     "CWC_MODEL_CYCLES=3:73500 --" "CWC_NO_FUSE=1 -- --batch-per-gpu 256" > $O/policies_$R.log 2>&1
-ls $O
+du -sh $O; for f in $O/*_$R*.log $O/*_$R*.err; do echo "== $f: $(tail -1 $f | cut -c1-200)"; done

@@ -29,10 +29,13 @@ def main():
     ap.add_argument("--tag", default="", help="passes of another bench command line (tools/collect_evidence.sh: config3, config4, config5): reads gpurun_out/*_<round>_<tag>, "
                                               "writes profiles/<round>_*_<tag>.*")
     ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --extras 0")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"), help="where the summaries go (tools/collect_evidence.sh summarises on the GPU box, into gpurun_out/summary_<round>: "
+                                                                          "the rocpd databases of four configurations do not fit what a lease copies back)")
     a = ap.parse_args()
     r = a.round
     sfx = ("_" + a.tag) if a.tag else ""
-    out = os.path.join(ROOT, "profiles")
+    out = a.out
+    os.makedirs(out, exist_ok=True)
     # ---- kernel trace + stats ----
     con = db("prof_%s%s" % (r, sfx))
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
